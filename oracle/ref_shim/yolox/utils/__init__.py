@@ -1,0 +1,83 @@
+"""Shim of yolox.utils.{bboxes_iou, postprocess} (yolox==0.3).
+
+`postprocess` needs torchvision.ops.batched_nms, which is absent: a pure-torch greedy NMS with
+torchvision's semantics (score-descending, suppress iff IoU > thr, class offset trick) stands in.
+Reference call sites: exps/model/tal_head.py:11,398,526; exps/evaluators/onex_stream_evaluator.py:148.
+"""
+import torch
+
+
+def bboxes_iou(bboxes_a, bboxes_b, xyxy=True):
+    if bboxes_a.shape[1] != 4 or bboxes_b.shape[1] != 4:
+        raise IndexError
+    if xyxy:
+        tl = torch.max(bboxes_a[:, None, :2], bboxes_b[:, :2])
+        br = torch.min(bboxes_a[:, None, 2:], bboxes_b[:, 2:])
+        area_a = torch.prod(bboxes_a[:, 2:] - bboxes_a[:, :2], 1)
+        area_b = torch.prod(bboxes_b[:, 2:] - bboxes_b[:, :2], 1)
+    else:
+        tl = torch.max(bboxes_a[:, None, :2] - bboxes_a[:, None, 2:] / 2,
+                       bboxes_b[:, :2] - bboxes_b[:, 2:] / 2)
+        br = torch.min(bboxes_a[:, None, :2] + bboxes_a[:, None, 2:] / 2,
+                       bboxes_b[:, :2] + bboxes_b[:, 2:] / 2)
+        area_a = torch.prod(bboxes_a[:, 2:], 1)
+        area_b = torch.prod(bboxes_b[:, 2:], 1)
+    en = (tl < br).type(tl.type()).prod(dim=2)
+    area_i = torch.prod(br - tl, 2) * en
+    return area_i / (area_a[:, None] + area_b - area_i)
+
+
+def _nms(boxes, scores, thr):
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    n = b.shape[0]
+    dead = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if dead[i]:
+            continue
+        keep.append(i)
+        if i + 1 < n:
+            lt = torch.max(b[i, :2], b[i + 1:, :2])
+            rb = torch.min(b[i, 2:], b[i + 1:, 2:])
+            wh = (rb - lt).clamp(min=0)
+            inter = wh[:, 0] * wh[:, 1]
+            iou = inter / (area[i] + area[i + 1:] - inter)
+            dead[i + 1:] |= iou > thr
+    return order[torch.tensor(keep, dtype=torch.long)]
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return _nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
+    box_corner = prediction.new(prediction.shape)
+    box_corner[:, :, 0] = prediction[:, :, 0] - prediction[:, :, 2] / 2
+    box_corner[:, :, 1] = prediction[:, :, 1] - prediction[:, :, 3] / 2
+    box_corner[:, :, 2] = prediction[:, :, 0] + prediction[:, :, 2] / 2
+    box_corner[:, :, 3] = prediction[:, :, 1] + prediction[:, :, 3] / 2
+    prediction[:, :, :4] = box_corner[:, :, :4]
+    output = [None for _ in range(len(prediction))]
+    for i, image_pred in enumerate(prediction):
+        if not image_pred.size(0):
+            continue
+        class_conf, class_pred = torch.max(image_pred[:, 5:5 + num_classes], 1, keepdim=True)
+        conf_mask = (image_pred[:, 4] * class_conf.squeeze() >= conf_thre).squeeze()
+        detections = torch.cat((image_pred[:, :5], class_conf, class_pred.float()), 1)
+        detections = detections[conf_mask]
+        if not detections.size(0):
+            continue
+        if class_agnostic:
+            keep = _nms(detections[:, :4], detections[:, 4] * detections[:, 5], nms_thre)
+        else:
+            keep = batched_nms(detections[:, :4], detections[:, 4] * detections[:, 5],
+                               detections[:, 6], nms_thre)
+        detections = detections[keep]
+        output[i] = detections if output[i] is None else torch.cat((output[i], detections))
+    return output
