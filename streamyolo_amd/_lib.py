@@ -1,0 +1,127 @@
+"""ctypes binding of libstreamyolo_hip.so (C ABI: include/streamyolo_hip.h).
+
+The product path has exactly one implementation: the hand-written gfx950 kernels in this shared
+library.  If it is missing the package fails loudly — there is no eager / CPU fallback
+(build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C streamyolo_amd/csrc`).
+
+`use_library(path)` exists for the test-suite only: tests/emu builds the SAME kernel sources for
+the host with a lock-step SIMT emulator so that indexing logic can be checked in a GPU-less
+container.  Nothing in the package ever selects it on its own.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "lib", "libstreamyolo_hip.so")
+
+DT_BF16, DT_F16, DT_F32 = 0, 1, 2
+EPI_LINEAR, EPI_SILU, EPI_SIGMOID, EPI_DECODE = 0, 1, 2, 3
+CONV_FWD, CONV_DGRAD = 0, 1
+
+_ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape"}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("res", C.c_void_p), ("y", C.c_void_p), ("stat_sum", C.c_void_p), ("stat_sqsum", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
+        ("xbs", C.c_int64), ("ybs", C.c_int64), ("rbs", C.c_int64),
+        ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
+        ("accumulate", C.c_int32), ("dec_stride", C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("ldx", C.c_int32), ("lddy", C.c_int32), ("xbs", C.c_int64), ("dybs", C.c_int64),
+        ("dtype", C.c_int32),
+    ]
+
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> (restype, argtypes).  Must list every symbol include/streamyolo_hip.h declares
+# (tests/test_abi.py parses the header and checks both directions).
+SIGNATURES = {
+    "sy_conv2d": (_I, [C.POINTER(ConvDesc), _P]),
+    "sy_conv2d_wgrad": (_I, [C.POINTER(WgradDesc), _P]),
+    "sy_focus_pack": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "sy_resize_nearest": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _I, _I, _L, _I, _P]),
+    "sy_resize_nearest_bwd": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _I, _I, _L, _I, _I, _P]),
+    "sy_spp_pool": (_I, [_P, _I, _I, _I, _I, _I, _L, _I, _P]),
+    "sy_spp_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
+    "sy_postprocess_workspace_bytes": (_L, [_I, _I]),
+    "sy_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
+    "sy_bn_finalize": (_I, [_P, _P, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "sy_bn_silu_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
+    "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _I, _P]),
+    "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),
+    "sy_version": (C.c_char_p, []),
+    "sy_abi_version": (_I, []),
+}
+
+_lib = None
+_lib_path = None
+
+
+def _bind(path):
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            "streamyolo_amd: %s not found. The MI355X kernels are the ONLY implementation of this "
+            "package (no CPU/eager fallback). Build them: make -C streamyolo_amd/csrc" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError("streamyolo_amd: %s lacks symbol %s (stale build?)" % (path, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sy_abi_version() != 1:
+        raise HipLibraryError("streamyolo_amd: ABI version mismatch in %s" % path)
+    return lib
+
+
+def lib():
+    """The bound library (loads libstreamyolo_hip.so on first use; raises HipLibraryError if absent)."""
+    global _lib, _lib_path
+    if _lib is None:
+        _lib = _bind(DEFAULT_PATH)
+        _lib_path = DEFAULT_PATH
+    return _lib
+
+
+def use_library(path):
+    """TEST-SUITE ONLY: bind an explicitly named build of the kernel sources (e.g. the SIMT-emulator
+    build under tests/emu/_build).  Never called by the package itself."""
+    global _lib, _lib_path
+    _lib = _bind(path)
+    _lib_path = path
+    return _lib
+
+
+def library_path():
+    lib()
+    return _lib_path
+
+
+def is_emulator():
+    return b"EMULATOR" in lib().sy_version()
+
+
+def check(status, what):
+    if status != 0:
+        raise HipLibraryError("streamyolo_amd: %s failed: %s (status %d)" % (what, _ERR.get(status, "?"), status))

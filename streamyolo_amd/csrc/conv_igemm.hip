@@ -1,0 +1,368 @@
+// conv_igemm.hip — NHWC implicit-GEMM convolution on the CDNA4 matrix cores, fused epilogue.
+//
+// Replaces (reference, per call): nn.Conv2d -> nn.BatchNorm2d -> nn.SiLU of yolox BaseConv, three
+// cuDNN/ATen kernels plus the cat/add kernels around them.
+//
+// GEMM view:  D[co][p] = sum_k Wp[co][k] * X[p][k],   k = (tap, ci),  p = (n, ho, wo)
+//   * MFMA "A/row" operand = packed weights [Cout][K] (K-contiguous), "B/col" operand = pixels:
+//     each lane then owns 4 CONSECUTIVE output channels of one pixel per accumulator quad, so the
+//     epilogue stores 8 B (16-bit types) / 16 B (fp32) per lane straight from registers — NHWC
+//     output needs no LDS transpose.
+//   * K is walked in 64-byte slabs per row (32 bf16/f16 or 16 fp32 elements): 16-byte coalesced
+//     global loads (8 / 4 channels of one tap), staged in LDS with an 80-byte row pitch (conflict
+//     free for ds_read_b128: 5 is odd), register prefetch of slab t+1 while slab t feeds the MFMAs.
+//   * wave64: 4 waves per workgroup arranged WC x WP over (channels x pixels); each wave owns
+//     TC x TP accumulator tiles of 32x32 (16 fp32 registers each).
+//   * gather modes: forward (stride 1/2, zero padding) and data-gradient (transposed conv);
+//     chunks are predicated per 16 bytes so Cin only has to be a multiple of 8 (4 for fp32).
+//   * epilogue (all fp32): z = acc*scale[co] + shift[co]; linear | SiLU | sigmoid | box decode;
+//     optional residual add, optional += into the destination, optional per-channel sum / sum of
+//     squares of the raw accumulator for training-mode BatchNorm (wave shuffle reduction, then
+//     one atomic per channel per wave).
+#include "sy_device.h"
+#include "../../include/streamyolo_hip.h"
+
+namespace {
+
+struct ConvArgs {
+    const unsigned char* x;
+    const unsigned char* w;
+    const float* scale;
+    const float* shift;
+    const unsigned char* res;
+    unsigned char* y;
+    float* stat_sum;
+    float* stat_sq;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int ldx, ldy, ldr;
+    long long xbs, ybs, rbs;
+    int y_f32, mode, epilogue, accumulate;
+    float dec_stride;
+    int M, K, HoWo;
+};
+
+constexpr int kPitch = 80;          // LDS row pitch in bytes: 64 B of K + 16 B pad
+constexpr int kThreads = 256;
+
+template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
+    typedef typename T::elem elem;
+    constexpr int EPC = T::kEPC;                 // elements per 16-byte chunk
+    constexpr int ESZ = 16 / EPC;                // bytes per element
+    constexpr int BK = 4 * EPC;                  // elements per 64-byte K slab
+    constexpr int CT = WC * TC * 32;             // channels per workgroup
+    constexpr int PT = WP * TP * 32;             // pixels per workgroup
+    constexpr int WCH = (CT * 4 + kThreads - 1) / kThreads;   // weight chunks per thread per slab
+    constexpr int XCH = (PT * 4 + kThreads - 1) / kThreads;   // pixel chunks per thread per slab
+    static_assert(WC * WP == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) unsigned char sW[CT * kPitch];
+    __shared__ __attribute__((aligned(16))) unsigned char sX[PT * kPitch];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave / WP;
+    const int wp = wave % WP;
+    const int c0 = blockIdx.x * CT;
+    const int m0 = blockIdx.y * PT;
+
+    // ---- staging assignment: chunk id = tid + i*256 -> (row = id>>2, kc = id&3); kc is the same
+    //      for every chunk of a thread, so (tap, ci) is tracked once per thread.
+    const int kc = tid & 3;
+    const int row0 = tid >> 2;
+
+    // pixel rows handled by this thread
+    int px_h0[XCH], px_w0[XCH];
+    long long px_base[XCH];
+    bool px_ok[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int r = row0 + i * 64;
+        const int m = m0 + r;
+        const bool ok = (r < PT) && (m < p.M);
+        const int mm = ok ? m : 0;
+        const int n = mm / p.HoWo;
+        const int rem = mm - n * p.HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        px_ok[i] = ok;
+        px_base[i] = (long long)n * p.xbs;
+        if (p.mode == SY_CONV_FWD) {
+            px_h0[i] = ho * p.stride - p.pad;
+            px_w0[i] = wo * p.stride - p.pad;
+        } else {
+            px_h0[i] = ho + p.pad;
+            px_w0[i] = wo + p.pad;
+        }
+    }
+
+    int k_el = kc * EPC;            // this thread's element offset inside the current slab's K range
+    int tap = k_el / p.Cin;
+    int ci = k_el - tap * p.Cin;
+
+    uint4 rw[WCH], rx[XCH];
+
+    auto load_slab = [&]() {
+        const bool k_ok = k_el < p.K;
+        // weights: row-major [Cout][K]
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int r = row0 + i * 64;
+            const int co = c0 + r;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (k_ok && r < CT && co < p.Cout)
+                v = *reinterpret_cast<const uint4*>(p.w + ((long long)co * p.K + k_el) * ESZ);
+            rw[i] = v;
+        }
+        const int kh = tap / p.KW;
+        const int kw = tap - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            int hi, wi;
+            bool ok = k_ok && px_ok[i];
+            if (p.mode == SY_CONV_FWD) {
+                hi = px_h0[i] + kh;
+                wi = px_w0[i] + kw;
+            } else {
+                hi = px_h0[i] - kh;
+                wi = px_w0[i] - kw;
+                if (p.stride == 2) {
+                    ok = ok && ((hi & 1) == 0) && ((wi & 1) == 0);
+                    hi >>= 1;
+                    wi >>= 1;
+                }
+            }
+            ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok)
+                v = *reinterpret_cast<const uint4*>(
+                    p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ);
+            rx[i] = v;
+        }
+    };
+    auto advance_k = [&]() {
+        k_el += BK;
+        ci += BK;
+        while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int r = row0 + i * 64;
+            if (r < CT) *reinterpret_cast<uint4*>(sW + r * kPitch + kc * 16) = rw[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int r = row0 + i * 64;
+            if (r < PT) *reinterpret_cast<uint4*>(sX + r * kPitch + kc * 16) = rx[i];
+        }
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int u = 0; u < TP; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    const int nslab = (p.K + BK - 1) / BK;
+    const int l31 = lane & 31;
+    const int hi16 = (lane >> 5) * 16;
+
+    load_slab();
+    store_slab();
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const bool more = (s + 1 < nslab);
+        if (more) { advance_k(); load_slab(); }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 a[TC], b[TP];
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+                a[t] = *reinterpret_cast<const uint4*>(sW + ((wc * TC + t) * 32 + l31) * kPitch + g * 32 + hi16);
+#pragma unroll
+            for (int u = 0; u < TP; ++u)
+                b[u] = *reinterpret_cast<const uint4*>(sX + ((wp * TP + u) * 32 + l31) * kPitch + g * 32 + hi16);
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
+        }
+        __syncthreads();
+        if (more) {
+            store_slab();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    const int half = lane >> 5;
+    const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
+                        (p.res == nullptr || (p.ldr & 3) == 0);
+    const bool want_stats = (p.stat_sum != nullptr);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+        float ssum[16], ssq[16];
+        if (want_stats) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+        }
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            const int m = m0 + (wp * TP + u) * 32 + l31;
+            const bool m_ok = m < p.M;
+            const int mm = m_ok ? m : 0;
+            const int n = mm / p.HoWo;
+            const int rem = mm - n * p.HoWo;
+            const long long yoff = (long long)n * p.ybs + (long long)rem * p.ldy;
+            const long long roff = (long long)n * p.rbs + (long long)rem * p.ldr;
+            int gy = 0, gx = 0;
+            if (p.epilogue == SY_EPI_DECODE) { gy = rem / p.Wo; gx = rem - gy * p.Wo; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cb = c0 + (wc * TC + t) * 32 + q * 8 + half * 4;   // first of 4 channels
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[t][u][q * 4 + j];
+                    if (want_stats) { ssum[q * 4 + j] += a; ssq[q * 4 + j] += a * a; }
+                    const int co = cb + j;
+                    const float sc = (p.scale != nullptr && co < p.Cout) ? p.scale[co] : 1.0f;
+                    const float sh = (p.shift != nullptr && co < p.Cout) ? p.shift[co] : 0.0f;
+                    float z = a * sc + sh;
+                    if (p.epilogue == SY_EPI_SILU) z = sy_silu(z);
+                    else if (p.epilogue == SY_EPI_SIGMOID) z = sy_sigmoid(z);
+                    else if (p.epilogue == SY_EPI_DECODE) {
+                        if (co == 0) z = (z + (float)gx) * p.dec_stride;
+                        else if (co == 1) z = (z + (float)gy) * p.dec_stride;
+                        else if (co == 2 || co == 3) z = sy_exp(z) * p.dec_stride;
+                        else z = sy_sigmoid(z);
+                    }
+                    v[j] = z;
+                }
+                if (!m_ok || cb >= p.Cout) continue;
+                if (vec_ok) {
+                    if (p.res != nullptr) {
+                        const elem* rp = reinterpret_cast<const elem*>(p.res) + roff + cb;
+                        if (ESZ == 2) {
+                            uint2 rv = *reinterpret_cast<const uint2*>(rp);
+                            elem e[4];
+                            __builtin_memcpy(e, &rv, 8);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += T::to_f32(e[j]);
+                        } else {
+                            float4 rv = *reinterpret_cast<const float4*>(rp);
+                            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                        }
+                    }
+                    if (p.y_f32 || ESZ == 4) {
+                        float* yp = reinterpret_cast<float*>(p.y) + yoff + cb;
+                        if (p.accumulate) {
+                            float4 o = *reinterpret_cast<const float4*>(yp);
+                            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                        }
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        elem* yp = reinterpret_cast<elem*>(p.y) + yoff + cb;
+                        elem e[4];
+                        if (p.accumulate) {
+                            uint2 o = *reinterpret_cast<const uint2*>(yp);
+                            __builtin_memcpy(e, &o, 8);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += T::to_f32(e[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e[j] = T::from_f32(v[j]);
+                        uint2 o;
+                        __builtin_memcpy(&o, e, 8);
+                        *reinterpret_cast<uint2*>(yp) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = cb + j;
+                        if (co >= p.Cout) continue;
+                        float z = v[j];
+                        if (p.res != nullptr) z += T::to_f32(reinterpret_cast<const elem*>(p.res)[roff + co]);
+                        if (p.y_f32 || ESZ == 4) {
+                            float* yp = reinterpret_cast<float*>(p.y) + yoff + co;
+                            if (p.accumulate) z += *yp;
+                            *yp = z;
+                        } else {
+                            elem* yp = reinterpret_cast<elem*>(p.y) + yoff + co;
+                            if (p.accumulate) z += T::to_f32(*yp);
+                            *yp = T::from_f32(z);
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            // reduce over the 32 pixels held by lanes with equal `half`, then one atomic per channel
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = ssum[r], b = ssq[r];
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    a += __shfl_xor(a, off);
+                    b += __shfl_xor(b, off);
+                }
+                const int co = c0 + (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
+                if (l31 == 0 && co < p.Cout) {
+                    atomicAdd(p.stat_sum + co, a);
+                    atomicAdd(p.stat_sq + co, b);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int WC, int WP, int TC, int TP>
+int launch_cfg(const ConvArgs& a, void* stream) {
+    constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
+    dim3 grid((a.Cout + CT - 1) / CT, (a.M + PT - 1) / PT, 1);
+    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(kThreads), 0, stream, a);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_typed(const ConvArgs& a, void* stream) {
+    // tile choice by output-channel count: wide layers 128ch x 128px, narrow ones trade channels for pixels
+    if (a.Cout > 64) return launch_cfg<T, 2, 2, 2, 2>(a, stream);       // 128 ch x 128 px
+    if (a.Cout > 32) return launch_cfg<T, 1, 4, 2, 2>(a, stream);       //  64 ch x 256 px
+    return launch_cfg<T, 1, 4, 1, 2>(a, stream);                        //  32 ch x 256 px
+}
+
+}  // namespace
+
+extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
+    if (d == nullptr || d->x == nullptr || d->w == nullptr || d->y == nullptr) return SY_ERR_ARG;
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return SY_ERR_ARG;
+    if (d->dtype < SY_DT_BF16 || d->dtype > SY_DT_F32) return SY_ERR_ARG;
+    const int epc = d->dtype == SY_DT_F32 ? 4 : 8;
+    // 16-byte chunks must never straddle a tap or a pixel
+    if (d->Cin % epc != 0 || d->ldx % epc != 0) return SY_ERR_UNSUPPORTED;
+    if (d->stride != 1 && d->stride != 2) return SY_ERR_UNSUPPORTED;
+    if (d->KH < 1 || d->KW < 1 || d->KH * d->KW > 49) return SY_ERR_UNSUPPORTED;
+    if ((d->stat_sum == nullptr) != (d->stat_sqsum == nullptr)) return SY_ERR_ARG;
+    if (d->epilogue < SY_EPI_LINEAR || d->epilogue > SY_EPI_DECODE) return SY_ERR_ARG;
+    if ((long long)d->N * d->Ho * d->Wo > 0x7fffffffLL) return SY_ERR_UNSUPPORTED;
+    ConvArgs a;
+    a.x = (const unsigned char*)d->x; a.w = (const unsigned char*)d->w;
+    a.scale = d->scale; a.shift = d->shift; a.res = (const unsigned char*)d->res; a.y = (unsigned char*)d->y;
+    a.stat_sum = d->stat_sum; a.stat_sq = d->stat_sqsum;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.xbs = d->xbs; a.ybs = d->ybs; a.rbs = d->rbs;
+    a.y_f32 = d->y_f32; a.mode = d->mode; a.epilogue = d->epilogue; a.accumulate = d->accumulate;
+    a.dec_stride = d->dec_stride;
+    a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
+    switch (d->dtype) {
+        case SY_DT_BF16: return launch_typed<BF16>(a, stream);
+        case SY_DT_F16: return launch_typed<F16>(a, stream);
+        default: return launch_typed<F32>(a, stream);
+    }
+}

@@ -1,0 +1,286 @@
+// conv_wgrad.hip — convolution weight gradient on the CDNA4 matrix cores.
+//
+// Replaces cuDNN backward-filter under autograd (reference: loss.backward() in
+// exps/train_utils/double_trainer.py:114).
+//
+// GEMM view:  dW[co][k] += sum_p  dY[p][co] * X[gather(p, tap)][ci],    k = (tap, ci)
+// The contraction index is the PIXEL, which is the slow axis of both NHWC operands, so both tiles
+// are transposed on their way into LDS: a lane loads 16 bytes (8 / 4 consecutive channels of one
+// pixel) and scatters them as 32-bit words into channel-major rows [channel][pixel] (two adjacent
+// pixels are packed per word for 16-bit types).  Row pitch 72 B: the scatter is at most 2-way bank
+// conflicted (free on ds_write_b32) and the MFMA fragments read back as conflict-free ds_read_b64.
+//   rows  (MFMA A operand) = X^T : (tap, ci)      cols (MFMA B operand) = dY^T : co
+// so a lane's accumulator quad is 4 consecutive k of one co = 4 consecutive floats of dW[co][:].
+// The pixel range is split over gridDim.z; partial tiles are combined with fp32 atomics into dW,
+// which also sums the current-frame and support-frame passes of the shared backbone weights
+// (SURVEY.md §8(e)); the caller zeroes the gradient arena once per step.
+#include "sy_device.h"
+#include "../../include/streamyolo_hip.h"
+
+namespace {
+
+struct WgradArgs {
+    const unsigned char* x;
+    const unsigned char* dy;
+    float* dw;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int ldx, lddy;
+    long long xbs, dybs;
+    int M, K, slabs_per_split;
+};
+
+constexpr int kPitchT = 72;
+constexpr int kThreadsW = 256;
+
+struct PixelCursor {            // (n, ho, wo) of one output pixel, advanced slab by slab
+    int n, ho, wo, m;
+    __device__ __forceinline__ void init(int m_, int Ho, int Wo) {
+        m = m_;
+        const int hw = Ho * Wo;
+        n = m_ / hw;
+        const int rem = m_ - n * hw;
+        ho = rem / Wo;
+        wo = rem - ho * Wo;
+    }
+    __device__ __forceinline__ void advance(int step, int Ho, int Wo) {
+        m += step;
+        wo += step;
+        while (wo >= Wo) {
+            wo -= Wo;
+            if (++ho == Ho) { ho = 0; ++n; }
+        }
+    }
+};
+
+template <typename T, int WR, int WC, int TR, int TC>
+__global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
+    typedef typename T::elem elem;
+    constexpr int EPC = T::kEPC;
+    constexpr int ESZ = 16 / EPC;
+    constexpr int SLAB = 4 * EPC;                 // pixels per slab (64 bytes per transposed row)
+    constexpr int PPU = (ESZ == 2) ? 2 : 1;       // pixels per staging unit (pair-packed for 16-bit)
+    constexpr int SLOTS = SLAB / PPU;             // 16 pixel slots per slab
+    constexpr int RT = WR * TR * 32;              // rows: (tap, ci)
+    constexpr int CT = WC * TC * 32;              // cols: co
+    constexpr int UA = ((RT / EPC) * SLOTS + kThreadsW - 1) / kThreadsW;
+    constexpr int UB = ((CT / EPC) * SLOTS + kThreadsW - 1) / kThreadsW;
+    static_assert(WR * WC == 4, "4 waves per workgroup");
+    static_assert(SLOTS == 16, "slot arithmetic below assumes 16 slots");
+
+    __shared__ __attribute__((aligned(16))) unsigned char sA[RT * kPitchT];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[CT * kPitchT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WC;
+    const int wcn = wave % WC;
+    const int r0 = blockIdx.x * RT;
+    const int c0 = blockIdx.y * CT;
+    const int slab0 = blockIdx.z * p.slabs_per_split;
+    int nslab = p.slabs_per_split;
+    const int slabs_total = (p.M + SLAB - 1) / SLAB;
+    if (slab0 + nslab > slabs_total) nslab = slabs_total - slab0;
+    if (nslab <= 0) return;                       // uniform for the whole workgroup
+
+    const int slot = tid & 15;                    // pixel slot inside the slab (fastest across lanes)
+    const int g0 = tid >> 4;                      // channel group; unit i uses group g0 + 16*i
+
+    // per-unit constants
+    int a_tap_h[UA], a_tap_w[UA], a_ci[UA];
+    bool a_ok[UA];
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+        const int g = g0 + 16 * i;
+        const int k = r0 + g * EPC;
+        a_ok[i] = (g < RT / EPC) && (k < p.K);
+        const int kk = a_ok[i] ? k : 0;
+        const int tap = kk / p.Cin;
+        a_ci[i] = kk - tap * p.Cin;
+        a_tap_h[i] = tap / p.KW;
+        a_tap_w[i] = tap - a_tap_h[i] * p.KW;
+    }
+    int b_co[UB];
+    bool b_ok[UB];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+        const int g = g0 + 16 * i;
+        b_co[i] = c0 + g * EPC;
+        b_ok[i] = (g < CT / EPC) && (b_co[i] < p.Cout);
+    }
+
+    PixelCursor cur[PPU];
+#pragma unroll
+    for (int q = 0; q < PPU; ++q) cur[q].init(slab0 * SLAB + slot * PPU + q, p.Ho, p.Wo);
+
+    uint4 ra[UA][PPU], rb[UB][PPU];
+
+    auto load_slab = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPU; ++q) {
+            const bool m_ok = cur[q].m < p.M;
+            const int hb = cur[q].ho * p.stride - p.pad, wb = cur[q].wo * p.stride - p.pad;
+#pragma unroll
+            for (int i = 0; i < UA; ++i) {
+                const int hi = hb + a_tap_h[i], wi = wb + a_tap_w[i];
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (m_ok && a_ok[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+                    v = *reinterpret_cast<const uint4*>(
+                        p.x + ((long long)cur[q].n * p.xbs + ((long long)hi * p.W + wi) * p.ldx + a_ci[i]) * ESZ);
+                ra[i][q] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < UB; ++i) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (m_ok && b_ok[i])
+                    v = *reinterpret_cast<const uint4*>(
+                        p.dy + ((long long)cur[q].n * p.dybs +
+                                ((long long)cur[q].ho * p.Wo + cur[q].wo) * p.lddy + b_co[i]) * ESZ);
+                rb[i][q] = v;
+            }
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPU; ++q) cur[q].advance(SLAB, p.Ho, p.Wo);
+    };
+    // transpose-scatter one unit: element j of the chunk goes to row (g*EPC + j), 32-bit word `slot`
+    auto scatter = [&](unsigned char* base, int g, const uint4 (&v)[PPU]) {
+        if (ESZ == 2) {
+            unsigned short e0[8], e1[8];
+            __builtin_memcpy(e0, &v[0], 16);
+            __builtin_memcpy(e1, &v[PPU - 1], 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<unsigned*>(base + (g * 8 + j) * kPitchT + slot * 4) =
+                    (unsigned)e0[j] | ((unsigned)e1[j] << 16);
+        } else {
+            unsigned w[4];
+            __builtin_memcpy(w, &v[0], 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<unsigned*>(base + (g * 4 + j) * kPitchT + slot * 4) = w[j];
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < UA; ++i) {
+            const int g = g0 + 16 * i;
+            if (g < RT / EPC) scatter(sA, g, ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
+            const int g = g0 + 16 * i;
+            if (g < CT / EPC) scatter(sB, g, rb[i]);
+        }
+    };
+
+    f32x16 acc[TR][TC];
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+        for (int u = 0; u < TC; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    const int l31 = lane & 31;
+    const int hi16 = (lane >> 5) * 16;
+
+    load_slab();
+    store_slab();
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const bool more = (s + 1 < nslab);
+        if (more) { advance(); load_slab(); }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 a[TR], b[TC];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                const unsigned char* ptr = sA + ((wr * TR + t) * 32 + l31) * kPitchT + g * 32 + hi16;
+                const uint2 lo = *reinterpret_cast<const uint2*>(ptr);
+                const uint2 hi = *reinterpret_cast<const uint2*>(ptr + 8);
+                a[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const unsigned char* ptr = sB + ((wcn * TC + u) * 32 + l31) * kPitchT + g * 32 + hi16;
+                const uint2 lo = *reinterpret_cast<const uint2*>(ptr);
+                const uint2 hi = *reinterpret_cast<const uint2*>(ptr + 8);
+                b[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int t = 0; t < TR; ++t)
+#pragma unroll
+                for (int u = 0; u < TC; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
+        }
+        __syncthreads();
+        if (more) {
+            store_slab();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[row = k][col = co] -> dW[co][k] (fp32 atomics) ------------------------------
+    const int half = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+        for (int u = 0; u < TC; ++u) {
+            const int co = c0 + (wcn * TC + u) * 32 + l31;
+            if (co >= p.Cout) continue;
+            float* row = p.dw + (long long)co * p.K;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kb = r0 + (wr * TR + t) * 32 + q * 8 + half * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (kb + j < p.K) atomicAdd(row + kb + j, acc[t][u][q * 4 + j]);
+            }
+        }
+}
+
+template <typename T, int WR, int WC, int TR, int TC>
+int launch_wgrad_cfg(WgradArgs a, void* stream) {
+    constexpr int RT = WR * TR * 32, CT = WC * TC * 32, SLAB = 4 * T::kEPC;
+    const int gx = (a.K + RT - 1) / RT, gy = (a.Cout + CT - 1) / CT;
+    const int slabs_total = (a.M + SLAB - 1) / SLAB;
+    // enough workgroups to cover 256 CUs a few times over, at least 8 slabs of work each
+    int splits = (1024 + gx * gy - 1) / (gx * gy);
+    const int max_splits = (slabs_total + 7) / 8;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.slabs_per_split = (slabs_total + splits - 1) / splits;
+    splits = (slabs_total + a.slabs_per_split - 1) / a.slabs_per_split;
+    SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_wgrad_typed(const WgradArgs& a, void* stream) {
+    if (a.Cout > 64) return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, stream);     // 128 k x 128 co
+    if (a.Cout > 32) return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, stream);     // 128 k x  64 co
+    return launch_wgrad_cfg<T, 4, 1, 1, 1>(a, stream);                      // 128 k x  32 co
+}
+
+}  // namespace
+
+extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
+    if (d == nullptr || d->x == nullptr || d->dy == nullptr || d->dw == nullptr) return SY_ERR_ARG;
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return SY_ERR_ARG;
+    if (d->dtype < SY_DT_BF16 || d->dtype > SY_DT_F32) return SY_ERR_ARG;
+    const int epc = d->dtype == SY_DT_F32 ? 4 : 8;
+    if (d->Cin % epc || d->Cout % epc || d->ldx % epc || d->lddy % epc) return SY_ERR_UNSUPPORTED;
+    if (d->stride != 1 && d->stride != 2) return SY_ERR_UNSUPPORTED;
+    if ((long long)d->N * d->Ho * d->Wo > 0x7fffffffLL) return SY_ERR_UNSUPPORTED;
+    WgradArgs a;
+    a.x = (const unsigned char*)d->x; a.dy = (const unsigned char*)d->dy; a.dw = d->dw;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.ldx = d->ldx; a.lddy = d->lddy; a.xbs = d->xbs; a.dybs = d->dybs;
+    a.M = d->N * d->Ho * d->Wo; a.K = d->KH * d->KW * d->Cin; a.slabs_per_split = 0;
+    switch (d->dtype) {
+        case SY_DT_BF16: return launch_wgrad_typed<BF16>(a, stream);
+        case SY_DT_F16: return launch_wgrad_typed<F16>(a, stream);
+        default: return launch_wgrad_typed<F32>(a, stream);
+    }
+}

@@ -1,0 +1,267 @@
+// postprocess.hip — box decode to corners, confidence filter, class-aware greedy NMS, on device,
+// for a whole batch, with no host synchronisation.
+//
+// Replaces yolox.utils.postprocess (exps/evaluators/onex_stream_evaluator.py:148-150 of the
+// reference) and the inline `inference()` of sAP/streamyolo/streamyolo_det.py:62-83, i.e. a per-image
+// Python loop + torchvision.ops.batched_nms + D2H copy.  Index selection must be BIT-EXACT with the
+// reference semantics, so every float operation below is written in the order
+// the reference evaluates it and this library is built with -ffp-contract=off:
+//     corners  x1 = cx - w/2 ...;  class_conf = max_c cls (first max wins);  score = obj*class_conf
+//     keep     score >= conf_thre
+//     order    score descending, ties by ascending anchor index (stable argsort)
+//     offset   box + class_id * (max_coord_over_kept_boxes + 1)        (torchvision batched_nms)
+//     NMS      area = (x2-x1)*(y2-y1); inter = max(0,·)*max(0,·); iou = inter/(a_i+a_j-inter);
+//              a later box is suppressed iff iou > nms_thre with an earlier KEPT box
+//
+// Three kernels per batch:
+//   1. rank   — one 1024-thread workgroup per image: score, filter, max-coord reduction, LDS bitonic
+//               sort of 64-bit keys (~score_bits << 32 | anchor), emit sorted offset boxes.
+//   2. mask   — 64x64 tiles of the upper-triangular suppression bit matrix, one wave per tile,
+//               grid-strided (the candidate count only exists on the device).
+//   3. sweep  — one wave per image walks the sorted list 64 boxes at a time: intra-chunk resolution
+//               with wave shuffles on the diagonal word, then ORs the kept rows into the running
+//               `removed` bitmap (independent, coalesced loads), and writes detections.
+#include "sy_device.h"
+#include "../../include/streamyolo_hip.h"
+
+namespace {
+
+constexpr int kRankThreads = 1024;
+constexpr int kRec = 8;                       // floats per sorted record: x1o,y1o,x2o,y2o,area,anchor,pad,pad
+
+struct PostLayout {                           // per-image slices of the workspace
+    long long acap;                           // anchors rounded up to 64
+    long long words;                          // acap / 64
+    long long rec_off, mask_off, count_off, image_bytes;
+};
+
+inline PostLayout make_layout(int A) {
+    PostLayout L;
+    L.acap = ((long long)A + 63) / 64 * 64;
+    L.words = L.acap / 64;
+    L.rec_off = 0;
+    L.mask_off = L.rec_off + L.acap * kRec * 4;
+    L.count_off = L.mask_off + L.acap * L.words * 8;
+    L.image_bytes = (L.count_off + 64 + 255) / 256 * 256;
+    return L;
+}
+
+inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+__global__ __launch_bounds__(kRankThreads) void nms_rank_kernel(const float* pred, int A, int nc, float conf_thre,
+                                                                unsigned char* ws, PostLayout L, int sort_n) {
+    SY_DYN_SMEM(smem);
+    // all LDS lives in the dynamic region so its base stays 16-byte aligned (guide §6 G17)
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);        // [sort_n]
+    float* s_max = reinterpret_cast<float*>(smem + (size_t)sort_n * 8);           // [kRankThreads/64]
+    int& s_count = *reinterpret_cast<int*>(smem + (size_t)sort_n * 8 + (kRankThreads / 64) * 4);
+    const int img = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* P = pred + (long long)img * A * (5 + nc);
+    unsigned char* wsi = ws + (long long)img * L.image_bytes;
+    float* rec = reinterpret_cast<float*>(wsi + L.rec_off);
+    int* count_out = reinterpret_cast<int*>(wsi + L.count_off);
+
+    if (tid == 0) s_count = 0;
+    for (int i = tid; i < sort_n; i += kRankThreads) keys[i] = ~0ull;
+    __syncthreads();
+
+    float lmax = -INFINITY;
+    for (int a = tid; a < A; a += kRankThreads) {
+        const float* r = P + (long long)a * (5 + nc);
+        float best = r[5];
+        for (int c = 1; c < nc; ++c) { const float v = r[5 + c]; if (v > best) best = v; }
+        const float score = r[4] * best;
+        if (score >= conf_thre) {
+            const int slot = atomicAdd(&s_count, 1);
+            const unsigned bits = __builtin_bit_cast(unsigned, score);
+            keys[slot] = ((unsigned long long)(0xffffffffu - bits) << 32) | (unsigned)a;
+            const float hw = r[2] / 2, hh = r[3] / 2;
+            const float x1 = r[0] - hw, y1 = r[1] - hh, x2 = r[0] + hw, y2 = r[1] + hh;
+            lmax = fmaxf(fmaxf(fmaxf(lmax, x1), fmaxf(y1, x2)), y2);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if ((tid & 63) == 0) s_max[tid >> 6] = lmax;
+    __syncthreads();
+    const int count = s_count;
+    float max_coord = s_max[0];
+    for (int w = 1; w < kRankThreads / 64; ++w) max_coord = fmaxf(max_coord, s_max[w]);
+
+    // bitonic sort (ascending) of the first `n2` keys; empty slots hold ~0 and sink to the end
+    int n2 = 1;
+    while (n2 < count) n2 <<= 1;
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += kRankThreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    const float off_unit = max_coord + 1.0f;
+    for (int i = tid; i < count; i += kRankThreads) {
+        const int a = (int)(keys[i] & 0xffffffffu);
+        const float* r = P + (long long)a * (5 + nc);
+        float best = r[5];
+        int bc = 0;
+        for (int c = 1; c < nc; ++c) { const float v = r[5 + c]; if (v > best) { best = v; bc = c; } }
+        const float hw = r[2] / 2, hh = r[3] / 2;
+        const float off = (float)bc * off_unit;
+        const float x1 = (r[0] - hw) + off, y1 = (r[1] - hh) + off, x2 = (r[0] + hw) + off, y2 = (r[1] + hh) + off;
+        float* o = rec + (long long)i * kRec;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+        o[4] = (x2 - x1) * (y2 - y1);
+        o[5] = __builtin_bit_cast(float, a);
+        o[6] = 0.0f; o[7] = 0.0f;
+    }
+    if (tid == 0) *count_out = count;
+}
+
+// One wave per 64x64 tile (row block rb <= col block cb).  Lane l owns row i = rb*64 + l.
+__global__ __launch_bounds__(64) void nms_mask_kernel(unsigned char* ws, PostLayout L, float thr, int tiles_per_image_cap) {
+    const int img = blockIdx.y;
+    unsigned char* wsi = ws + (long long)img * L.image_bytes;
+    const float* rec = reinterpret_cast<const float*>(wsi + L.rec_off);
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(wsi + L.mask_off);
+    const int count = *reinterpret_cast<const int*>(wsi + L.count_off);
+    const int nblk = (count + 63) / 64;
+    const long long ntiles = (long long)nblk * (nblk + 1) / 2;
+    __shared__ float cbox[64 * 5];
+    const int lane = threadIdx.x;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // unrank t -> (rb, cb) with rb <= cb, row-major over the upper triangle
+        int rb = 0;
+        long long rem = t;
+        while (rem >= nblk - rb) { rem -= nblk - rb; ++rb; }
+        const int cb = rb + (int)rem;
+        const int j0 = cb * 64;
+        __syncthreads();
+        if (j0 + lane < count) {
+            const float* r = rec + (long long)(j0 + lane) * kRec;
+            cbox[lane * 5 + 0] = r[0]; cbox[lane * 5 + 1] = r[1]; cbox[lane * 5 + 2] = r[2];
+            cbox[lane * 5 + 3] = r[3]; cbox[lane * 5 + 4] = r[4];
+        }
+        __syncthreads();
+        const int i = rb * 64 + lane;
+        if (i < count) {
+            const float* r = rec + (long long)i * kRec;
+            const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3], ai = r[4];
+            unsigned long long bits = 0ull;
+            const int jn = (count - j0) < 64 ? (count - j0) : 64;
+            for (int jj = 0; jj < jn; ++jj) {
+                if (j0 + jj <= i) continue;
+                const float lx = fmaxf(x1, cbox[jj * 5 + 0]), ly = fmaxf(y1, cbox[jj * 5 + 1]);
+                const float rx = fminf(x2, cbox[jj * 5 + 2]), ry = fminf(y2, cbox[jj * 5 + 3]);
+                const float w = fmaxf(rx - lx, 0.0f), h = fmaxf(ry - ly, 0.0f);
+                const float inter = w * h;
+                const float iou = inter / (ai + cbox[jj * 5 + 4] - inter);
+                if (iou > thr) bits |= (1ull << jj);
+            }
+            mask[(long long)i * L.words + cb] = bits;
+        }
+    }
+    (void)tiles_per_image_cap;
+}
+
+__global__ __launch_bounds__(64) void nms_sweep_kernel(const float* pred, int A, int nc, unsigned char* ws, PostLayout L,
+                                                       int max_det, float* out_det, int* out_index, int* out_count) {
+    SY_DYN_SMEM(smem);
+    unsigned long long* removed = reinterpret_cast<unsigned long long*>(smem);     // [L.words]
+    const int img = blockIdx.x;
+    const int lane = threadIdx.x;
+    unsigned char* wsi = ws + (long long)img * L.image_bytes;
+    const float* rec = reinterpret_cast<const float*>(wsi + L.rec_off);
+    const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(wsi + L.mask_off);
+    const int count = *reinterpret_cast<const int*>(wsi + L.count_off);
+    const int nblk = (count + 63) / 64;
+    const float* P = pred + (long long)img * A * (5 + nc);
+    float* det = out_det + (long long)img * max_det * 7;
+    int* oidx = out_index + (long long)img * max_det;
+
+    for (int w = lane; w < nblk; w += 64) removed[w] = 0ull;
+    __syncthreads();
+    int nkept = 0;
+    for (int k = 0; k < nblk; ++k) {
+        const int i = k * 64 + lane;
+        const unsigned long long diag = (i < count) ? mask[(long long)i * L.words + k] : 0ull;
+        unsigned long long rem = removed[k];
+        unsigned long long alive = 0ull;
+        const int nl = (count - k * 64) < 64 ? (count - k * 64) : 64;
+        for (int l = 0; l < nl; ++l) {
+            const unsigned long long row = __shfl(diag, l);
+            if (!((rem >> l) & 1ull)) { alive |= (1ull << l); rem |= row; }
+        }
+        // fold the kept rows of this chunk into the running bitmap of later chunks
+        for (int w = k + 1 + lane; w < nblk; w += 64) {
+            unsigned long long acc = removed[w];
+            unsigned long long bits = alive;
+            while (bits) {
+                const int b = __ffsll(bits) - 1;
+                bits &= bits - 1;
+                acc |= mask[(long long)(k * 64 + b) * L.words + w];
+            }
+            removed[w] = acc;
+        }
+        // emit this chunk's survivors in order
+        if ((alive >> lane) & 1ull) {
+            const int pos = nkept + __popcll(alive & ((1ull << lane) - 1ull));
+            if (pos < max_det) {
+                const int a = __builtin_bit_cast(int, rec[(long long)i * kRec + 5]);
+                const float* r = P + (long long)a * (5 + nc);
+                float best = r[5];
+                int bc = 0;
+                for (int c = 1; c < nc; ++c) { const float v = r[5 + c]; if (v > best) { best = v; bc = c; } }
+                const float hw = r[2] / 2, hh = r[3] / 2;
+                float* d = det + (long long)pos * 7;
+                d[0] = r[0] - hw; d[1] = r[1] - hh; d[2] = r[0] + hw; d[3] = r[1] + hh;
+                d[4] = r[4]; d[5] = best; d[6] = (float)bc;
+                oidx[pos] = a;
+            }
+        }
+        nkept += __popcll(alive);
+        __syncthreads();
+    }
+    if (lane == 0) out_count[img] = nkept < max_det ? nkept : max_det;
+}
+
+}  // namespace
+
+extern "C" int64_t sy_postprocess_workspace_bytes(int B, int A) {
+    if (B <= 0 || A <= 0) return 0;
+    return make_layout(A).image_bytes * (int64_t)B;
+}
+
+extern "C" int sy_postprocess(const float* pred, int B, int A, int num_classes, float conf_thre, float nms_thre,
+                              int max_det, float* out_det, int32_t* out_index, int32_t* out_count, void* workspace,
+                              void* stream) {
+    if (pred == nullptr || out_det == nullptr || out_index == nullptr || out_count == nullptr || workspace == nullptr)
+        return SY_ERR_ARG;
+    if (B <= 0 || A <= 0 || num_classes <= 0 || max_det <= 0) return SY_ERR_ARG;
+    const int sort_n = next_pow2(A);
+    if (sort_n > 16384) return SY_ERR_UNSUPPORTED;          // 128 KiB of LDS keys (160 KiB per CU on gfx950)
+    PostLayout L = make_layout(A);
+    const size_t rank_smem = (size_t)sort_n * 8 + 128;
+#ifndef SY_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)nms_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 128) != hipSuccess)
+            return SY_ERR_LAUNCH;
+        attr_done = true;
+    }
+#endif
+    SY_LAUNCH(nms_rank_kernel, dim3(B), dim3(kRankThreads), rank_smem, stream, pred, A, num_classes, conf_thre,
+              (unsigned char*)workspace, L, sort_n);
+    if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
+    SY_LAUNCH(nms_mask_kernel, dim3(512, B), dim3(64), 0, stream, (unsigned char*)workspace, L, nms_thre, 0);
+    if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
+    SY_LAUNCH(nms_sweep_kernel, dim3(B), dim3(64), (size_t)L.words * 8, stream, pred, A, num_classes,
+              (unsigned char*)workspace, L, max_det, out_det, out_index, out_count);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}

@@ -1,0 +1,106 @@
+// sy_device.h — device-side vocabulary shared by every kernel in this directory.
+//
+// Product build: hipcc --offload-arch=gfx950 (CDNA4 only: wave64, MFMA 32x32x16 bf16/f16,
+// MFMA 32x32x2 f32).  There is deliberately no other GPU back end.
+// Test build (-DSY_EMU, host clang++): tests/emu/simt_emu.h supplies a lock-step emulation of the
+// few HIP constructs used here so the same sources can be checked on CPU against the oracle.
+#pragma once
+
+#ifdef SY_EMU
+#include "simt_emu.h"
+#define SY_DYN_SMEM(name) unsigned char* name = emu::g_blk->dyn_smem
+#define SY_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define SY_LAUNCH_OK() 0
+#else
+#include <hip/hip_runtime.h>
+#define SY_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define SY_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define SY_LAUNCH_OK() ((int)hipGetLastError())
+#endif
+
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- element types --------------------------------------------------------------------------
+// Storage dtypes of activations / packed weights.  Codes are part of the C ABI (include/streamyolo_hip.h).
+enum : int { SY_BF16 = 0, SY_F16 = 1, SY_F32 = 2 };
+
+struct BF16 {   // bfloat16 storage; arithmetic is always fp32
+    typedef unsigned short elem;
+    static constexpr int kCode = SY_BF16;
+    static constexpr int kEPC = 8;     // elements per 16-byte chunk
+    static __device__ __forceinline__ float to_f32(elem h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+    static __device__ __forceinline__ elem from_f32(float f) {        // round-to-nearest-even
+        unsigned u = __builtin_bit_cast(unsigned, f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (elem)((u >> 16) | 0x40);   // quiet NaN
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (elem)(u >> 16);
+    }
+};
+struct F16 {
+    typedef unsigned short elem;
+    static constexpr int kCode = SY_F16;
+    static constexpr int kEPC = 8;
+    static __device__ __forceinline__ float to_f32(elem h) { return (float)__builtin_bit_cast(_Float16, h); }
+    static __device__ __forceinline__ elem from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+};
+struct F32 {
+    typedef float elem;
+    static constexpr int kCode = SY_F32;
+    static constexpr int kEPC = 4;
+    static __device__ __forceinline__ float to_f32(elem h) { return h; }
+    static __device__ __forceinline__ elem from_f32(float f) { return f; }
+};
+
+// ---- MFMA wrappers ------------------------------------------------------------------------------
+// One 64-byte K-slab per operand row is consumed as two 32-byte groups g; within a group lane-half
+// h = lane>>5 owns bytes [16h, 16h+16).  For 16-bit types that is one 32x32x16 MFMA per group; for
+// fp32 it is four 32x32x2 MFMAs (element j of each half).  A and B use the same (h, j) -> k map,
+// so the contraction is exact whatever the hardware's internal k order is.
+#ifdef SY_EMU
+static inline f32x16 sy_mfma_group(BF16, uint4 a, uint4 b, f32x16 c) { return emu_mfma_32x32x16(a, b, c, 0); }
+static inline f32x16 sy_mfma_group(F16, uint4 a, uint4 b, f32x16 c) { return emu_mfma_32x32x16(a, b, c, 1); }
+static inline f32x16 sy_mfma_group(F32, uint4 a, uint4 b, f32x16 c) {
+    float fa[4], fb[4];
+    __builtin_memcpy(fa, &a, 16);
+    __builtin_memcpy(fb, &b, 16);
+    for (int j = 0; j < 4; ++j) c = emu_mfma_32x32x2_f32(fa[j], fb[j], c);
+    return c;
+}
+#else
+typedef __bf16 sy_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sy_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 sy_mfma_group(BF16, uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sy_bf16x8, a), __builtin_bit_cast(sy_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 sy_mfma_group(F16, uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sy_f16x8, a), __builtin_bit_cast(sy_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 sy_mfma_group(F32, uint4 a, uint4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    return c;
+}
+#endif
+
+// ---- small math ---------------------------------------------------------------------------------
+#ifdef SY_EMU
+static inline float sy_exp(float x) { return expf(x); }
+#else
+__device__ __forceinline__ float sy_exp(float x) { return __expf(x); }      // v_exp_f32 based, ~1e-6 relative
+#endif
+__device__ __forceinline__ float sy_sigmoid(float z) { return 1.0f / (1.0f + sy_exp(-z)); }
+__device__ __forceinline__ float sy_silu(float z) { return z * sy_sigmoid(z); }
+// d silu(z)/dz = s * (1 + z * (1 - s))
+__device__ __forceinline__ float sy_silu_grad(float z) { float s = sy_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
+
+template <typename T> __device__ __forceinline__ T sy_min(T a, T b) { return a < b ? a : b; }
+template <typename T> __device__ __forceinline__ T sy_max(T a, T b) { return a > b ? a : b; }
+
+// status codes returned through the C ABI
+enum : int { SY_OK = 0, SY_ERR_ARG = 1, SY_ERR_LAUNCH = 2, SY_ERR_UNSUPPORTED = 3 };

@@ -1,0 +1,223 @@
+"""Thin typed wrappers over the C ABI: torch tensors in, raw pointers + the current HIP stream out.
+
+PyTorch is plumbing here (device memory, streams); every numeric result comes from the kernels in
+streamyolo_amd/csrc through libstreamyolo_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (CONV_DGRAD, CONV_FWD, DT_BF16, DT_F16, DT_F32, EPI_DECODE, EPI_LINEAR, EPI_SIGMOID,
+                   EPI_SILU, ConvDesc, WgradDesc, check)
+
+TORCH_DTYPE = {DT_BF16: torch.bfloat16, DT_F16: torch.float16, DT_F32: torch.float32}
+DTYPE_CODE = {v: k for k, v in TORCH_DTYPE.items()}
+DTYPE_NAME = {"bf16": DT_BF16, "fp16": DT_F16, "f16": DT_F16, "fp32": DT_F32, "f32": DT_F32}
+
+
+def dtype_code(d):
+    if isinstance(d, str):
+        return DTYPE_NAME[d]
+    if isinstance(d, torch.dtype):
+        return DTYPE_CODE[d]
+    return int(d)
+
+
+def stream_of(t):
+    """Raw hipStream_t of torch's CURRENT stream on t's device (kernels must run on
+    the stream the trainer/prefetcher handed the tensors over on)."""
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+class View:
+    """NHWC activation view: a channel slice [c_off, c_off+C) of a dense [N,H,W,ld] buffer."""
+    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c_off")
+
+    def __init__(self, buf, N, H, W, C_, ld=None, c_off=0):
+        self.buf, self.N, self.H, self.W, self.C = buf, N, H, W, C_
+        self.ld = C_ if ld is None else ld
+        self.c_off = c_off
+
+    @staticmethod
+    def alloc(N, H, W, C_, dtype, device, zero=False):
+        fn = torch.zeros if zero else torch.empty
+        return View(fn((N, H, W, C_), dtype=TORCH_DTYPE[dtype_code(dtype)], device=device), N, H, W, C_)
+
+    @property
+    def bs(self):
+        return self.H * self.W * self.ld
+
+    @property
+    def dtype(self):
+        return DTYPE_CODE[self.buf.dtype]
+
+    @property
+    def pixels(self):
+        return self.N * self.H * self.W
+
+    def ptr(self):
+        return self.buf.data_ptr() + self.c_off * self.buf.element_size()
+
+    def slice(self, c0, c):
+        assert 0 <= c0 and c0 + c <= self.C
+        return View(self.buf, self.N, self.H, self.W, c, self.ld, self.c_off + c0)
+
+    def like(self, zero=False):
+        """A fresh dense buffer with the same full layout (used for gradient mirrors)."""
+        fn = torch.zeros_like if zero else torch.empty_like
+        return View(fn(self.buf), self.N, self.H, self.W, self.C, self.ld, self.c_off)
+
+    def nchw(self):
+        """Float32 NCHW copy (tests / debugging only)."""
+        return self.buf.view(self.N, self.H, self.W, self.ld)[..., self.c_off:self.c_off + self.C] \
+            .permute(0, 3, 1, 2).float().contiguous()
+
+    def set_nchw(self, t):
+        self.buf.view(self.N, self.H, self.W, self.ld)[..., self.c_off:self.c_off + self.C] = \
+            t.permute(0, 2, 3, 1).to(self.buf.dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_out_size(h, k, stride):
+    return (h + 2 * ((k - 1) // 2) - k) // stride + 1
+
+
+def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
+           accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
+           cout=None):
+    """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
+    y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
+    d = ConvDesc()
+    d.x, d.w = x.ptr(), w.data_ptr()
+    d.scale, d.shift = _p(scale), _p(shift)
+    d.res = None if res is None else res.ptr()
+    d.stat_sum, d.stat_sqsum = (None, None) if stats is None else (stats[0].data_ptr(), stats[1].data_ptr())
+    d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
+    if y is not None:
+        d.y, d.Ho, d.Wo, d.Cout = y.ptr(), y.H, y.W, y.C
+        d.ldy, d.ybs = y.ld, y.bs
+    if y_ptr is not None:
+        d.y, d.ldy, d.ybs = y_ptr, y_ld, y_bs
+        if y is None:
+            d.Ho, d.Wo = conv_out_size(x.H, ksize, stride), conv_out_size(x.W, ksize, stride)
+    if cout is not None:
+        d.Cout = cout
+    d.KH = d.KW = ksize
+    d.stride, d.pad = stride, (ksize - 1) // 2
+    d.ldx, d.xbs = x.ld, x.bs
+    d.ldr, d.rbs = (0, 0) if res is None else (res.ld, res.bs)
+    d.dtype = x.dtype
+    d.y_f32 = 1 if y_f32 else 0
+    d.mode, d.epilogue, d.accumulate = mode, epilogue, 1 if accumulate else 0
+    d.dec_stride = float(dec_stride)
+    check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
+
+
+def conv2d_wgrad(x, dy, dw, ksize, stride):
+    """dw [Cout, k*k*Cin] fp32 += wgrad(x, dy)."""
+    d = WgradDesc()
+    d.x, d.dy, d.dw = x.ptr(), dy.ptr(), dw.data_ptr()
+    d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
+    d.Ho, d.Wo, d.Cout = dy.H, dy.W, dy.C
+    d.KH = d.KW = ksize
+    d.stride, d.pad = stride, (ksize - 1) // 2
+    d.ldx, d.lddy, d.xbs, d.dybs = x.ld, dy.ld, x.bs, dy.bs
+    d.dtype = x.dtype
+    check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")
+
+
+def focus_pack(frames, c0, out):
+    """frames: [N, Ctot, H, W] fp32 contiguous; out: View [N, H/2, W/2, 16]."""
+    assert frames.dtype == torch.float32 and frames.is_contiguous()
+    N, Ct, H, W = frames.shape
+    assert out.C == 16 and out.ld == 16 and out.c_off == 0
+    check(_lib.lib().sy_focus_pack(frames.data_ptr(), N, Ct, c0, H, W, out.ptr(), out.dtype, stream_of(frames)),
+          "sy_focus_pack")
+
+
+def resize_nearest(src, dst):
+    assert src.C == dst.C and src.N == dst.N
+    check(_lib.lib().sy_resize_nearest(src.ptr(), src.N, src.H, src.W, src.C, src.ld, src.bs, dst.ptr(), dst.H,
+                                       dst.W, dst.ld, dst.bs, src.dtype, stream_of(src.buf)), "sy_resize_nearest")
+
+
+def resize_nearest_bwd(ddst, dsrc, accumulate):
+    check(_lib.lib().sy_resize_nearest_bwd(ddst.ptr(), ddst.N, ddst.H, ddst.W, ddst.C, ddst.ld, ddst.bs, dsrc.ptr(),
+                                           dsrc.H, dsrc.W, dsrc.ld, dsrc.bs, 1 if accumulate else 0, ddst.dtype,
+                                           stream_of(ddst.buf)), "sy_resize_nearest_bwd")
+
+
+def spp_pool(v):
+    """v: View of the 4C-wide SPP concat buffer (C = v.C // 4 channels already hold x)."""
+    c = v.C // 4
+    check(_lib.lib().sy_spp_pool(v.ptr(), v.N, v.H, v.W, c, v.ld, v.bs, v.dtype, stream_of(v.buf)), "sy_spp_pool")
+
+
+def spp_pool_bwd(v, dv):
+    c = v.C // 4
+    check(_lib.lib().sy_spp_pool_bwd(v.ptr(), dv.ptr(), v.N, v.H, v.W, c, v.ld, v.bs, v.dtype, stream_of(v.buf)),
+          "sy_spp_pool_bwd")
+
+
+def view_copy(src, dst, accumulate=False):
+    assert src.C == dst.C and src.pixels == dst.pixels
+    check(_lib.lib().sy_view_copy(src.ptr(), src.ld, dst.ptr(), dst.ld, src.pixels, src.C, src.dtype,
+                                  1 if accumulate else 0, stream_of(src.buf)), "sy_view_copy")
+
+
+def bn_finalize(ssum, ssq, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd):
+    check(_lib.lib().sy_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), ssum.numel(), float(count), gamma.data_ptr(),
+                                    beta.data_ptr(), float(eps), float(momentum), _p(running_mean), _p(running_var),
+                                    scale.data_ptr(), shift.data_ptr(), _p(mean), _p(invstd), stream_of(ssum)),
+          "sy_bn_finalize")
+
+
+def bn_silu_apply(y, scale, shift, out, res=None):
+    check(_lib.lib().sy_bn_silu_apply(y.ptr(), y.ld, scale.data_ptr(), shift.data_ptr(),
+                                      None if res is None else res.ptr(), 0 if res is None else res.ld, out.ptr(),
+                                      out.ld, y.pixels, y.C, y.dtype, stream_of(y.buf)), "sy_bn_silu_apply")
+
+
+def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums):
+    check(_lib.lib().sy_bn_silu_bwd_reduce(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
+                                           mean.data_ptr(), invstd.data_ptr(), sums.data_ptr(), y.pixels, y.C,
+                                           y.dtype, stream_of(y.buf)), "sy_bn_silu_bwd_reduce")
+
+
+def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None):
+    check(_lib.lib().sy_bn_silu_bwd_apply(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
+                                          mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
+                                          dy.ptr(), dy.ld, y.pixels, y.C, _p(dgamma), _p(dbeta), y.dtype,
+                                          stream_of(y.buf)), "sy_bn_silu_bwd_apply")
+
+
+class PostprocessWorkspace:
+    """Device buffers reused across sy_postprocess calls for a given (B, A)."""
+
+    def __init__(self, B, A, device, max_det=None):
+        self.B, self.A = B, A
+        self.max_det = A if max_det is None else max_det
+        nbytes = _lib.lib().sy_postprocess_workspace_bytes(B, A)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.det = torch.zeros((B, self.max_det, 7), dtype=torch.float32, device=device)
+        self.index = torch.zeros((B, self.max_det), dtype=torch.int32, device=device)
+        self.count = torch.zeros((B,), dtype=torch.int32, device=device)
+
+
+def postprocess(pred, num_classes, conf_thre, nms_thre, ws=None):
+    """pred: [B, A, 5+nc] fp32 decoded head output.  Returns (det [B,max,7], index [B,max], count [B])
+    device tensors; no host synchronisation happens here."""
+    assert pred.dtype == torch.float32 and pred.is_contiguous() and pred.shape[2] == 5 + num_classes
+    B, A = pred.shape[:2]
+    if ws is None or ws.B != B or ws.A != A:
+        ws = PostprocessWorkspace(B, A, pred.device)
+    check(_lib.lib().sy_postprocess(pred.data_ptr(), B, A, num_classes, float(conf_thre), float(nms_thre),
+                                    ws.max_det, ws.det.data_ptr(), ws.index.data_ptr(), ws.count.data_ptr(),
+                                    ws.ws.data_ptr(), stream_of(pred)), "sy_postprocess")
+    return ws.det, ws.index, ws.count

@@ -28,3 +28,32 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libstreamyolo_emu.so")
+
+
+def _build_emulator():
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "streamyolo_amd", "csrc"), "-j8", "emu"], check=True)
+    return EMU_LIB
+
+
+@pytest.fixture(scope="session", params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    """Device the kernel tests run on.
+
+    "emu": the SAME kernel sources compiled for the host with tests/emu (lock-step SIMT emulator),
+           CPU tensors — checks indexing / predication / epilogues without a GPU (test infra only).
+    "gpu": the real gfx950 library on cuda:0 — the parity tests proper (pytest -m gpu)."""
+    import torch
+    from streamyolo_amd import _lib
+    if request.param == "emu":
+        _lib.use_library(_build_emulator())
+        assert _lib.is_emulator()
+        return torch.device("cpu")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _lib.use_library(_lib.DEFAULT_PATH)
+    assert not _lib.is_emulator()
+    return torch.device("cuda:0")

@@ -1,0 +1,111 @@
+"""sy_conv2d / sy_conv2d_wgrad against torch fp32 references of the same op (per-kernel parity)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from streamyolo_amd import ops
+from streamyolo_amd.ops import View
+from streamyolo_amd.model.packing import pack_conv_weight
+
+TOL = {"bf16": 2e-2, "fp16": 3e-3, "fp32": 2e-5}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def _q(t, dt):
+    """round a reference tensor through the storage dtype so only accumulation differs"""
+    return t.to(ops.TORCH_DTYPE[ops.dtype_code(dt)]).float()
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [
+    (16, 32, 3, 1, 9, 11, 2),       # stem-like: Cin 16 (taps straddle the 64-byte slab), narrow Cout
+    (32, 64, 3, 2, 11, 14, 1),      # stride 2, odd sizes
+    (64, 136, 1, 1, 7, 9, 2),       # 1x1, Cout not a multiple of the tile
+    (24, 40, 3, 1, 6, 5, 1),        # K = 216: partial last slab
+])
+def test_conv_fwd_silu_residual(backend, dt, cin, cout, k, stride, H, W, N):
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, dt)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.3
+    Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
+    res = _q(torch.randn(N, cout, Ho, Wo, generator=g), dt)
+    ref = F.silu(F.conv2d(x, w, None, stride, (k - 1) // 2) * scale[None, :, None, None] + shift[None, :, None, None]) + res
+
+    # views inside wider buffers: exercises ld / channel offsets (concat-free writes)
+    xb = View.alloc(N, H, W, cin + 8, dt, backend, zero=True).slice(8, cin)
+    xb.set_nchw(x.to(backend))
+    yb = View.alloc(N, Ho, Wo, cout + 16, dt, backend, zero=True).slice(16, cout)
+    rb = View.alloc(N, Ho, Wo, cout, dt, backend)
+    rb.set_nchw(res.to(backend))
+    wp = pack_conv_weight(w, ops.dtype_code(dt)).to(backend)
+    ops.conv2d(xb, wp, yb, k, stride, scale.to(backend), shift.to(backend), res=rb, epilogue=ops.EPI_SILU)
+    got = yb.nchw().cpu()
+    assert _rel(got, ref) < TOL[dt]
+    # the neighbouring channels of the wide buffer stay untouched
+    assert float(yb.buf[..., :16].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [(32, 48, 3, 1, 8, 7, 2), (32, 64, 3, 2, 9, 12, 1), (64, 32, 1, 1, 5, 6, 2)])
+def test_conv_stats_dgrad_wgrad(backend, dt, cin, cout, k, stride, H, W, N):
+    g = torch.Generator().manual_seed(7 + cin + cout)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt).requires_grad_(True)
+    w = _q(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, dt).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, (k - 1) // 2)
+    Ho, Wo = y.shape[2:]
+    dy = _q(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    code = ops.dtype_code(dt)
+
+    xv = View.alloc(N, H, W, cin, dt, backend); xv.set_nchw(x.detach().to(backend))
+    yv = View.alloc(N, Ho, Wo, cout, dt, backend)
+    ssum = torch.zeros(cout, device=backend); ssq = torch.zeros(cout, device=backend)
+    ops.conv2d(xv, pack_conv_weight(w.detach(), code).to(backend), yv, k, stride, stats=(ssum, ssq))
+    assert _rel(yv.nchw().cpu(), y.detach()) < TOL[dt]
+    assert _rel(ssum.cpu(), y.detach().sum((0, 2, 3))) < 1e-3 + TOL[dt] * 0.1 or float(y.detach().sum((0, 2, 3)).abs().max()) < 1e-2
+    assert _rel(ssq.cpu(), (y.detach() ** 2).sum((0, 2, 3))) < 1e-3
+
+    dyv = View.alloc(N, Ho, Wo, cout, dt, backend); dyv.set_nchw(dy.to(backend))
+    dxv = View.alloc(N, H, W, cin, dt, backend, zero=True)
+    wt = pack_conv_weight(w.detach(), code, transpose=True).to(backend)
+    ops.conv2d(dyv, wt, dxv, k, stride, mode=ops.CONV_DGRAD)
+    assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
+    # accumulate: second launch doubles the result
+    ops.conv2d(dyv, wt, dxv, k, stride, mode=ops.CONV_DGRAD, accumulate=True)
+    assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]
+
+    dw = torch.zeros(cout, k * k * cin, device=backend)
+    ops.conv2d_wgrad(xv, dyv, dw, k, stride)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(cout, -1)
+    assert _rel(dw.cpu(), ref_dw) < TOL[dt]
+
+
+def test_head_prediction_epilogues(backend):
+    """reg+obj (decode) and cls (sigmoid) 1x1 convs writing into one [B, A, 5+nc] fp32 tensor."""
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W, nc, A0, A = 2, 32, 5, 7, 8, 10, 60
+    feat = torch.randn(N, C, H, W, generator=g)
+    w_ro = torch.randn(5, C, 1, 1, generator=g) * 0.1
+    b_ro = torch.randn(5, generator=g) * 0.1
+    w_c = torch.randn(nc, C, 1, 1, generator=g) * 0.1
+    b_c = torch.randn(nc, generator=g) * 0.1
+    ro = F.conv2d(feat, w_ro, b_ro)
+    cl = torch.sigmoid(F.conv2d(feat, w_c, b_c))
+    yv, xv = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    ref = torch.cat([(ro[:, 0:1] + xv) * 16.0, (ro[:, 1:2] + yv) * 16.0, torch.exp(ro[:, 2:4]) * 16.0,
+                     torch.sigmoid(ro[:, 4:5]), cl], 1).flatten(2).permute(0, 2, 1)
+    fv = View.alloc(N, H, W, C, "fp32", backend); fv.set_nchw(feat.to(backend))
+    out = torch.zeros(N, A, 5 + nc, device=backend)
+    base = out.data_ptr() + A0 * (5 + nc) * 4
+    ops.conv2d(fv, pack_conv_weight(w_ro, ops.DT_F32).to(backend), None, 1, 1, None, b_ro.to(backend),
+               epilogue=ops.EPI_DECODE, dec_stride=16.0, y_f32=True, y_ptr=base, y_ld=5 + nc, y_bs=A * (5 + nc), cout=5)
+    ops.conv2d(fv, pack_conv_weight(w_c, ops.DT_F32).to(backend), None, 1, 1, None, b_c.to(backend),
+               epilogue=ops.EPI_SIGMOID, y_f32=True, y_ptr=base + 5 * 4, y_ld=5 + nc, y_bs=A * (5 + nc), cout=nc)
+    got = out[:, A0:A0 + H * W].cpu()
+    assert _rel(got, ref) < 1e-5
+    assert float(out[:, :A0].abs().max()) == 0.0 and float(out[:, A0 + H * W:].abs().max()) == 0.0

@@ -1,0 +1,148 @@
+"""Glue kernels (focus, resize, SPP, BN-train, NMS) against torch fp32 references / the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import streamyolo_oracle as O
+from streamyolo_amd import ops
+from streamyolo_amd.ops import View
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_focus_pack(backend, dt):
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 6, 12, 20, generator=g) * 255
+    out = View.alloc(2, 6, 10, 16, dt, backend)
+    ops.focus_pack(x.to(backend), 3, out)
+    ref = O.focus_pack(x[:, 3:6])
+    got = out.nchw().cpu()
+    tol = 1e-2 if dt == "bf16" else 0.0
+    assert _rel(got[:, :12], ref) <= tol
+    assert float(got[:, 12:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hi,wi,ho,wo", [(19, 30, 38, 60), (38, 60, 75, 120), (10, 13, 19, 25), (5, 5, 5, 5)])
+def test_resize_nearest_fwd_bwd(backend, hi, wi, ho, wo):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 8, hi, wi, generator=g, requires_grad=True)
+    ref = F.interpolate(x, size=(ho, wo), mode="nearest")
+    dref = torch.randn(ref.shape, generator=g)
+    ref.backward(dref)
+    src = View.alloc(2, hi, wi, 8, "fp32", backend); src.set_nchw(x.detach().to(backend))
+    wide = View.alloc(2, ho, wo, 24, "fp32", backend, zero=True)
+    dst = wide.slice(8, 8)
+    ops.resize_nearest(src, dst)
+    assert torch.equal(dst.nchw().cpu(), ref.detach())
+    dd = View.alloc(2, ho, wo, 8, "fp32", backend); dd.set_nchw(dref.to(backend))
+    ds = View.alloc(2, hi, wi, 8, "fp32", backend, zero=True)
+    ops.resize_nearest_bwd(dd, ds, accumulate=False)
+    assert _rel(ds.nchw().cpu(), x.grad) < 1e-6
+    ops.resize_nearest_bwd(dd, ds, accumulate=True)
+    assert _rel(ds.nchw().cpu(), 2 * x.grad) < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_spp_pool_fwd_bwd(backend, dt):
+    g = torch.Generator().manual_seed(2)
+    C, H, W = 8, 9, 14
+    x = torch.randn(1, C, H, W, generator=g).to(ops.TORCH_DTYPE[ops.dtype_code(dt)]).float().requires_grad_(True)
+    pools = [F.max_pool2d(x, k, 1, k // 2) for k in (5, 9, 13)]
+    ref = torch.cat([x] + pools, 1)
+    v = View.alloc(1, H, W, 4 * C, dt, backend, zero=True)
+    v.slice(0, C).set_nchw(x.detach().to(backend))
+    ops.spp_pool(v)
+    assert torch.equal(v.nchw().cpu(), ref.detach())
+    if dt == "fp32":        # tie-free inputs: arg-max routing is well defined
+        dref = torch.randn(ref.shape, generator=g)
+        ref.backward(dref)
+        dv = View.alloc(1, H, W, 4 * C, dt, backend); dv.set_nchw(dref.to(backend))
+        ops.spp_pool_bwd(v, dv)
+        assert _rel(dv.slice(0, C).nchw().cpu(), x.grad) < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_bn_train_silu_fwd_bwd(backend, dt):
+    g = torch.Generator().manual_seed(4)
+    N, C, H, W = 2, 16, 6, 5
+    tdt = ops.TORCH_DTYPE[ops.dtype_code(dt)]
+    y = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(tdt).float().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    res = torch.randn(N, C, H, W, generator=g).to(tdt).float()
+    a = F.silu(F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.03, 1e-3)) + res
+    da = torch.randn(a.shape, generator=g).to(tdt).float()
+    a.backward(da)
+
+    dev = backend
+    yv = View.alloc(N, H, W, C, dt, dev); yv.set_nchw(y.detach().to(dev))
+    ssum = y.detach().sum((0, 2, 3)).to(dev); ssq = (y.detach() ** 2).sum((0, 2, 3)).to(dev)
+    scale, shift, mean, invstd = [torch.empty(C, device=dev) for _ in range(4)]
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    ops.bn_finalize(ssum, ssq, N * H * W, gamma.detach().to(dev), beta.detach().to(dev), 1e-3, 0.03, rmd, rvd,
+                    scale, shift, mean, invstd)
+    assert _rel(rmd.cpu(), rm_ref) < 1e-5 and _rel(rvd.cpu(), rv_ref) < 1e-5
+    rv_ = View.alloc(N, H, W, C, dt, dev); rv_.set_nchw(res.to(dev))
+    av = View.alloc(N, H, W, C, dt, dev)
+    ops.bn_silu_apply(yv, scale, shift, av, res=rv_)
+    tol = 2e-2 if dt == "bf16" else 1e-5
+    assert _rel(av.nchw().cpu(), a.detach()) < tol
+    dav = View.alloc(N, H, W, C, dt, dev); dav.set_nchw(da.to(dev))
+    sums = torch.zeros(2 * C, device=dev)
+    ops.bn_silu_bwd_reduce(yv, dav, scale, shift, mean, invstd, sums)
+    dyv = View.alloc(N, H, W, C, dt, dev)
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_silu_bwd_apply(yv, dav, scale, shift, mean, invstd, gamma.detach().to(dev), sums, dyv, dgam, dbet)
+    assert _rel(dbet.cpu(), beta.grad) < 1e-4 and _rel(dgam.cpu(), gamma.grad) < 1e-4
+    assert _rel(dyv.nchw().cpu(), y.grad) < (3e-2 if dt == "bf16" else 1e-4)
+
+
+def _random_preds(B, A, nc, seed, img=(600.0, 960.0), tie_free=True):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.zeros(B, A, 5 + nc)
+    p[..., 0] = torch.rand(B, A, generator=g) * img[1]
+    p[..., 1] = torch.rand(B, A, generator=g) * img[0]
+    p[..., 2] = torch.rand(B, A, generator=g) * 200 + 8
+    p[..., 3] = torch.rand(B, A, generator=g) * 200 + 8
+    p[..., 4] = torch.rand(B, A, generator=g)
+    p[..., 5:] = torch.rand(B, A, nc, generator=g)
+    if tie_free:
+        p[..., 4] = p[..., 4] * 0.5 + 0.25 + torch.arange(A)[None] * 2.0 ** -20
+    return p
+
+
+@pytest.mark.parametrize("A", [0 + 1, 64, 257, 1500])
+def test_postprocess_matches_oracle_bit_exact(backend, A):
+    nc = 8
+    pred = _random_preds(2, A, nc, seed=A)
+    pred[1, :, 4] *= 0.02                       # second image: most anchors fall under the threshold
+    det, idx, cnt = ops.postprocess(pred.to(backend), nc, 0.01, 0.65)
+    ref = O.postprocess(pred, nc, 0.01, 0.65)
+    for i, (rdet, ridx) in enumerate(ref):
+        n = int(cnt[i])
+        assert n == ridx.numel()
+        assert np.array_equal(idx[i, :n].cpu().numpy(), ridx.numpy().astype(np.int32))     # order included
+        assert torch.equal(det[i, :n].cpu(), rdet)
+
+
+def test_postprocess_empty_and_ties(backend):
+    nc = 8
+    pred = _random_preds(1, 100, nc, seed=9)
+    pred[..., 4] = 0.0                          # nothing survives the confidence filter
+    det, idx, cnt = ops.postprocess(pred.to(backend), nc, 0.01, 0.65)
+    assert int(cnt[0]) == 0
+    # exact score ties: stable order = ascending anchor index
+    pred = _random_preds(1, 200, nc, seed=10, tie_free=False)
+    pred[..., 4] = 0.5
+    pred[..., 5:] = 0.0
+    pred[..., 5] = 0.8
+    det, idx, cnt = ops.postprocess(pred.to(backend), nc, 0.01, 0.65)
+    rdet, ridx = O.postprocess(pred, nc, 0.01, 0.65)[0]
+    n = int(cnt[0])
+    assert n == ridx.numel() and np.array_equal(idx[0, :n].cpu().numpy(), ridx.numpy().astype(np.int32))
