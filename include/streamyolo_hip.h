@@ -74,13 +74,15 @@ typedef struct sy_conv_desc {
  * sigmoid/decode of tal_head.py:197-199,245-260, and (mode DGRAD) cuDNN's backward-data. */
 int sy_conv2d(const sy_conv_desc* d, void* stream);
 
-/* Weight gradient: dw[Cout][KH*KW][Cin] (fp32, +=) = sum_pixels dy[p][co] * x[p@tap][ci].
- * Replaces cuDNN backward-filter under autograd (double_trainer.py:114). */
+/* Weight gradient (fp32, +=): dw[co][tap][ci] = sum_pixels dy[p][co] * x[p@tap][ci]; with
+ * dw_oihw = 1 the result lands in the nn.Parameter layout [Cout][Cin][KH][KW] (so .grad can be a
+ * view of the gradient arena).  Replaces cuDNN backward-filter under autograd (double_trainer.py:114). */
 typedef struct sy_wgrad_desc {
     const void* x;  const void* dy;  float* dw;
     int32_t N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int32_t ldx, lddy;  int64_t xbs, dybs;
     int32_t dtype;
+    int32_t dw_oihw;
 } sy_wgrad_desc;
 int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
 

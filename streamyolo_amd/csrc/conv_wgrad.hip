@@ -27,6 +27,7 @@ struct WgradArgs {
     int ldx, lddy;
     long long xbs, dybs;
     int M, K, slabs_per_split;
+    int oihw;                   // 1: dW laid out [Cout][Cin][KH][KW] (the nn.Parameter layout), 0: [Cout][tap][Cin]
 };
 
 constexpr int kPitchT = 72;
@@ -232,9 +233,17 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int kb = r0 + (wr * TR + t) * 32 + q * 8 + half * 4;
+                if (kb >= p.K) continue;                       // Cin % 4 == 0: the quad shares one tap
+                if (p.oihw) {
+                    const int taps = p.KH * p.KW;
+                    const int tap = kb / p.Cin;
+                    const int ci = kb - tap * p.Cin;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (kb + j < p.K) atomicAdd(row + kb + j, acc[t][u][q * 4 + j]);
+                    for (int j = 0; j < 4; ++j) atomicAdd(row + (ci + j) * taps + tap, acc[t][u][q * 4 + j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(row + kb + j, acc[t][u][q * 4 + j]);
+                }
             }
         }
 }
@@ -278,6 +287,7 @@ extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.ldx = d->ldx; a.lddy = d->lddy; a.xbs = d->xbs; a.dybs = d->dybs;
     a.M = d->N * d->Ho * d->Wo; a.K = d->KH * d->KW * d->Cin; a.slabs_per_split = 0;
+    a.oihw = d->dw_oihw;
     switch (d->dtype) {
         case SY_DT_BF16: return launch_wgrad_typed<BF16>(a, stream);
         case SY_DT_F16: return launch_wgrad_typed<F16>(a, stream);

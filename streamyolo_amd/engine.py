@@ -1,0 +1,354 @@
+"""Execution plans: the StreamYOLO network as a static list of HIP kernel launches over
+pre-allocated NHWC buffers.
+
+MI355X-first design (not a translation of the reference's eager module tree):
+  * the nn.Module tree (streamyolo_amd/model/*) only owns parameters; a Plan is compiled once per
+    (mode, batch, H, W, dtype) and replayed — fixed buffers, fixed launch order, capturable in a
+    hipGraph (torch.cuda.graphs) because nothing allocates or synchronises while it runs;
+  * every torch.cat of the reference (CSP, SPP, top-down, bottom-up, DFP — trap T6) is a channel
+    slice of a wider buffer that the producing kernel writes directly;
+  * eval / streaming: BN folded into the conv epilogue, both frames of a pair batched as 2B images
+    (legal outside training — SURVEY.md R4), DFP "cat + add" is the residual epilogue of the two
+    jian convs, sigmoid + box decode are the epilogue of the prediction convs;
+  * training: per-frame passes (separate BN statistics, current frame first — trap T2), conv
+    emits sum / sum-of-squares from its fp32 accumulators, backward = BN/SiLU reduce+apply,
+    MFMA dgrad and MFMA wgrad writing into one flat fp32 gradient arena in parameter layout.
+
+Reference lines each piece follows are cited in the builders below.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import View, EPI_SILU, EPI_LINEAR, EPI_SIGMOID, EPI_DECODE, CONV_DGRAD
+from .model.packing import pack_conv_weight, fold_bn
+
+
+# ------------------------------------------------------------------------------------------------
+# op records (pure data; executors below interpret them)
+# ------------------------------------------------------------------------------------------------
+class ConvOp:
+    """BaseConv: conv -> BN -> SiLU (+ residual).  `mod` is the parameter-holding BaseConv module."""
+    kind = "conv"
+
+    def __init__(self, mod, x, y, res=None, need_dx=True, tag=""):
+        self.mod, self.x, self.y, self.res, self.need_dx, self.tag = mod, x, y, res, need_dx, tag
+        self.k, self.stride = mod.ksize, mod.stride
+        # training state (allocated lazily by TrainState)
+        self.yraw = None
+        self.stat = None
+
+
+class PredOp:
+    """The three 1x1 prediction convs of one level as two launches: (reg|obj) from reg_feat and cls
+    from cls_feat (tal_head.py:167-171 of the reference)."""
+    kind = "pred"
+
+    def __init__(self, level, cls_mod, reg_mod, obj_mod, cls_x, reg_x, a0, stride):
+        self.level, self.cls_mod, self.reg_mod, self.obj_mod = level, cls_mod, reg_mod, obj_mod
+        self.cls_x, self.reg_x, self.a0, self.stride = cls_x, reg_x, a0, stride
+
+
+class ResizeOp:
+    kind = "resize"
+
+    def __init__(self, src, dst):
+        self.src, self.dst = src, dst
+
+
+class SppOp:
+    kind = "spp"
+
+    def __init__(self, v):
+        self.v = v
+
+
+class FocusOp:
+    kind = "focus"
+
+    def __init__(self, c0, out):
+        self.c0, self.out = c0, out
+
+
+# ------------------------------------------------------------------------------------------------
+# network builders
+# ------------------------------------------------------------------------------------------------
+class _Builder:
+    def __init__(self, dtype, device):
+        self.dtype, self.device = dtype, device
+        self.ops = []
+
+    def buf(self, N, H, W, C):
+        return View.alloc(N, H, W, C, self.dtype, self.device)
+
+    def conv(self, mod, x, y=None, res=None, need_dx=True, tag=""):
+        if y is None:
+            y = self.buf(x.N, ops.conv_out_size(x.H, mod.ksize, mod.stride),
+                         ops.conv_out_size(x.W, mod.ksize, mod.stride), mod.conv.out_channels)
+        self.ops.append(ConvOp(mod, x, y, res, need_dx, tag))
+        return y
+
+    def csp(self, mod, x, out=None, tag=""):
+        """CSPLayer: conv3(cat[m(conv1(x)), conv2(x)])  (yolox CSPLayer, Appendix C; trap T6)."""
+        hid = mod.hidden
+        cat = self.buf(x.N, x.H, x.W, 2 * hid)
+        n = mod.n
+        a = self.conv(mod.conv1, x, cat.slice(0, hid) if n == 0 else None, tag=tag + ".conv1")
+        self.conv(mod.conv2, x, cat.slice(hid, hid), tag=tag + ".conv2")
+        for i, b in enumerate(mod.m):
+            u = self.conv(b.conv1, a, tag="%s.m.%d.conv1" % (tag, i))
+            dst = cat.slice(0, hid) if i == n - 1 else None
+            a = self.conv(b.conv2, u, dst, res=a if b.use_add else None, tag="%s.m.%d.conv2" % (tag, i))
+        return self.conv(mod.conv3, cat, out, tag=tag + ".conv3")
+
+
+def build_frame_net(b, pafpn, N, H, W):
+    """CSPDarknet (exps/model/darknet.py:167-179) + PAFPN (dfp_pafpn.py:124-140) for N images.
+    Returns (focus_buffer, (pan2, pan1, pan0))."""
+    bb = pafpn.backbone
+    w = pafpn.width
+    c3, c4, c5 = [int(c * w) for c in pafpn.in_channels]
+    f0 = b.buf(N, H // 2, W // 2, 16)
+    x = b.conv(bb.stem.conv, f0, need_dx=False, tag="stem")
+    x = b.conv(bb.dark2[0], x, tag="dark2.0")
+    x = b.csp(bb.dark2[1], x, tag="dark2.1")
+    x = b.conv(bb.dark3[0], x, tag="dark3.0")
+    h8, w8 = x.H, x.W
+    catP3 = b.buf(N, h8, w8, 2 * c3)                     # cat[up(fpn_out1), dark3]  (:131)
+    d3 = b.csp(bb.dark3[1], x, catP3.slice(c3, c3), tag="dark3.1")
+    x = b.conv(bb.dark4[0], d3, tag="dark4.0")
+    h16, w16 = x.H, x.W
+    catP4 = b.buf(N, h16, w16, 2 * c4)                   # cat[up(fpn_out0), dark4]  (:126)
+    d4 = b.csp(bb.dark4[1], x, catP4.slice(c4, c4), tag="dark4.1")
+    x = b.conv(bb.dark5[0], d4, tag="dark5.0")
+    h32, w32 = x.H, x.W
+    spp = bb.dark5[1]
+    hid = spp.conv1.conv.out_channels
+    sppcat = b.buf(N, h32, w32, 4 * hid)                 # cat[x, pool5, pool9, pool13]  (trap T5)
+    b.conv(spp.conv1, x, sppcat.slice(0, hid), tag="spp.conv1")
+    b.ops.append(SppOp(sppcat))
+    x = b.conv(spp.conv2, sppcat, tag="spp.conv2")
+    d5 = b.csp(bb.dark5[2], x, tag="dark5.2")
+    catN4 = b.buf(N, h32, w32, 2 * c4)                   # cat[bu_conv1(pan1), fpn_out0]  (:139)
+    fpn0 = b.conv(pafpn.lateral_conv0, d5, catN4.slice(c4, c4), tag="lateral_conv0")
+    b.ops.append(ResizeOp(fpn0, catP4.slice(0, c4)))     # F.interpolate(size=x1.shape[2:4]) (:125)
+    f_out0 = b.csp(pafpn.C3_p4, catP4, tag="C3_p4")
+    catN3 = b.buf(N, h16, w16, 2 * c3)                   # cat[bu_conv2(pan2), fpn_out1]  (:135)
+    fpn1 = b.conv(pafpn.reduce_conv1, f_out0, catN3.slice(c3, c3), tag="reduce_conv1")
+    b.ops.append(ResizeOp(fpn1, catP3.slice(0, c3)))     # (:130)
+    pan2 = b.csp(pafpn.C3_p3, catP3, tag="C3_p3")
+    b.conv(pafpn.bu_conv2, pan2, catN3.slice(0, c3), tag="bu_conv2")
+    pan1 = b.csp(pafpn.C3_n3, catN3, tag="C3_n3")
+    b.conv(pafpn.bu_conv1, pan1, catN4.slice(0, c4), tag="bu_conv1")
+    pan0 = b.csp(pafpn.C3_n4, catN4, tag="C3_n4")
+    return f0, (pan2, pan1, pan0)
+
+
+def build_fuse_net(b, pafpn, cur, sup):
+    """DFP: out_K = cat[jianK(cur_K), jianK(sup_K)] + cur_K (dfp_pafpn.py:168-170): the `+ cur_K`
+    is the residual epilogue of the two jian launches, the cat is their channel slices."""
+    fused = []
+    for mod, c, s, name in zip((pafpn.jian2, pafpn.jian1, pafpn.jian0), cur, sup, ("jian2", "jian1", "jian0")):
+        half = c.C // 2
+        out = b.buf(c.N, c.H, c.W, c.C)
+        b.conv(mod, c, out.slice(0, half), res=c.slice(0, half), tag=name + ".cur")
+        b.conv(mod, s, out.slice(half, half), res=c.slice(half, half), tag=name + ".sup")
+        fused.append(out)
+    return tuple(fused)
+
+
+def build_head_net(b, head, feats):
+    """TALHead towers (tal_head.py:159-171).  Returns per-level PredOps appended to b.ops."""
+    a0 = 0
+    preds = []
+    for k, x in enumerate(feats):
+        st = b.conv(head.stems[k], x, tag="head.stem%d" % k)
+        c = b.conv(head.cls_convs[k][0], st, tag="head.cls%d.0" % k)
+        c = b.conv(head.cls_convs[k][1], c, tag="head.cls%d.1" % k)
+        r = b.conv(head.reg_convs[k][0], st, tag="head.reg%d.0" % k)
+        r = b.conv(head.reg_convs[k][1], r, tag="head.reg%d.1" % k)
+        op = PredOp(k, head.cls_preds[k], head.reg_preds[k], head.obj_preds[k], c, r, a0, head.strides[k])
+        b.ops.append(op)
+        preds.append(op)
+        a0 += x.H * x.W
+    return preds, a0
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter cache (packed K-contiguous weights + folded BN), refreshed when a parameter changes
+# ------------------------------------------------------------------------------------------------
+class ParamCache:
+    def __init__(self, dtype, device):
+        self.dtype, self.device = ops.dtype_code(dtype), device
+        self.entries = {}
+
+    @staticmethod
+    def _ver(*ts):
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def conv_eval(self, mod):
+        """(packed weight, scale, shift) with eval-mode BN folded (eps read at call time — trap T1)."""
+        bn = mod.bn
+        key = ("eval", id(mod))
+        ver = self._ver(mod.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var) + (bn.eps,)
+        e = self.entries.get(key)
+        if e is None or e[0] != ver:
+            w = self._pack(mod.conv.weight)
+            scale, shift = fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            e = (ver, w, scale.to(self.device), shift.to(self.device))
+            self.entries[key] = e
+        return e[1:]
+
+    def _pack(self, w, transpose=False):
+        cin = w.shape[1]
+        pad = 16 if cin == 12 else None                  # Focus stem: 12 -> 16 channels (zero weights)
+        return pack_conv_weight(w.detach().float(), self.dtype, transpose=transpose, pad_cin_to=pad).to(self.device)
+
+    def conv_weight(self, mod, transpose=False):
+        key = ("w", id(mod), transpose)
+        ver = self._ver(mod.conv.weight)
+        e = self.entries.get(key)
+        if e is None or e[0] != ver:
+            e = (ver, self._pack(mod.conv.weight, transpose))
+            self.entries[key] = e
+        return e[1]
+
+    def pred(self, op):
+        """Packed (reg|obj) [5 -> rows, Cin] and cls [nc, Cin] weights + fp32 biases."""
+        key = ("pred", id(op.cls_mod))
+        ver = self._ver(op.cls_mod.weight, op.cls_mod.bias, op.reg_mod.weight, op.reg_mod.bias,
+                        op.obj_mod.weight, op.obj_mod.bias)
+        e = self.entries.get(key)
+        if e is None or e[0] != ver:
+            w_ro = torch.cat([op.reg_mod.weight.detach().float(), op.obj_mod.weight.detach().float()], 0)
+            b_ro = torch.cat([op.reg_mod.bias.detach().float(), op.obj_mod.bias.detach().float()], 0)
+            e = (ver,
+                 pack_conv_weight(w_ro, self.dtype).to(self.device), b_ro.contiguous().to(self.device),
+                 pack_conv_weight(op.cls_mod.weight.detach().float(), self.dtype).to(self.device),
+                 op.cls_mod.bias.detach().float().contiguous().to(self.device),
+                 pack_conv_weight(w_ro, self.dtype, transpose=True, pad_cout_to=8).to(self.device),
+                 pack_conv_weight(op.cls_mod.weight.detach().float(), self.dtype, transpose=True).to(self.device))
+            self.entries[key] = e
+        return e[1:]
+
+
+# ------------------------------------------------------------------------------------------------
+# inference plan (eval off_pipe / on_pipe)
+# ------------------------------------------------------------------------------------------------
+class InferencePlan:
+    """mode 'off_pipe': frames [B,6,H,W] -> decoded [B,A,5+nc]   (yolox.py:31-50, dfp_pafpn.py:109-175)
+       mode 'on_pipe' : frame  [B,3,H,W] + buffer -> (decoded, buffer')   (yolox.py:51-55, dfp_pafpn.py:177-228)
+    Either part may be absent (pafpn only / head only) for the stand-alone module entry points."""
+
+    def __init__(self, pafpn, head, mode, B, H, W, dtype, device, decode=True):
+        self.pafpn, self.head, self.mode = pafpn, head, mode
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.dtype = ops.dtype_code(dtype)
+        self.decode = decode
+        self.cache = ParamCache(self.dtype, device)
+        b = _Builder(self.dtype, device)
+        self.b = b
+        self.pair = (mode == "off_pipe")
+        self.fused = None
+        if pafpn is not None:
+            n_img = 2 * B if self.pair else B
+            self.f0, pans = build_frame_net(b, pafpn, n_img, H, W)
+            if self.pair:
+                cur = tuple(_batch_slice(p, 0, B) for p in pans)
+                sup = tuple(_batch_slice(p, B, B) for p in pans)
+                self.cur_pans = cur
+            else:
+                cur = pans
+                self.cur_pans = pans
+                # the support-frame inputs of the fusion are re-pointed at the caller's buffer per call
+                sup = tuple(View.alloc(p.N, p.H, p.W, p.C, self.dtype, device, zero=True) for p in pans)
+            self.sup_in = sup
+            self.fused = build_fuse_net(b, pafpn, cur, sup)
+        self.n_backbone_ops = len(b.ops)
+        self.preds, self.A, self.out = None, 0, None
+        if head is not None:
+            if self.fused is None:
+                w = head.width
+                self.fused = tuple(b.buf(B, math.ceil(H / s), math.ceil(W / s), int(c * w))
+                                   for s, c in zip(head.strides, head.in_channels_))
+            self.preds, self.A = build_head_net(b, head, self.fused)
+            self.nc = head.num_classes
+            self.out = torch.empty((B, self.A, 5 + self.nc), dtype=torch.float32, device=device)
+        self.ops = b.ops
+
+    # -- execution --------------------------------------------------------------------------------
+    def _run_op(self, op):
+        if op.kind == "conv":
+            w, scale, shift = self.cache.conv_eval(op.mod)
+            ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU)
+        elif op.kind == "resize":
+            ops.resize_nearest(op.src, op.dst)
+        elif op.kind == "spp":
+            ops.spp_pool(op.v)
+        elif op.kind == "pred":
+            w_ro, b_ro, w_c, b_c = self.cache.pred(op)[:4]
+            nch = 5 + self.nc
+            base = self.out.data_ptr() + op.a0 * nch * 4
+            ybs = self.A * nch
+            dec = self.decode
+            ops.conv2d(op.reg_x, w_ro, None, 1, 1, None, b_ro, epilogue=EPI_DECODE if dec else EPI_LINEAR,
+                       dec_stride=op.stride, y_f32=True, y_ptr=base, y_ld=nch, y_bs=ybs, cout=5)
+            ops.conv2d(op.cls_x, w_c, None, 1, 1, None, b_c, epilogue=EPI_SIGMOID, y_f32=True,
+                       y_ptr=base + 5 * 4, y_ld=nch, y_bs=ybs, cout=self.nc)
+        else:
+            raise AssertionError(op.kind)
+
+    def run_backbone(self, x, buffer=None):
+        """x: [B,6,H,W] (off_pipe) or [B,3,H,W] (on_pipe) float tensor on self.device.
+        on_pipe: `buffer` = the 3 pre-fusion PAN tensors returned by the previous call, or None for the
+        first frame, which fuses with itself (node 'star', dfp_pafpn.py:211-214)."""
+        x = x.float().contiguous()
+        B = self.B
+        n_fuse = 6
+        if self.pair:
+            ops.focus_pack(x, 0, _batch_slice(self.f0, 0, B))          # current frame  (dfp_pafpn.py:120)
+            ops.focus_pack(x, 3, _batch_slice(self.f0, B, B))          # support frame  (:145)
+        else:
+            ops.focus_pack(x, 0, self.f0)
+        for op in self.ops[:self.n_backbone_ops - n_fuse]:
+            self._run_op(op)
+        if not self.pair:
+            src = self.cur_pans if buffer is None else buffer
+            for dst, s in zip(self.sup_in, src):
+                dst.buf = s.buf if isinstance(s, View) else _nhwc_of(s, dst)
+        for op in self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]:
+            self._run_op(op)
+        return self.fused
+
+    def export_buffer(self):
+        """The current frame's PRE-fusion PAN outputs as NCHW-shaped (channels-last memory) tensors:
+        what the reference returns as `buffer_` (dfp_pafpn.py:226) and takes back next frame."""
+        return tuple(p.buf.clone().permute(0, 3, 1, 2) for p in self.cur_pans)
+
+    def run_head(self):
+        for op in self.ops[self.n_backbone_ops:]:
+            self._run_op(op)
+        if not self.decode:
+            # decode_in_inference=False (tal_head.py:220-223): boxes stay raw, obj/cls are still sigmoids
+            self.out[..., 4].sigmoid_()
+        return self.out
+
+    def run(self, x, buffer=None):
+        self.run_backbone(x, buffer)
+        return self.run_head()
+
+
+def _nhwc_of(t, like):
+    """NHWC storage of a caller-supplied NCHW-shaped feature tensor, in the plan's dtype."""
+    u = t.permute(0, 2, 3, 1)
+    if u.dtype != like.buf.dtype or not u.is_contiguous():
+        u = u.to(like.buf.dtype).contiguous()
+    assert tuple(u.shape) == (like.N, like.H, like.W, like.C), "on_pipe buffer has the wrong shape"
+    return u
+
+
+def _batch_slice(v, n0, n):
+    """Images [n0, n0+n) of a View (same channel slice)."""
+    sub = v.buf.view(v.N, v.H, v.W, v.ld)[n0:n0 + n]
+    return View(sub, n, v.H, v.W, v.C, v.ld, v.c_off)

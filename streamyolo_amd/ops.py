@@ -119,8 +119,8 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
-def conv2d_wgrad(x, dy, dw, ksize, stride):
-    """dw [Cout, k*k*Cin] fp32 += wgrad(x, dy)."""
+def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, cin=None):
+    """dw fp32 += wgrad(x, dy): [Cout, k*k*Cin] packed layout, or the OIHW parameter layout."""
     d = WgradDesc()
     d.x, d.dy, d.dw = x.ptr(), dy.ptr(), dw.data_ptr()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
@@ -129,6 +129,7 @@ def conv2d_wgrad(x, dy, dw, ksize, stride):
     d.stride, d.pad = stride, (ksize - 1) // 2
     d.ldx, d.lddy, d.xbs, d.dybs = x.ld, dy.ld, x.bs, dy.bs
     d.dtype = x.dtype
+    d.dw_oihw = 1 if oihw else 0
     check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")
 
 

@@ -59,7 +59,13 @@ def synth_state_dict(shapes, seed=0, bn_stats=None):
         elif key.endswith(".weight") and len(shp) == 4:
             fan_in = shp[1] * shp[2] * shp[3]
             is_pred = "_preds." in key
-            std = math.sqrt((1.0 if is_pred else 2.5) / fan_in)
+            # prediction convs are kept small so box logits stay in a trained model's range (wh = exp(v)*stride)
+            if "reg_preds" in key:
+                std = 0.05 / math.sqrt(fan_in)
+            elif is_pred:                    # obj / cls logits spread enough for some anchors to pass conf 0.01
+                std = 0.8 / math.sqrt(fan_in)
+            else:
+                std = math.sqrt(2.5 / fan_in)
             t = torch.randn(shp, generator=g) * std
         elif key.endswith(".bias"):
             if "cls_preds" in key or "obj_preds" in key:
