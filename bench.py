@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the StreamYOLO dual-frame hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--workload train|infer] [--model l] [--batch 8]
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one batch of synthetic 600x960 frame pairs that are already
+resident in HBM when the timed region starts:
+    train : forward + Trend-Aware loss + backward (+ RCCL gradient all-reduce when N>1), BASELINE.json configs[2]
+    infer : eval forward + decode (configs[1]-style)
+One process per GPU; W untimed warm-up steps, then EXACTLY K steps between barrier+synchronize
+pairs; time = MAX over ranks; rank 0 prints ONE JSON line.  `value` = frame pairs per second over
+all N GPUs (weak scaling: the per-GPU batch is fixed).
+
+Extra objects on the line:
+  roofline     — dominant kernel (conv_igemm / conv_wgrad on the MFMA units): algorithmic conv FLOPs per
+                 step (2*Cin*Cout*k^2*Ho*Wo, x3 for fwd+bwd) / the summed duration of
+                 those kernels per step, measured live with HIP events on the launch stream.
+  cpu_baseline — the CPU oracle (oracle/streamyolo_oracle.py, a torch-CPU restatement pinned to the
+                 reference; kind "port") timed on this box's host cores on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=[None, "train", "infer"])
+    ap.add_argument("--model", default="l")
+    ap.add_argument("--batch", type=int, default=8, help="frame pairs per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph when possible")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, workload, flops_pair):
+    """Oracle (reference restatement) on the host cores: bounded sample, same shapes, batch 1."""
+    from oracle import streamyolo_oracle as O
+    from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig.named(args.model)
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    x = synth_frames(1, args.height, args.width, seed=2)
+    lab, sup = synth_labels(1, args.height, args.width, cfg.num_classes, seed=3)
+
+    def once():
+        if workload == "train":
+            s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running_" not in k else v.clone())
+                 for k, v in sd.items()}
+            out = O.forward_train(s, x, lab, sup, cfg)
+            out["total_loss"].backward()
+        else:
+            O.forward_eval(sd, x, cfg)
+    once()                                        # warm-up (oneDNN primitive caches)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        once()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or n >= 50:
+            break
+    return {"value": n / el, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d x (StreamYOLO-%s %dx%d batch 1 %s, torch CPU fp32 oracle restatement of the reference)"
+                      % (n, args.model, args.height, args.width,
+                         "fwd+TAL loss+bwd" if workload == "train" else "eval fwd+decode"),
+            "gflops_effective": n * flops_pair / el / 1e9}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
+
+    import streamyolo_amd as sy
+    from oracle import streamyolo_oracle as O                   # FLOP accounting + cpu_baseline leg only
+    from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels, load_bn_stats
+
+    workload = args.workload
+    if workload is None:
+        try:
+            from streamyolo_amd import train_engine  # noqa: F401
+            workload = "train"
+        except ImportError:
+            workload = "infer"
+
+    cfg = O.OracleConfig.named(args.model)
+    flops_fwd = O.conv_flops_per_pair(cfg, args.height, args.width)
+    flops_pair = flops_fwd * (3.0 if workload == "train" else 1.0)
+
+    model = sy.build_model(args.model)
+    bn = load_bn_stats(args.model) if args.model in ("nano", "s", "l") else None
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=bn), strict=True)
+    model = model.to(dev).set_compute_dtype(args.dtype)
+    B = args.batch
+    x = synth_frames(B, args.height, args.width, seed=2 + rank).to(dev)
+
+    if workload == "train":
+        from streamyolo_amd.train_engine import TrainStep
+        lab, sup = synth_labels(B, args.height, args.width, cfg.num_classes, seed=3 + rank)
+        stepper = TrainStep(model, world_size=world, process_group=dist)
+        lab, sup = lab.to(dev), sup.to(dev)
+
+        def step():
+            return stepper.step(x, (lab, sup))
+        profile = stepper.profile
+    else:
+        model.eval()
+        plan = model._plans.inference(model.backbone, model.head, "off_pipe", x, owner=model)
+        graph = None
+
+        def eager():
+            with torch.no_grad():
+                return plan.run(x)
+        if args.graph:
+            for _ in range(2):
+                eager()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eager()
+
+        def step():
+            if graph is not None:
+                graph.replay()
+            else:
+                eager()
+        profile = lambda n: plan.profile(x, n)                  # noqa: E731
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernels, HIP events on the launch stream (rank 0) -----------------
+    roofline = None
+    if rank == 0:
+        prof = profile(3)                                       # {kind: ms per step}
+        mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad"))
+        ach = flops_pair * B / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel" + ("+conv_wgrad_kernel" if workload == "train" else ""),
+                    "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": None,
+                    "flops_per_step": flops_pair * B, "kernel_ms_per_step": mfma_ms,
+                    "per_kind_ms": {k: round(v, 4) for k, v in prof.items()},
+                    "whole_step_frac": flops_pair * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, workload, flops_pair)
+
+    if rank == 0:
+        line = {
+            "metric": "frame-pairs/sec (600x960) StreamYOLO-%s %s" % (args.model, "fwd+bwd" if workload == "train" else "fwd (eval)"),
+            "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "StreamYOLO-%s %dx%d %s, %d frame pairs/GPU/step, %s"
+                                   % (args.model, args.height, args.width,
+                                      "training step: dual-frame forward + TAL loss + backward" if workload == "train"
+                                      else "eval forward off_pipe + decode", B,
+                                      "random-init synthetic weights (utils/synth.py)"),
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "hipgraph": bool(args.graph)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

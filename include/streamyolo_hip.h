@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 #define SY_ABI_VERSION 1
+#define SY_API __attribute__((visibility("default")))
 
 enum { SY_DT_BF16 = 0, SY_DT_F16 = 1, SY_DT_F32 = 2 };
 
@@ -72,7 +73,7 @@ typedef struct sy_conv_desc {
  * (call sites exps/model/darknet.py:115-165, dfp_pafpn.py:33-105,168-170, tal_head.py:55-131,162-171),
  * the Bottleneck shortcut add, the DFP `+ current` add (dfp_pafpn.py:168-170), the eval-time
  * sigmoid/decode of tal_head.py:197-199,245-260, and (mode DGRAD) cuDNN's backward-data. */
-int sy_conv2d(const sy_conv_desc* d, void* stream);
+SY_API int sy_conv2d(const sy_conv_desc* d, void* stream);
 
 /* Weight gradient (fp32, +=): dw[co][tap][ci] = sum_pixels dy[p][co] * x[p@tap][ci]; with
  * dw_oihw = 1 the result lands in the nn.Parameter layout [Cout][Cin][KH][KW] (so .grad can be a
@@ -84,22 +85,22 @@ typedef struct sy_wgrad_desc {
     int32_t dtype;
     int32_t dw_oihw;
 } sy_wgrad_desc;
-int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
+SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
 
 /* Focus space-to-depth (trap T4: TL,BL,TR,BR) fused with NCHW fp32 -> NHWC `dtype` conversion.
  * in: [N, Ctot, H, W] fp32 planes, takes channels [c0, c0+3); out: [N, H/2, W/2, 16] (12 used, 4 zero).
  * Replaces yolox Focus.forward slicing + cat (exps/model/darknet.py:115) and torch.split (dfp_pafpn.py:120,145). */
-int sy_focus_pack(const float* in, int N, int Ctot, int c0, int H, int W, void* out, int dtype, void* stream);
+SY_API int sy_focus_pack(const float* in, int N, int Ctot, int c0, int H, int W, void* out, int dtype, void* stream);
 
 /* Nearest-neighbour resize to a target SIZE (trap T3), writing into a channel slice.
  * Replaces F.interpolate(size=..., mode='nearest') + torch.cat (dfp_pafpn.py:125-126,130-131). */
-int sy_resize_nearest(const void* in, int N, int Hi, int Wi, int C, int ldi, int64_t ibs,
+SY_API int sy_resize_nearest(const void* in, int N, int Hi, int Wi, int C, int ldi, int64_t ibs,
                       void* out, int Ho, int Wo, int ldo, int64_t obs, int dtype, void* stream);
 
 /* SPP pooling: buf holds x in channels [0,C) of a 4C-wide view; writes maxpool 5/9/13 (stride 1,
  * -inf padding) into [C,2C), [2C,3C), [3C,4C) (trap T5).  Replaces SPPBottleneck's three
  * nn.MaxPool2d + cat (exps/model/darknet.py:156). */
-int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, int dtype, void* stream);
+SY_API int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, int dtype, void* stream);
 
 /* Box decode + confidence filter + class-aware greedy NMS for a batch of images.
  * pred: [B, A, 5+nc] fp32 (cx,cy,w,h,obj,cls...) as produced by the head (tal_head.py:245-260).
@@ -108,45 +109,45 @@ int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, int d
  * Replaces yolox.utils.postprocess (exps/evaluators/onex_stream_evaluator.py:148-150) and the
  * inline `inference()` of sAP/streamyolo/streamyolo_det.py:62-83 incl. torchvision batched_nms.
  * `workspace` must hold sy_postprocess_workspace_bytes(B, A) bytes. */
-int64_t sy_postprocess_workspace_bytes(int B, int A);
-int sy_postprocess(const float* pred, int B, int A, int num_classes, float conf_thre, float nms_thre,
+SY_API int64_t sy_postprocess_workspace_bytes(int B, int A);
+SY_API int sy_postprocess(const float* pred, int B, int A, int num_classes, float conf_thre, float nms_thre,
                    int max_det, float* out_det, int32_t* out_index, int32_t* out_count,
                    void* workspace, void* stream);
 
 /* Training-mode BatchNorm helpers around sy_conv2d(stat_sum/stat_sqsum).
  * Replaces nn.BatchNorm2d in training mode (momentum/eps patched by init_yolo, cfgs/<name>.py:40-44). */
-int sy_bn_finalize(const float* sum, const float* sqsum, int C, double count, const float* gamma,
+SY_API int sy_bn_finalize(const float* sum, const float* sqsum, int C, double count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* scale, float* shift, float* mean, float* invstd,
                    void* stream);
 /* a = silu(scale*y + shift) [+ res], y raw conv output; views as in sy_conv2d. */
-int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res,
+SY_API int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res,
                      int ldr, void* out, int ldo, int64_t pixels, int C, int dtype, void* stream);
 /* Backward of (BN-train + SiLU): reduce pass then apply pass.
  * reduce: sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat, with dz = da * silu'(scale*y+shift). */
-int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,
+SY_API int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,
                           const float* shift, const float* mean, const float* invstd, float* sums,
                           int64_t pixels, int C, int dtype, void* stream);
 /* apply: dy = gamma*invstd*(dz - sums0/M - xhat*sums1/M); optionally dgamma += sums1, dbeta += sums0. */
-int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
+SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                          const float* shift, const float* mean, const float* invstd,
                          const float* gamma, const float* sums, void* dy, int lddy, int64_t pixels,
                          int C, float* dgamma, float* dbeta, int dtype, void* stream);
 
 /* elementwise helpers on views: out (+)= in */
-int sy_view_copy(const void* in, int ldi, void* out, int ldo, int64_t pixels, int C, int dtype,
+SY_API int sy_view_copy(const void* in, int ldi, void* out, int ldo, int64_t pixels, int C, int dtype,
                  int accumulate, void* stream);
 
 /* backward of sy_resize_nearest (scatter-add into the source grid) */
-int sy_resize_nearest_bwd(const void* dout, int N, int Ho, int Wo, int C, int lddo, int64_t dobs,
+SY_API int sy_resize_nearest_bwd(const void* dout, int N, int Ho, int Wo, int C, int lddo, int64_t dobs,
                           void* din, int Hi, int Wi, int lddi, int64_t dibs, int accumulate,
                           int dtype, void* stream);
 /* backward of sy_spp_pool: dbuf holds grads of the 4 slices; folds pooled grads into slice 0 */
-int sy_spp_pool_bwd(const void* buf, void* dbuf, int N, int H, int W, int C, int ld, int64_t bs,
+SY_API int sy_spp_pool_bwd(const void* buf, void* dbuf, int N, int H, int W, int C, int ld, int64_t bs,
                     int dtype, void* stream);
 
-const char* sy_version(void);
-int sy_abi_version(void);
+SY_API const char* sy_version(void);
+SY_API int sy_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -338,6 +338,34 @@ class InferencePlan:
         self.run_backbone(x, buffer)
         return self.run_head()
 
+    def profile(self, x, iters=3):
+        """Per-op-kind kernel time (ms per forward), HIP events recorded on the launch stream around
+        every op (bench.py's roofline leg; adds host gaps, so not used for the throughput number)."""
+        assert x.is_cuda
+        x = x.float().contiguous()
+        totals = {}
+        evs = []
+
+        def timed(kind, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            evs.append((kind, a, b))
+        for _ in range(iters):
+            B = self.B
+            if self.pair:
+                timed("focus", lambda: (ops.focus_pack(x, 0, _batch_slice(self.f0, 0, B)),
+                                        ops.focus_pack(x, 3, _batch_slice(self.f0, B, B))))
+            else:
+                timed("focus", lambda: ops.focus_pack(x, 0, self.f0))
+            for op in self.ops:
+                timed(op.kind, lambda op=op: self._run_op(op))
+        torch.cuda.synchronize()
+        for kind, a, b in evs:
+            totals[kind] = totals.get(kind, 0.0) + a.elapsed_time(b)
+        return {k: v / iters for k, v in totals.items()}
+
 
 def _nhwc_of(t, like):
     """NHWC storage of a caller-supplied NCHW-shaped feature tensor, in the plan's dtype."""
