@@ -50,11 +50,24 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole socket inside a container and oversubscribes torch)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(args, workload, flops_pair):
     """Oracle (reference restatement) on the host cores: bounded sample, same shapes, batch 1."""
     from oracle import streamyolo_oracle as O
     from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     torch.set_num_threads(cores)
     cfg = O.OracleConfig.named(args.model)
     sd = synth_state_dict(O.param_shapes(cfg), seed=0)

@@ -34,12 +34,13 @@ def stream_of(t):
 
 class View:
     """NHWC activation view: a channel slice [c_off, c_off+C) of a dense [N,H,W,ld] buffer."""
-    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c_off")
+    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c_off", "bs_")
 
-    def __init__(self, buf, N, H, W, C_, ld=None, c_off=0):
+    def __init__(self, buf, N, H, W, C_, ld=None, c_off=0, bs=None):
         self.buf, self.N, self.H, self.W, self.C = buf, N, H, W, C_
         self.ld = C_ if ld is None else ld
-        self.c_off = c_off
+        self.c_off = c_off            # element offset of the view's first element inside `buf`
+        self.bs_ = bs                 # explicit batch stride (elements) when images are not densely packed
 
     @staticmethod
     def alloc(N, H, W, C_, dtype, device, zero=False):
@@ -48,7 +49,7 @@ class View:
 
     @property
     def bs(self):
-        return self.H * self.W * self.ld
+        return self.H * self.W * self.ld if self.bs_ is None else self.bs_
 
     @property
     def dtype(self):
@@ -63,7 +64,7 @@ class View:
 
     def slice(self, c0, c):
         assert 0 <= c0 and c0 + c <= self.C
-        return View(self.buf, self.N, self.H, self.W, c, self.ld, self.c_off + c0)
+        return View(self.buf, self.N, self.H, self.W, c, self.ld, self.c_off + c0, self.bs_)
 
     def like(self, zero=False):
         """A fresh dense buffer with the same full layout (used for gradient mirrors)."""

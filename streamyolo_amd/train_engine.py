@@ -1,0 +1,365 @@
+"""Training plan: dual-frame forward, Trend-Aware loss and the full backward pass as a static list
+of HIP kernel launches (the measured unit of BASELINE.json: StreamYOLO-l fwd+bwd at 600x960).
+
+What the reference does for one `Trainer.train_one_iter` (exps/train_utils/double_trainer.py:95-131):
+autocast forward through ~260 eager modules (conv, BN, SiLU, cat, interpolate as separate
+kernels), a host-synchronising assignment loop, then autograd's generic backward.  Here:
+
+  forward   per BaseConv: MFMA conv emitting raw output + per-channel sum / sum^2 (fp32 accumulators)
+            -> sy_bn_finalize (batch statistics, running-stat update with the module's momentum/eps —
+            trap T1) -> sy_bn_silu_apply (+ Bottleneck / DFP residual) into the consumer's channel
+            slice.  Current frame first, then support frame, with SEPARATE statistics (trap T2).
+  loss      raw [B, A, 5+nc] fp32 -> TAL loss (model/tal_loss.py) -> d_raw.
+  backward  reverse walk: BN/SiLU backward (reduce + apply), MFMA wgrad straight into a flat fp32
+            gradient arena laid out like the parameters (so .grad tensors are views of it and the
+            RCCL all-reduce is ONE collective over one buffer), MFMA dgrad into gradient mirrors of
+            the activation buffers (fan-in = accumulate epilogue; torch.cat backward = channel slices).
+  DDP       one process per GPU; `TrainStep` all-reduces the arena over RCCL (xGMI) once per step.
+
+`train_forward` is the drop-in path (YOLOX.forward in training mode returns the reference's loss
+dict whose total_loss.backward() fills .grad through one autograd.Function); `TrainStep` is the
+sync-free fast path bench.py and a native trainer use.
+"""
+import torch
+
+from . import ops
+from .engine import (ConvOp, PredOp, ResizeOp, SppOp, ParamCache, _Builder, build_frame_net, build_fuse_net,
+                     build_head_net)
+from .model.packing import pack_conv_weight
+from .model.plan_cache import compute_dtype_for
+from .model.tal_loss import tal_loss
+from .ops import View, EPI_LINEAR, CONV_DGRAD
+
+
+class _GradSpace:
+    """Gradient mirrors of activation buffers + first-write / accumulate bookkeeping per channel range."""
+
+    def __init__(self):
+        self.mirror = {}          # id(buf tensor) -> grad tensor
+        self.written = {}         # id(buf tensor) -> list of (c0, c1)
+
+    def reset(self):
+        self.written = {}
+
+    def view(self, v):
+        g = self.mirror.get(id(v.buf))
+        if g is None:
+            g = torch.empty_like(v.buf)
+            self.mirror[id(v.buf)] = g
+        return View(g, v.N, v.H, v.W, v.C, v.ld, v.c_off, v.bs_)
+
+    def target(self, v):
+        """(grad view, accumulate?) for writing the gradient of activation view `v`."""
+        iv = self.written.setdefault(id(v.buf), [])          # sorted, merged, disjoint [a, b) channel ranges
+        c0, c1 = v.c_off, v.c_off + v.C
+        assert v.bs_ is None and c1 <= v.ld
+        gaps, pos = [], c0
+        for a, b in iv:
+            if b <= pos or a >= c1:
+                continue
+            if a > pos:
+                gaps.append((pos, a))
+            pos = max(pos, b)
+        if pos < c1:
+            gaps.append((pos, c1))
+        g = self.view(v)
+        if len(gaps) == 1 and gaps[0] == (c0, c1):
+            accumulate = False                                   # nothing written yet: plain store
+        else:
+            accumulate = True                                    # (partly) written: zero the holes, then +=
+            flat = g.buf.view(-1, v.ld)
+            for a, b in gaps:
+                flat[:, a:b].zero_()
+        if gaps:
+            merged = []
+            for a, b in sorted(iv + [(c0, c1)]):
+                if merged and a <= merged[-1][1]:
+                    merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+                else:
+                    merged.append((a, b))
+            iv[:] = merged
+        return g, accumulate
+
+
+class TrainPlan:
+    def __init__(self, model, B, H, W, dtype, device):
+        self.model, self.B, self.H, self.W, self.device = model, B, H, W, device
+        self.dtype = ops.dtype_code(dtype)
+        self.tdtype = ops.TORCH_DTYPE[self.dtype]
+        pafpn, head = model.backbone, model.head
+        self.head = head
+        self.cache = ParamCache(self.dtype, device)
+        b = _Builder(self.dtype, device)
+        self.f0_cur, cur = build_frame_net(b, pafpn, B, H, W)          # current frame  (dfp_pafpn.py:120-140)
+        self.f0_sup, sup = build_frame_net(b, pafpn, B, H, W)          # support frame  (:145-165), same weights
+        fused = build_fuse_net(b, pafpn, cur, sup)                      # (:168-170)
+        self.preds, self.A = build_head_net(b, head, fused)
+        self.hw = [(f.H, f.W) for f in fused]
+        self.ops = b.ops
+        self.nc = head.num_classes
+        nch = 5 + self.nc
+        self.raw = torch.empty((B, self.A, nch), dtype=torch.float32, device=device)
+        self.dpad = torch.zeros((B, self.A, 16), dtype=self.tdtype, device=device)
+
+        # ---- per-op training state carved out of flat arenas (zeroed with one memset each) ---------
+        convs = [op for op in self.ops if op.kind == "conv"]
+        tot_c = sum(op.y.C for op in convs)
+        self.stat_arena = torch.zeros(2 * tot_c, dtype=torch.float32, device=device)      # sum | sumsq
+        self.bwd_arena = torch.zeros(2 * tot_c, dtype=torch.float32, device=device)       # sum dz | sum dz*xhat
+        self.aff_arena = torch.empty(4 * tot_c, dtype=torch.float32, device=device)       # scale|shift|mean|invstd
+        off = 0
+        max_raw = 0
+        for op in convs:
+            C = op.y.C
+            op.stat = (self.stat_arena[off:off + C], self.stat_arena[tot_c + off:tot_c + off + C])
+            op.bsum = self.bwd_arena[2 * off:2 * off + 2 * C]
+            op.aff = tuple(self.aff_arena[k * tot_c + off:k * tot_c + off + C] for k in range(4))
+            op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
+            max_raw = max(max_raw, op.y.pixels * C)
+            off += C
+        self.dyraw_scratch = torch.empty(max_raw, dtype=self.tdtype, device=device)
+        self.grads = _GradSpace()
+
+        # ---- flat gradient arena in parameter layout ------------------------------------------------
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.arena = torch.zeros(n, dtype=torch.float32, device=device)
+        self.gview = {}
+        o = 0
+        for p in self.params:
+            self.gview[id(p)] = self.arena[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        self.bn_mods = [op.mod.bn for op in convs]
+        self.stem_scratch = None
+        self.pred_scratch = torch.zeros((2, 8, int(256 * head.width)), dtype=torch.float32, device=device)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x):
+        """x [B,6,H,W] float on device -> raw [B, A, 5+nc] fp32 (plan-owned)."""
+        x = x.float().contiguous()
+        self.stat_arena.zero_()
+        ops.focus_pack(x, 0, self.f0_cur)
+        ops.focus_pack(x, 3, self.f0_sup)
+        nch = 5 + self.nc
+        for op in self.ops:
+            k = op.kind
+            if k == "conv":
+                bn = op.mod.bn
+                w = self.cache.conv_weight(op.mod)
+                ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat)
+                scale, shift, mean, invstd = op.aff
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
+                                bn.running_mean, bn.running_var, scale, shift, mean, invstd)
+                ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
+            elif k == "resize":
+                ops.resize_nearest(op.src, op.dst)
+            elif k == "spp":
+                ops.spp_pool(op.v)
+            else:   # pred: raw logits (tal_head.py:174: cat[reg, obj, cls]), decoded later by the loss
+                w_ro, b_ro, w_c, b_c = self.cache.pred(op)[:4]
+                base = self.raw.data_ptr() + op.a0 * nch * 4
+                ops.conv2d(op.reg_x, w_ro, None, 1, 1, None, b_ro, epilogue=EPI_LINEAR, y_f32=True, y_ptr=base,
+                           y_ld=nch, y_bs=self.A * nch, cout=5)
+                ops.conv2d(op.cls_x, w_c, None, 1, 1, None, b_c, epilogue=EPI_LINEAR, y_f32=True, y_ptr=base + 20,
+                           y_ld=nch, y_bs=self.A * nch, cout=self.nc)
+        # num_batches_tracked: +1 per BN call (shared backbone/neck/jian BNs are called twice — trap T2)
+        counts = {}
+        for bn in self.bn_mods:
+            if bn.num_batches_tracked is not None:
+                counts[id(bn)] = (bn.num_batches_tracked, counts.get(id(bn), (None, 0))[1] + 1)
+        if counts:
+            ts, cs = zip(*counts.values())
+            torch._foreach_add_(list(ts), list(cs))
+        return self.raw
+
+    # ------------------------------------------------------------------------------------------------
+    def backward(self, d_raw):
+        """d_raw [B, A, 5+nc] fp32 -> parameter gradients accumulated into self.arena (zeroed here)."""
+        G = self.grads
+        G.reset()
+        self.arena.zero_()
+        self.bwd_arena.zero_()
+        nc, A = self.nc, self.A
+        # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels
+        self.dpad[..., 0:5] = d_raw[..., 0:5]
+        self.dpad[..., 8:8 + nc] = d_raw[..., 5:]
+        for op in reversed(self.ops):
+            k = op.kind
+            if k == "pred":
+                self._pred_backward(op, d_raw)
+            elif k == "conv":
+                self._conv_backward(op)
+            elif k == "resize":
+                dsrc, acc = G.target(op.src)
+                ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
+            elif k == "spp":
+                ops.spp_pool_bwd(op.v, G.view(op.v))
+        return self.arena
+
+    def _pred_backward(self, op, d_raw):
+        G = self.grads
+        hwk = op.reg_x.H * op.reg_x.W
+        B, A, nc = self.B, self.A, self.nc
+        w_ro_t, w_c_t = self.cache.pred(op)[4:6]
+        d_ro = View(self.dpad, B, op.reg_x.H, op.reg_x.W, 8, 16, op.a0 * 16, bs=A * 16)
+        d_c = View(self.dpad, B, op.reg_x.H, op.reg_x.W, nc, 16, op.a0 * 16 + 8, bs=A * 16)
+        g_r, acc_r = G.target(op.reg_x)
+        ops.conv2d(d_ro, w_ro_t, g_r, 1, 1, mode=CONV_DGRAD, accumulate=acc_r)
+        g_c, acc_c = G.target(op.cls_x)
+        ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c)
+        sc = self.pred_scratch
+        sc.zero_()
+        ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1)
+        ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1)
+        cin = op.reg_x.C
+        self.gview[id(op.reg_mod.weight)].view(4, cin).add_(sc[0, 0:4, :cin])
+        self.gview[id(op.obj_mod.weight)].view(1, cin).add_(sc[0, 4:5, :cin])
+        self.gview[id(op.cls_mod.weight)].view(nc, cin).add_(sc[1, 0:nc, :cin])
+        db = d_raw[:, op.a0:op.a0 + hwk].sum((0, 1))
+        self.gview[id(op.reg_mod.bias)].add_(db[0:4])
+        self.gview[id(op.obj_mod.bias)].add_(db[4:5])
+        self.gview[id(op.cls_mod.bias)].add_(db[5:])
+
+    def _conv_backward(self, op):
+        G = self.grads
+        bn = op.mod.bn
+        dY = G.view(op.y)
+        if op.res is not None:                                       # y = silu(bn(conv)) + res
+            dres, acc = G.target(op.res)
+            ops.view_copy(dY, dres, accumulate=acc)
+        scale, shift, mean, invstd = op.aff
+        ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
+        C = op.y.C
+        dyraw = View(self.dyraw_scratch[:op.y.pixels * C].view(op.y.N, op.y.H, op.y.W, C), op.y.N, op.y.H, op.y.W, C)
+        ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, bn.weight, op.bsum, dyraw,
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)])
+        w = op.mod.conv.weight
+        if w.shape[1] == op.x.C:
+            ops.conv2d_wgrad(op.x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True)
+        else:                                                        # Focus stem: 12 real + 4 zero-padded channels
+            if self.stem_scratch is None:
+                self.stem_scratch = torch.zeros((w.shape[0], op.x.C, op.k, op.k), dtype=torch.float32, device=self.device)
+            self.stem_scratch.zero_()
+            ops.conv2d_wgrad(op.x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True)
+            self.gview[id(w)].add_(self.stem_scratch[:, :w.shape[1]])
+        if op.need_dx:
+            dx, acc = G.target(op.x)
+            ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
+                       mode=CONV_DGRAD, accumulate=acc)
+
+    # ------------------------------------------------------------------------------------------------
+    def profile(self, x, targets, iters=2):
+        """Per-op-kind kernel time (ms / step) with HIP events on the launch stream (bench.py roofline)."""
+        import types
+        evs = []
+        real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply",
+                                             "bn_silu_bwd_reduce", "bn_silu_bwd_apply", "resize_nearest",
+                                             "resize_nearest_bwd", "spp_pool", "spp_pool_bwd", "view_copy", "focus_pack")}
+
+        def wrap(name, fn):
+            def inner(*a, **k):
+                kind = name
+                if name == "conv2d":
+                    kind = "dgrad" if k.get("mode", 0) == CONV_DGRAD else "conv"
+                elif name == "conv2d_wgrad":
+                    kind = "wgrad"
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = fn(*a, **k)
+                e.record()
+                evs.append((kind, s, e))
+                return r
+            return inner
+        try:
+            for n, fn in real.items():
+                setattr(ops, n, wrap(n, fn))
+            for _ in range(iters):
+                raw = self.forward(x).detach().requires_grad_(True)
+                loss = tal_loss(raw, self.hw, targets[0], targets[1], self.head)["total_loss"]
+                (d_raw,) = torch.autograd.grad(loss, raw)
+                self.backward(d_raw)
+        finally:
+            for n, fn in real.items():
+                setattr(ops, n, fn)
+        torch.cuda.synchronize()
+        tot = {}
+        for kind, s, e in evs:
+            tot[kind] = tot.get(kind, 0.0) + s.elapsed_time(e)
+        return {k: v / iters for k, v in tot.items()}
+
+
+def get_train_plan(model, x):
+    dt = compute_dtype_for(model, x)
+    B, _, H, W = x.shape
+    key = ("train", B, H, W, dt, str(x.device))
+    plan = model._plans.plans.get(key)
+    if plan is None:
+        plan = TrainPlan(model, B, H, W, dt, x.device)
+        model._plans.plans[key] = plan
+    return plan
+
+
+class _PlanFunction(torch.autograd.Function):
+    """raw = plan.forward(x); backward runs the HIP backward plan and hands each parameter its slice
+    of the gradient arena (so DDP hooks, GradScaler and optimizers see ordinary .grad tensors)."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.plan = plan
+        return plan.forward(x).clone()
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        plan = ctx.plan
+        arena = plan.backward(d_raw.float().contiguous()).clone()
+        outs, o = [], 0
+        for p in plan.params:
+            outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
+            o += p.numel()
+        return (None, None) + tuple(outs)
+
+
+def train_forward(model, x, targets):
+    """YOLOX.forward in training mode (exps/model/yolox.py:33-46): returns the reference's loss dict."""
+    if x.size()[1] == 3:
+        x = torch.cat([x, x], dim=1)
+    assert x.size()[1] == 6
+    plan = get_train_plan(model, x)
+    raw = _PlanFunction.apply(plan, x, *plan.params)
+    labels, support = targets
+    return tal_loss(raw, plan.hw, labels, support, model.head)
+
+
+class TrainStep:
+    """Sync-free training step for bench.py / a native trainer: forward + loss + backward (+ one RCCL
+    all-reduce of the flat gradient arena when world_size > 1); parameters' .grad are arena views."""
+
+    def __init__(self, model, world_size=1, process_group=None):
+        self.model, self.world, self.dist = model, world_size, process_group
+        self.plan = None
+        model.train()
+        model.head.use_l1 = True                    # double_trainer.py:209-216 (no_aug_epochs == max_epoch)
+
+    def _ensure(self, x):
+        if self.plan is None:
+            self.plan = get_train_plan(self.model, x)
+            for p in self.plan.params:
+                p.grad = self.plan.gview[id(p)]
+        return self.plan
+
+    def step(self, x, targets):
+        plan = self._ensure(x)
+        self._last = (x, targets)
+        raw = plan.forward(x).detach().requires_grad_(True)
+        out = tal_loss(raw, plan.hw, targets[0], targets[1], self.model.head)
+        (d_raw,) = torch.autograd.grad(out["total_loss"], raw)
+        plan.backward(d_raw)
+        if self.world > 1:
+            self.dist.all_reduce(plan.arena)        # RCCL over xGMI: one collective over the whole arena
+            plan.arena.div_(self.world)
+        return out
+
+    def profile(self, iters=2):
+        x, targets = self._last
+        return self.plan.profile(x, targets, iters)

@@ -1,0 +1,95 @@
+"""Training-step parity: HIP forward + TAL loss + HIP backward vs the reference's golden losses,
+parameter gradients and BatchNorm running statistics (SURVEY.md §8(d) parity metric)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import streamyolo_amd as sy
+from oracle import streamyolo_oracle as O
+from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
+
+NAMES = ("total_loss", "iou_loss", "l1_loss", "conf_loss", "cls_loss", "num_fg")
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _setup(name, tag, golden_dir, device, dt, ngt=6):
+    z = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, H, W = [int(v) for v in z["shape"]]
+    cfg = O.OracleConfig.named(name)
+    model = sy.build_model(name)
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0), strict=True)
+    model = model.to(device).train().set_compute_dtype(dt)
+    model.head.use_l1 = True
+    x = synth_frames(B, H, W, seed=2).to(device)
+    lab, sup = synth_labels(B, H, W, cfg.num_classes, num_gt=ngt, seed=3)
+    return z, model, x, (lab.to(device), sup.to(device))
+
+
+@pytest.mark.parametrize("dt,ltol,gtol", [("fp32", 1e-3, 2e-3), ("bf16", 1e-1, None)])
+def test_train_step_nano_dropin_autograd(backend, golden_dir, dt, ltol, gtol):
+    z, model, x, targets = _setup("nano", "nano_train_2x64x96", golden_dir, backend, dt)
+    out = model(x, targets)                                  # the reference's call: model(inps, targets)
+    assert set(NAMES) == set(out.keys())
+    out["total_loss"].backward()
+    got = np.array([float(out[k]) for k in NAMES])
+    lerr = np.abs(got - z["losses"]).max() / np.abs(z["losses"]).max()
+    assert lerr < ltol, "loss rel err %.3e (%s vs %s)" % (lerr, got, z["losses"])
+    sd = model.state_dict()
+    # BN running statistics after one step; shared BNs were updated twice (trap T2)
+    for k in z.files:
+        if k.startswith("stat:") and "num_batches" not in k:
+            assert _rel(sd[k[5:]].float().cpu(), z[k]) < max(ltol, 1e-3), k
+    assert int(sd["backbone.backbone.stem.conv.bn.num_batches_tracked"]) == 2
+    assert int(sd["backbone.jian0.bn.num_batches_tracked"]) == 2
+    assert int(sd["head.stems.2.bn.num_batches_tracked"]) == 1
+    if gtol is not None:
+        worst = ("", 0.0)
+        for name, p in model.named_parameters():
+            assert p.grad is not None, name
+            r = _rel(p.grad.cpu(), z["grad:" + name])
+            if r > worst[1]:
+                worst = (name, r)
+        assert worst[1] < gtol, "worst grad rel err %.3e at %s" % (worst[1], worst[0])
+
+
+def test_train_step_fast_path_matches_dropin(backend, golden_dir):
+    from streamyolo_amd.train_engine import TrainStep
+    z, model, x, targets = _setup("nano", "nano_train_2x64x96", golden_dir, backend, "fp32")
+    st = TrainStep(model)
+    out = st.step(x, targets)
+    assert abs(float(out["total_loss"]) - z["losses"][0]) / z["losses"][0] < 1e-3
+    for name, p in model.named_parameters():
+        assert p.grad.data_ptr() == st.plan.gview[id(p)].data_ptr()         # .grad is a view of the arena
+    g = dict(model.named_parameters())["backbone.backbone.dark3.1.m.0.conv2.conv.weight"].grad
+    assert _rel(g.cpu(), z["grad:backbone.backbone.dark3.1.m.0.conv2.conv.weight"]) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,ltol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_train_step_s_160x256(golden_dir, dt, ltol):
+    from streamyolo_amd import _lib
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda:0")
+    z, model, x, targets = _setup("s", "s_train_2x160x256", golden_dir, dev, dt)
+    out = model(x, targets)
+    out["total_loss"].backward()
+    got = np.array([float(out[k]) for k in NAMES])
+    lerr = np.abs(got - z["losses"]).max() / np.abs(z["losses"]).max()
+    print("s train %s: loss rel err %.3e" % (dt, lerr))
+    assert lerr < ltol
+    if dt == "fp32":
+        worst = 0.0
+        for name, p in model.named_parameters():
+            if "grad:" + name in z.files:
+                worst = max(worst, _rel(p.grad.cpu(), z["grad:" + name]))
+        norms = np.array([float(dict(model.named_parameters())[k].grad.double().norm())
+                          for k in sorted(n for n, _ in model.named_parameters())])
+        nerr = np.abs(norms - z["grad_norms"]).max() / np.abs(z["grad_norms"]).max()
+        print("s train fp32: worst small-grad rel err %.3e, grad-norm rel err %.3e" % (worst, nerr))
+        assert worst < 5e-3 and nerr < 2e-3
