@@ -1,0 +1,496 @@
+// tal_loss.hip — SimOTA label assignment + Trend-Aware loss, forward AND gradient, for a whole
+// batch, with no host synchronisation.
+//
+// Replaces TALHead.get_losses / get_assignments / get_in_boxes_info / dynamic_k_matching of the
+// reference (exps/model/tal_head.py:262-470, :479-592, :594-677, :679-712): a per-image Python loop
+// of ~50 tiny kernels with `.item()` / `int()` host syncs and a `torch.cuda.empty_cache()` per image
+// (:306-307, :376, :690, :702), followed by autograd's backward over the same small tensors.
+//
+//   kernel 1  tal_assign   one 1024-thread workgroup per image
+//       candidates  = anchors whose centre lies in any GT box or in any GT's 2.5-stride centre square
+//                     (:644-672), compacted in ascending anchor order (wave ballots + LDS scan)
+//       cost[g][c]  = BCE(sqrt(sigmoid(cls)*sigmoid(obj)), onehot_g) + 3*(-log(IoU+1e-8)) + 1e5*[not in both]
+//                     (:534-553; BCE log terms clamped at -100 like F.binary_cross_entropy)
+//       dynamic k   = clamp(int(sum of the 10 largest IoUs of g), 1)        (:685-687)   -- one wave per GT:
+//       matching    = the k_g cheapest candidates of each GT                 (:688-692)      iterated wave arg-min/max
+//       conflicts   = an anchor claimed by several GTs keeps the arg-min cost over ALL GTs  (:696-700)
+//       trend       = per GT max IoU with the support-frame GTs, < ignore_thr -> ignore_value (:394-406)
+//       plus per-image partial sums of the IoU / L1 losses needed by the TAL weight normalisation (:429-438)
+//   kernel 2  tal_grad     grid-stride over B*A anchors
+//       loss = 5 * sum(w_iou (1 - IoU^2))/N + sum BCE(obj)/N + sum BCE(cls | fg)/N + sum(w_l1 |l1|)/N  (:441-461)
+//       and its closed-form gradient w.r.t. the RAW head output (decode chain rule included: xy*stride,
+//       wh = exp(v)*stride), written for all 5+nc channels of every anchor.
+// Ties (equal costs / IoUs) resolve to the lower candidate index; the reference leaves them to
+// torch.topk, so parity is defined on tie-free inputs.
+#include "sy_device.h"
+#include "../../include/streamyolo_hip.h"
+
+namespace {
+
+constexpr int kAssignThreads = 1024;
+constexpr int kMaxLevels = 8;
+constexpr int kMaxGT = 128;
+
+struct TalGeom {
+    int nlevels;
+    int h[kMaxLevels], w[kMaxLevels], a0[kMaxLevels + 1];
+    float stride[kMaxLevels];
+};
+
+struct TalLayout {       // per-image workspace slices (byte offsets)
+    long long cand_idx, cbox, cobj, csum, cost, iou, mcnt, mgt, agt, aiou, part, image_bytes;
+    int acap;
+};
+
+inline TalLayout tal_layout(int A, int max_gt) {
+    TalLayout L;
+    long long o = 0;
+    L.acap = (A + 63) / 64 * 64;
+    auto take = [&](long long bytes) { long long r = o; o += (bytes + 255) / 256 * 256; return r; };
+    L.cand_idx = take(4LL * L.acap);
+    L.cbox = take(16LL * L.acap);
+    L.cobj = take(4LL * L.acap);
+    L.csum = take(4LL * L.acap);
+    L.cost = take(4LL * L.acap * max_gt);
+    L.iou = take(4LL * L.acap * max_gt);
+    L.mcnt = take(4LL * L.acap);
+    L.mgt = take(4LL * L.acap);
+    L.agt = take(4LL * L.acap);         // per ANCHOR: matched GT index or -1
+    L.aiou = take(4LL * L.acap);        // per ANCHOR: IoU with the matched GT
+    L.part = take((16 + kMaxGT) * 4);   // [0..4] partial sums, [5] #GT, [16+g] trend weight of GT g
+    L.image_bytes = o;
+    return L;
+}
+
+__device__ __forceinline__ void anchor_geom(const TalGeom& g, int a, float& gx, float& gy, float& s) {
+    int l = 0;
+    while (l + 1 < g.nlevels && a >= g.a0[l + 1]) ++l;
+    const int r = a - g.a0[l];
+    const int y = r / g.w[l];
+    gx = (float)(r - y * g.w[l]);
+    gy = (float)y;
+    s = g.stride[l];
+}
+
+__device__ __forceinline__ float clamp_log(float p) { float l = logf(p); return l < -100.0f ? -100.0f : l; }
+
+// IoU of two cxcywh boxes, yolox bboxes_iou(xyxy=False): no epsilon
+__device__ __forceinline__ float iou_cxcywh(float ax, float ay, float aw, float ah, float bx, float by, float bw, float bh) {
+    const float lx = fmaxf(ax - aw / 2, bx - bw / 2), ly = fmaxf(ay - ah / 2, by - bh / 2);
+    const float rx = fminf(ax + aw / 2, bx + bw / 2), ry = fminf(ay + ah / 2, by + bh / 2);
+    const float en = (lx < rx && ly < ry) ? 1.0f : 0.0f;
+    const float inter = (rx - lx) * (ry - ly) * en;
+    return inter / (aw * ah + bw * bh - inter);
+}
+
+// wave-wide arg-min of (value, index): smaller value wins, then smaller index
+__device__ __forceinline__ void wave_argmin(float& v, int& i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+__global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float* raw, int A, int nc, const float* labels,
+                                                                    const float* support, int max_labels, TalGeom geom,
+                                                                    float gamma, float ignore_thr, float ignore_value,
+                                                                    int use_l1, unsigned char* ws, TalLayout L) {
+    __shared__ float s_gt[kMaxGT][4];
+    __shared__ int s_gcls[kMaxGT];
+    __shared__ float s_w[kMaxGT];
+    __shared__ int s_k[kMaxGT];
+    __shared__ int s_wave_cnt[kAssignThreads / 64];
+    __shared__ int s_base, s_G, s_S;
+    __shared__ float s_red[kAssignThreads / 64][8];
+
+    const int img = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kAssignThreads / 64;
+    const int nch = 5 + nc;
+    const float* R = raw + (long long)img * A * nch;
+    const float* LB = labels + (long long)img * max_labels * 5;
+    const float* SP = support + (long long)img * max_labels * 5;
+    unsigned char* wsi = ws + (long long)img * L.image_bytes;
+    int* cand_idx = (int*)(wsi + L.cand_idx);
+    float* cbox = (float*)(wsi + L.cbox);
+    float* cobj = (float*)(wsi + L.cobj);
+    float* csum = (float*)(wsi + L.csum);
+    float* cost = (float*)(wsi + L.cost);
+    float* ioum = (float*)(wsi + L.iou);
+    int* mcnt = (int*)(wsi + L.mcnt);
+    int* mgt = (int*)(wsi + L.mgt);
+    int* agt = (int*)(wsi + L.agt);
+    float* aiou = (float*)(wsi + L.aiou);
+    float* part = (float*)(wsi + L.part);
+
+    // ---- GT bookkeeping: nlabel = #rows with sum > 0; the FIRST nlabel rows are used (:285, :317-319)
+    if (tid == 0) { s_G = 0; s_S = 0; s_base = 0; }
+    __syncthreads();
+    if (tid < max_labels) {
+        const float* r = LB + tid * 5;
+        if (r[0] + r[1] + r[2] + r[3] + r[4] > 0.0f) atomicAdd(&s_G, 1);
+        const float* q = SP + tid * 5;
+        if (q[0] + q[1] + q[2] + q[3] + q[4] > 0.0f) atomicAdd(&s_S, 1);
+    }
+    for (int a = tid; a < A; a += kAssignThreads) { agt[a] = -1; aiou[a] = 0.0f; }
+    __syncthreads();
+    const int G = s_G < kMaxGT ? s_G : kMaxGT;
+    const int S = s_S;
+    if (tid < G) {
+        const float* r = LB + tid * 5;
+        s_gcls[tid] = (int)r[0];
+        s_gt[tid][0] = r[1]; s_gt[tid][1] = r[2]; s_gt[tid][2] = r[3]; s_gt[tid][3] = r[4];
+        // trend weight (:394-406, :429)
+        float tr = 1.0f;
+        if (S > 0) {
+            tr = -INFINITY;
+            for (int s = 0; s < S; ++s) {
+                const float* q = SP + s * 5;
+                tr = fmaxf(tr, iou_cxcywh(r[1], r[2], r[3], r[4], q[1], q[2], q[3], q[4]));
+            }
+            if (tr < ignore_thr) tr = ignore_value;
+        }
+        s_w[tid] = 1.0f / (powf(tr, gamma) + 1e-8f);
+    }
+    __syncthreads();
+    if (tid < 16) part[tid] = (tid == 5) ? (float)G : 0.0f;
+    if (tid < G) part[16 + tid] = s_w[tid];
+    if (G == 0) return;
+
+    // ---- candidates, ascending anchor order -------------------------------------------------------
+    for (int a0 = 0; a0 < A; a0 += kAssignThreads) {
+        const int a = a0 + tid;
+        bool is_cand = false;
+        float gx = 0, gy = 0, st = 1;
+        if (a < A) {
+            anchor_geom(geom, a, gx, gy, st);
+            const float xc = gx * st + 0.5f * st, yc = gy * st + 0.5f * st;
+            const float rad = 2.5f * st;
+            for (int g = 0; g < G && !is_cand; ++g) {
+                const float bx = s_gt[g][0], by = s_gt[g][1], bw = s_gt[g][2], bh = s_gt[g][3];
+                const float bl = xc - (bx - 0.5f * bw), bt = yc - (by - 0.5f * bh);
+                const float br = (bx + 0.5f * bw) - xc, bb = (by + 0.5f * bh) - yc;
+                const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
+                const float cl = xc - (bx - rad), ct = yc - (by - rad), cr = (bx + rad) - xc, cbm = (by + rad) - yc;
+                const bool inc = fminf(fminf(cl, ct), fminf(cr, cbm)) > 0.0f;
+                is_cand = inb || inc;
+            }
+        }
+        const unsigned long long bal = __ballot(is_cand ? 1 : 0);
+        if (lane == 0) s_wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_wave_cnt[w];
+        if (is_cand) {
+            const int c = before + __popcll(bal & ((1ull << lane) - 1ull));
+            const float* r = R + (long long)a * nch;
+            cand_idx[c] = a;
+            cbox[c * 4 + 0] = (r[0] + gx) * st;
+            cbox[c * 4 + 1] = (r[1] + gy) * st;
+            cbox[c * 4 + 2] = expf(r[2]) * st;
+            cbox[c * 4 + 3] = expf(r[3]) * st;
+            const float so = 1.0f / (1.0f + expf(-r[4]));
+            cobj[c] = so;
+            float acc = 0.0f;
+            for (int k = 0; k < nc; ++k) {
+                const float p = sqrtf((1.0f / (1.0f + expf(-r[5 + k]))) * so);
+                acc += -clamp_log(1.0f - p);
+            }
+            csum[c] = acc;
+            mcnt[c] = 0;
+            mgt[c] = -1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = s_base;
+            for (int w = 0; w < NW; ++w) t += s_wave_cnt[w];
+            s_base = t;
+        }
+        __syncthreads();
+    }
+    const int C = s_base;
+    if (C == 0) return;
+
+    // ---- pairwise IoU and cost ------------------------------------------------------------------------
+    for (long long i = tid; i < (long long)G * C; i += kAssignThreads) {
+        const int g = (int)(i / C), c = (int)(i - (long long)g * C);
+        const int a = cand_idx[c];
+        float gx, gy, st;
+        anchor_geom(geom, a, gx, gy, st);
+        const float xc = gx * st + 0.5f * st, yc = gy * st + 0.5f * st, rad = 2.5f * st;
+        const float bx = s_gt[g][0], by = s_gt[g][1], bw = s_gt[g][2], bh = s_gt[g][3];
+        const bool inb = fminf(fminf(xc - (bx - 0.5f * bw), yc - (by - 0.5f * bh)),
+                               fminf((bx + 0.5f * bw) - xc, (by + 0.5f * bh) - yc)) > 0.0f;
+        const bool inc = fminf(fminf(xc - (bx - rad), yc - (by - rad)), fminf((bx + rad) - xc, (by + rad) - yc)) > 0.0f;
+        const float iou = iou_cxcywh(bx, by, bw, bh, cbox[c * 4], cbox[c * 4 + 1], cbox[c * 4 + 2], cbox[c * 4 + 3]);
+        const float* r = R + (long long)a * nch;
+        const float p = sqrtf((1.0f / (1.0f + expf(-r[5 + s_gcls[g]]))) * cobj[c]);
+        const float cls_cost = csum[c] - (-clamp_log(1.0f - p)) + (-clamp_log(p));
+        ioum[(long long)g * L.acap + c] = iou;
+        cost[(long long)g * L.acap + c] = cls_cost + 3.0f * (-logf(iou + 1e-8f)) + ((inb && inc) ? 0.0f : 100000.0f);
+    }
+    __syncthreads();
+
+    // ---- dynamic k + matching: one wave per GT -----------------------------------------------------------
+    for (int g = wave; g < G; g += NW) {
+        const float* irow = ioum + (long long)g * L.acap;
+        float* crow = cost + (long long)g * L.acap;
+        // sum of the 10 largest IoUs: ten arg-max sweeps with a "taken" threshold (value, index) ordering
+        float sum = 0.0f;
+        float last_v = INFINITY;
+        int last_i = -1;
+        const int nk = C < 10 ? C : 10;
+        for (int it = 0; it < nk; ++it) {
+            float bv = INFINITY;          // arg-min of (-iou)
+            int bi = 0x7fffffff;
+            for (int c = lane; c < C; c += 64) {
+                const float v = -irow[c];
+                // skip entries already taken: (v, c) must come strictly after (last_v', last_i) in (value, index) order
+                const float lv = -last_v;
+                const bool after = (it == 0) || (v > lv) || (v == lv && c > last_i);
+                if (after && (v < bv || (v == bv && c < bi))) { bv = v; bi = c; }
+            }
+            wave_argmin(bv, bi);
+            sum += -bv;
+            last_v = -bv;
+            last_i = bi;
+        }
+        int kg = (int)sum;
+        if (kg < 1) kg = 1;
+        if (kg > C) kg = C;
+        if (lane == 0) s_k[g] = kg;
+        float lcv = -INFINITY;
+        int lci = -1;
+        for (int it = 0; it < kg; ++it) {
+            float bv = INFINITY;
+            int bi = 0x7fffffff;
+            for (int c = lane; c < C; c += 64) {
+                const float v = crow[c];
+                const bool after = (it == 0) || (v > lcv) || (v == lcv && c > lci);
+                if (after && (v < bv || (v == bv && c < bi))) { bv = v; bi = c; }
+            }
+            wave_argmin(bv, bi);
+            lcv = bv;
+            lci = bi;
+            if (lane == 0) { atomicAdd(&mcnt[bi], 1); mgt[bi] = g; }
+        }
+    }
+    __syncthreads();
+
+    // ---- conflicts, foreground list, per-image partial sums ----------------------------------------------
+    float p_iou = 0, p_wiou = 0, p_l1 = 0, p_wl1 = 0, p_nfg = 0;
+    for (int c = tid; c < C; c += kAssignThreads) {
+        const int cnt = mcnt[c];
+        if (cnt == 0) continue;
+        int g = mgt[c];
+        if (cnt > 1) {
+            float bv = INFINITY;
+            for (int gg = 0; gg < G; ++gg) {
+                const float v = cost[(long long)gg * L.acap + c];
+                if (v < bv) { bv = v; g = gg; }
+            }
+        }
+        const int a = cand_idx[c];
+        const float miou = ioum[(long long)g * L.acap + c];
+        agt[a] = g;
+        aiou[a] = miou;
+        // IoU loss of this foreground anchor (IOUloss: +1e-16 in the denominator) and its L1 loss
+        const float px = cbox[c * 4], py = cbox[c * 4 + 1], pw = cbox[c * 4 + 2], ph = cbox[c * 4 + 3];
+        const float tx = s_gt[g][0], ty = s_gt[g][1], tw = s_gt[g][2], th = s_gt[g][3];
+        const float lx = fmaxf(px - pw / 2, tx - tw / 2), ly = fmaxf(py - ph / 2, ty - th / 2);
+        const float rx = fminf(px + pw / 2, tx + tw / 2), ry = fminf(py + ph / 2, ty + th / 2);
+        const float en = (lx < rx && ly < ry) ? 1.0f : 0.0f;
+        const float inter = (rx - lx) * (ry - ly) * en;
+        const float iou = inter / (pw * ph + tw * th - inter + 1e-16f);
+        const float il = 1.0f - iou * iou;
+        const float w = s_w[g];
+        p_iou += il;
+        p_wiou += w * il;
+        p_nfg += 1.0f;
+        if (use_l1) {
+            float gx, gy, st;
+            anchor_geom(geom, a, gx, gy, st);
+            const float* r = R + (long long)a * nch;
+            const float l1 = fabsf(r[0] - (tx / st - gx)) + fabsf(r[1] - (ty / st - gy)) +
+                             fabsf(r[2] - logf(tw / st + 1e-8f)) + fabsf(r[3] - logf(th / st + 1e-8f));
+            p_l1 += l1;
+            p_wl1 += w * l1;
+        }
+    }
+    float vals[5] = {p_iou, p_wiou, p_l1, p_wl1, p_nfg};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        float v = vals[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) s_red[wave][j] = v;
+    }
+    __syncthreads();
+    if (tid < 5) {
+        float v = 0.0f;
+        for (int w = 0; w < NW; ++w) v += s_red[w][tid];
+        part[tid] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, int A, int nc, const float* labels,
+                                                       int max_labels, TalGeom geom, float gamma, int use_l1,
+                                                       const unsigned char* ws, TalLayout L,
+                                                       float* d_raw, float* losses, int* fg_mask) {
+    __shared__ float s_tot[8];
+    __shared__ float s_acc[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // batch totals of the per-image partial sums (every workgroup recomputes them: B is small)
+    if (tid < 8) {
+        float v = 0.0f;
+        for (int b = 0; b < B; ++b) v += ((const float*)(ws + (long long)b * L.image_bytes + L.part))[tid];
+        s_tot[tid] = v;
+    }
+    __syncthreads();
+    const float sum_iou = s_tot[0], sum_wiou = s_tot[1], sum_l1 = s_tot[2], sum_wl1 = s_tot[3];
+    const float num_fg = s_tot[4], num_gt = s_tot[5];
+    const float nf = num_fg > 1.0f ? num_fg : 1.0f;
+    const float inv_nf = 1.0f / nf;
+    const int nch = 5 + nc;
+    float l_iou = 0, l_obj = 0, l_cls = 0, l_l1 = 0;
+    const long long total = (long long)B * A;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / A), a = (int)(i - (long long)b * A);
+        const unsigned char* wsi = ws + (long long)b * L.image_bytes;
+        const int g = ((const int*)(wsi + L.agt))[a];
+        const float* r = raw + i * nch;
+        float* d = d_raw + i * nch;
+        const float tobj = g >= 0 ? 1.0f : 0.0f;
+        if (fg_mask != nullptr) fg_mask[i] = g >= 0 ? 1 : 0;
+        {   // objectness BCE-with-logits on every anchor (:445-447)
+            const float z = r[4];
+            l_obj += fmaxf(z, 0.0f) - z * tobj + log1pf(expf(-fabsf(z)));
+            d[4] = (1.0f / (1.0f + expf(-z)) - tobj) * inv_nf;
+        }
+        if (g < 0) {
+            d[0] = 0.0f; d[1] = 0.0f; d[2] = 0.0f; d[3] = 0.0f;
+            for (int k = 0; k < nc; ++k) d[5 + k] = 0.0f;
+            continue;
+        }
+        const float miou = ((const float*)(wsi + L.aiou))[a];
+        const float* lb = labels + ((long long)b * max_labels + g) * 5;
+        const int gcls = (int)lb[0];
+        const float tx = lb[1], ty = lb[2], tw = lb[3], th = lb[4];
+        for (int k = 0; k < nc; ++k) {   // class BCE on foreground anchors, target = one-hot * matched IoU (:379-381, :448-452)
+            const float z = r[5 + k];
+            const float t = (k == gcls) ? miou : 0.0f;
+            l_cls += fmaxf(z, 0.0f) - z * t + log1pf(expf(-fabsf(z)));
+            d[5 + k] = (1.0f / (1.0f + expf(-z)) - t) * inv_nf;
+        }
+        float gx, gy, st;
+        anchor_geom(geom, a, gx, gy, st);
+        const float wg = ((const float*)(wsi + L.part))[16 + g];       // trend weight of GT g (written by kernel 1)
+        // IoU loss and gradient (:431-433, :442-444)
+        const float px = (r[0] + gx) * st, py = (r[1] + gy) * st, pw = expf(r[2]) * st, ph = expf(r[3]) * st;
+        const float plx = px - pw / 2, ply = py - ph / 2, prx = px + pw / 2, pry = py + ph / 2;
+        const float tlx = tx - tw / 2, tly = ty - th / 2, trx = tx + tw / 2, try_ = ty + th / 2;
+        const float lx = fmaxf(plx, tlx), ly = fmaxf(ply, tly), rx = fminf(prx, trx), ry = fminf(pry, try_);
+        const bool en = (lx < rx) && (ly < ry);
+        const float wi = rx - lx, hi = ry - ly;
+        const float inter = en ? wi * hi : 0.0f;
+        const float ap = pw * ph, ag = tw * th;
+        const float D = ap + ag - inter + 1e-16f;
+        const float iou = inter / D;
+        const float w_iou = (sum_wiou != 0.0f) ? wg * sum_iou / sum_wiou : 0.0f;
+        l_iou += w_iou * (1.0f - iou * iou);
+        float dIx = 0, dIy = 0, dIw = 0, dIh = 0;
+        if (en) {
+            const float dl = plx > tlx ? 1.0f : 0.0f, dr = prx < trx ? 1.0f : 0.0f;
+            const float dt = ply > tly ? 1.0f : 0.0f, db = pry < try_ ? 1.0f : 0.0f;
+            dIx = hi * (dr - dl);
+            dIw = hi * 0.5f * (dr + dl);
+            dIy = wi * (db - dt);
+            dIh = wi * 0.5f * (db + dt);
+        }
+        // d iou = (dI * D - I * (dAp - dI)) / D^2 ; loss = 5 * w_iou * (1 - iou^2) / nf
+        const float c0 = -2.0f * iou * 5.0f * w_iou * inv_nf / (D * D);
+        const float gpx = c0 * (dIx * D - inter * (0.0f - dIx));
+        const float gpy = c0 * (dIy * D - inter * (0.0f - dIy));
+        const float gpw = c0 * (dIw * D - inter * (ph - dIw));
+        const float gph = c0 * (dIh * D - inter * (pw - dIh));
+        float d0 = gpx * st, d1 = gpy * st, d2 = gpw * pw, d3 = gph * ph;
+        if (use_l1) {   // L1 on the raw regression outputs (:384-391, :435-438, :453-456)
+            const float w_l1 = (sum_wl1 != 0.0f) ? wg * sum_l1 / sum_wl1 : 0.0f;
+            const float t0 = tx / st - gx, t1 = ty / st - gy, t2 = logf(tw / st + 1e-8f), t3 = logf(th / st + 1e-8f);
+            const float e0 = r[0] - t0, e1 = r[1] - t1, e2 = r[2] - t2, e3 = r[3] - t3;
+            l_l1 += w_l1 * (fabsf(e0) + fabsf(e1) + fabsf(e2) + fabsf(e3));
+            const float c1 = w_l1 * inv_nf;
+            d0 += c1 * ((e0 > 0.0f) - (e0 < 0.0f));
+            d1 += c1 * ((e1 > 0.0f) - (e1 < 0.0f));
+            d2 += c1 * ((e2 > 0.0f) - (e2 < 0.0f));
+            d3 += c1 * ((e3 > 0.0f) - (e3 < 0.0f));
+        }
+        d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3;
+    }
+    float vals[4] = {l_iou, l_obj, l_cls, l_l1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = vals[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) s_acc[wave][j] = v;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const float v = (s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid]) * inv_nf;
+        // losses: [0] total, [1] 5*iou, [2] l1, [3] conf, [4] cls, [5] num_fg/num_gt, [6] num_fg, [7] num_gt
+        if (tid == 0) { atomicAdd(losses + 1, 5.0f * v); atomicAdd(losses + 0, 5.0f * v); }
+        if (tid == 1) { atomicAdd(losses + 3, v); atomicAdd(losses + 0, v); }
+        if (tid == 2) { atomicAdd(losses + 4, v); atomicAdd(losses + 0, v); }
+        if (tid == 3) { atomicAdd(losses + 2, v); atomicAdd(losses + 0, v); }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        losses[5] = num_fg / (num_gt > 1.0f ? num_gt : 1.0f);
+        losses[6] = num_fg;
+        losses[7] = num_gt;
+    }
+}
+
+__global__ void tal_zero_losses_kernel(float* losses) {
+    if (threadIdx.x < 8) losses[threadIdx.x] = 0.0f;
+}
+
+}  // namespace
+
+extern "C" int64_t sy_tal_loss_workspace_bytes(int B, int A, int max_gt) {
+    if (B <= 0 || A <= 0 || max_gt <= 0) return 0;
+    if (max_gt > kMaxGT) max_gt = kMaxGT;
+    return tal_layout(A, max_gt).image_bytes * (int64_t)B;
+}
+
+extern "C" int sy_tal_loss(const float* raw, int B, int A, int num_classes, const float* labels, const float* support,
+                           int max_labels, const int32_t* level_h, const int32_t* level_w, const float* level_stride,
+                           int nlevels, float gamma, float ignore_thr, float ignore_value, int use_l1, float* d_raw,
+                           float* losses, int32_t* fg_mask, void* workspace, void* stream) {
+    if (raw == nullptr || labels == nullptr || support == nullptr || d_raw == nullptr || losses == nullptr ||
+        workspace == nullptr || level_h == nullptr || level_w == nullptr || level_stride == nullptr)
+        return SY_ERR_ARG;
+    if (B <= 0 || A <= 0 || num_classes <= 0 || nlevels <= 0 || nlevels > kMaxLevels) return SY_ERR_ARG;
+    if (max_labels <= 0 || max_labels > kMaxGT) return SY_ERR_UNSUPPORTED;
+    TalGeom g;
+    g.nlevels = nlevels;
+    int a0 = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        g.h[l] = level_h[l]; g.w[l] = level_w[l]; g.stride[l] = level_stride[l];
+        g.a0[l] = a0;
+        a0 += level_h[l] * level_w[l];
+    }
+    g.a0[nlevels] = a0;
+    if (a0 != A) return SY_ERR_ARG;
+    TalLayout L = tal_layout(A, max_labels);
+    SY_LAUNCH(tal_zero_losses_kernel, dim3(1), dim3(64), 0, stream, losses);
+    SY_LAUNCH(tal_assign_kernel, dim3(B), dim3(kAssignThreads), 0, stream, raw, A, num_classes, labels, support,
+              max_labels, g, gamma, ignore_thr, ignore_value, use_l1, (unsigned char*)workspace, L);
+    if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
+    long long work = (long long)B * A;
+    int blocks = (int)((work + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    SY_LAUNCH(tal_grad_kernel, dim3(blocks), dim3(256), 0, stream, raw, B, A, num_classes, labels, max_labels, g, gamma,
+              use_l1, (const unsigned char*)workspace, L, d_raw, losses, fg_mask);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
