@@ -66,6 +66,7 @@ typedef struct sy_conv_desc {
     int32_t epilogue;                   /* SY_EPI_*                                              */
     int32_t accumulate;                 /* 1: y += result (gradient fan-in)                      */
     float dec_stride;                   /* SY_EPI_DECODE: the level's stride (8/16/32)           */
+    int32_t stat_copies;                /* stat arrays hold this many replicas [copies][Cout] (>=1) */
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.
@@ -84,6 +85,8 @@ typedef struct sy_wgrad_desc {
     int32_t ldx, lddy;  int64_t xbs, dybs;
     int32_t dtype;
     int32_t dw_oihw;
+    void* workspace;                    /* optional fp32 scratch for split-K slabs (NULL: one split) */
+    int64_t workspace_bytes;
 } sy_wgrad_desc;
 SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
 
@@ -99,8 +102,10 @@ SY_API int sy_resize_nearest(const void* in, int N, int Hi, int Wi, int C, int l
 
 /* SPP pooling: buf holds x in channels [0,C) of a 4C-wide view; writes maxpool 5/9/13 (stride 1,
  * -inf padding) into [C,2C), [2C,3C), [3C,4C) (trap T5).  Replaces SPPBottleneck's three
- * nn.MaxPool2d + cat (exps/model/darknet.py:156). */
-SY_API int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, int dtype, void* stream);
+ * nn.MaxPool2d + cat (exps/model/darknet.py:156).  argmax (optional, training): [N,H,W,3,C] bytes,
+ * the window offset of each pooled maximum, consumed by sy_spp_pool_bwd. */
+SY_API int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, void* argmax, int dtype,
+                       void* stream);
 
 /* Box decode + confidence filter + class-aware greedy NMS for a batch of images.
  * pred: [B, A, 5+nc] fp32 (cx,cy,w,h,obj,cls...) as produced by the head (tal_head.py:245-260).
@@ -116,7 +121,7 @@ SY_API int sy_postprocess(const float* pred, int B, int A, int num_classes, floa
 
 /* Training-mode BatchNorm helpers around sy_conv2d(stat_sum/stat_sqsum).
  * Replaces nn.BatchNorm2d in training mode (momentum/eps patched by init_yolo, cfgs/<name>.py:40-44). */
-SY_API int sy_bn_finalize(const float* sum, const float* sqsum, int C, double count, const float* gamma,
+SY_API int sy_bn_finalize(const float* sum, const float* sqsum, int C, int copies, double count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* scale, float* shift, float* mean, float* invstd,
                    void* stream);
@@ -156,8 +161,8 @@ SY_API int sy_view_copy(const void* in, int ldi, void* out, int ldo, int64_t pix
 SY_API int sy_resize_nearest_bwd(const void* dout, int N, int Ho, int Wo, int C, int lddo, int64_t dobs,
                           void* din, int Hi, int Wi, int lddi, int64_t dibs, int accumulate,
                           int dtype, void* stream);
-/* backward of sy_spp_pool: dbuf holds grads of the 4 slices; folds pooled grads into slice 0 */
-SY_API int sy_spp_pool_bwd(const void* buf, void* dbuf, int N, int H, int W, int C, int ld, int64_t bs,
+/* backward of sy_spp_pool: dbuf holds grads of the 4 slices; routes pooled grads to their arg-max into slice 0 */
+SY_API int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int W, int C, int ld, int64_t bs,
                     int dtype, void* stream);
 
 SY_API const char* sy_version(void);

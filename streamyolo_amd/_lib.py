@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
         ("xbs", C.c_int64), ("ybs", C.c_int64), ("rbs", C.c_int64),
         ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
-        ("accumulate", C.c_int32), ("dec_stride", C.c_float),
+        ("accumulate", C.c_int32), ("dec_stride", C.c_float), ("stat_copies", C.c_int32),
     ]
 
 
@@ -46,7 +46,7 @@ class WgradDesc(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("ldx", C.c_int32), ("lddy", C.c_int32), ("xbs", C.c_int64), ("dybs", C.c_int64),
-        ("dtype", C.c_int32), ("dw_oihw", C.c_int32),
+        ("dtype", C.c_int32), ("dw_oihw", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -60,11 +60,11 @@ SIGNATURES = {
     "sy_focus_pack": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sy_resize_nearest": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _I, _I, _L, _I, _P]),
     "sy_resize_nearest_bwd": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _I, _I, _L, _I, _I, _P]),
-    "sy_spp_pool": (_I, [_P, _I, _I, _I, _I, _I, _L, _I, _P]),
+    "sy_spp_pool": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _P]),
     "sy_spp_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "sy_postprocess_workspace_bytes": (_L, [_I, _I]),
     "sy_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
-    "sy_bn_finalize": (_I, [_P, _P, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "sy_bn_finalize": (_I, [_P, _P, _I, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sy_bn_silu_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _I, _P]),

@@ -39,6 +39,7 @@ struct ConvArgs {
     int y_f32, mode, epilogue, accumulate;
     float dec_stride;
     int M, K, HoWo;
+    int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
 };
 
 constexpr int kPitch = 80;          // LDS row pitch in bytes: 64 B of K + 16 B pad
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
             }
         }
         if (want_stats) {
-            // reduce over the 32 pixels held by lanes with equal `half`, then one atomic per channel
+            // reduce over the 32 pixels held by lanes with equal `half`; park the wave's 32 channel sums in LDS
+            // (the K loop is over: sW is free after the barrier below), fold the WP waves, one atomic per channel.
+            float* red = reinterpret_cast<float*>(sW);            // [WP][CT][2]
+            if (t == 0) __syncthreads();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float a = ssum[r], b = ssq[r];
@@ -310,12 +314,26 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
                     a += __shfl_xor(a, off);
                     b += __shfl_xor(b, off);
                 }
-                const int co = c0 + (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
-                if (l31 == 0 && co < p.Cout) {
-                    atomicAdd(p.stat_sum + co, a);
-                    atomicAdd(p.stat_sq + co, b);
+                const int cl = (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
+                if (l31 == 0) {
+                    red[(wp * CT + cl) * 2 + 0] = a;
+                    red[(wp * CT + cl) * 2 + 1] = b;
                 }
             }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(sW);
+        const int copy = (int)(blockIdx.y % (unsigned)p.stat_copies);
+        for (int cl = tid; cl < CT; cl += kThreads) {
+            const int co = c0 + cl;
+            if (co >= p.Cout) continue;
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WP; ++w) { a += red[(w * CT + cl) * 2]; b += red[(w * CT + cl) * 2 + 1]; }
+            atomicAdd(p.stat_sum + (long long)copy * p.Cout + co, a);
+            atomicAdd(p.stat_sq + (long long)copy * p.Cout + co, b);
         }
     }
 }
@@ -359,6 +377,7 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.xbs = d->xbs; a.ybs = d->ybs; a.rbs = d->rbs;
     a.y_f32 = d->y_f32; a.mode = d->mode; a.epilogue = d->epilogue; a.accumulate = d->accumulate;
     a.dec_stride = d->dec_stride;
+    a.stat_copies = d->stat_copies > 0 ? d->stat_copies : 1;
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return launch_typed<BF16>(a, stream);

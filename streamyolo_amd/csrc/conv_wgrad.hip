@@ -11,9 +11,10 @@
 // conflicted (free on ds_write_b32) and the MFMA fragments read back as conflict-free ds_read_b64.
 //   rows  (MFMA A operand) = X^T : (tap, ci)      cols (MFMA B operand) = dY^T : co
 // so a lane's accumulator quad is 4 consecutive k of one co = 4 consecutive floats of dW[co][:].
-// The pixel range is split over gridDim.z; partial tiles are combined with fp32 atomics into dW,
-// which also sums the current-frame and support-frame passes of the shared backbone weights
-// (SURVEY.md §8(e)); the caller zeroes the gradient arena once per step.
+// The pixel range is split over gridDim.z; each split writes its partial tile to a private slab of the
+// caller's workspace (plain 16-byte stores) and a fold kernel sums the slabs INTO dW (+=), which is
+// how the current-frame and support-frame passes of the shared backbone weights add up
+// (SURVEY.md §8(e)); the caller zeroes the gradient arena once per step.  Deterministic: no atomics.
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
 
@@ -28,6 +29,8 @@ struct WgradArgs {
     long long xbs, dybs;
     int M, K, slabs_per_split;
     int oihw;                   // 1: dW laid out [Cout][Cin][KH][KW] (the nn.Parameter layout), 0: [Cout][tap][Cin]
+    float* part;                // split > 1: partial tiles [splits][Cout][K] (packed layout), folded by wgrad_fold_kernel
+    int splits;
 };
 
 constexpr int kPitchT = 72;
@@ -221,54 +224,91 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
         }
     }
 
-    // ---- epilogue: D[row = k][col = co] -> dW[co][k] (fp32 atomics) ------------------------------
+    // ---- epilogue: D[row = k][col = co].  One split: every dW element belongs to exactly one workgroup, so a
+    //      plain += into dW is race free.  Several splits: each writes its tile to a private slab (16-byte
+    //      stores, no atomics) and wgrad_fold_kernel sums the slabs into dW.
     const int half = lane >> 5;
+    const int taps = p.KH * p.KW;
 #pragma unroll
     for (int t = 0; t < TR; ++t)
 #pragma unroll
         for (int u = 0; u < TC; ++u) {
             const int co = c0 + (wcn * TC + u) * 32 + l31;
             if (co >= p.Cout) continue;
-            float* row = p.dw + (long long)co * p.K;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int kb = r0 + (wr * TR + t) * 32 + q * 8 + half * 4;
-                if (kb >= p.K) continue;                       // Cin % 4 == 0: the quad shares one tap
-                if (p.oihw) {
-                    const int taps = p.KH * p.KW;
+                if (kb >= p.K) continue;                       // Cin % 4 == 0: the quad shares one tap and K % 4 == 0
+                const float v0 = acc[t][u][q * 4 + 0], v1 = acc[t][u][q * 4 + 1], v2 = acc[t][u][q * 4 + 2],
+                            v3 = acc[t][u][q * 4 + 3];
+                if (p.splits > 1) {
+                    float* dst = p.part + ((long long)blockIdx.z * p.Cout + co) * p.K + kb;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+                } else if (p.oihw) {
                     const int tap = kb / p.Cin;
                     const int ci = kb - tap * p.Cin;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) atomicAdd(row + (ci + j) * taps + tap, acc[t][u][q * 4 + j]);
+                    float* row = p.dw + (long long)co * p.K + (long long)ci * taps + tap;
+                    row[0] += v0; row[taps] += v1; row[2 * taps] += v2; row[3 * taps] += v3;
                 } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) atomicAdd(row + kb + j, acc[t][u][q * 4 + j]);
+                    float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co * p.K + kb);
+                    float4 o = *dst;
+                    o.x += v0; o.y += v1; o.z += v2; o.w += v3;
+                    *dst = o;
                 }
             }
         }
 }
 
+// dW (+)= sum over splits of the partial slabs; also applies the packed -> OIHW layout change.
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, float* dw, int Cout, int K, int Cin, int taps,
+                                                         int splits, int oihw) {
+    const long long total = (long long)Cout * K;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float v = 0.0f;
+        for (int z = 0; z < splits; ++z) v += part[(long long)z * total + i];
+        long long o = i;
+        if (oihw) {
+            const int co = (int)(i / K), k = (int)(i - (long long)co * K);
+            const int tap = k / Cin, ci = k - tap * Cin;
+            o = (long long)co * K + (long long)ci * taps + tap;
+        }
+        dw[o] += v;
+    }
+}
+
 template <typename T, int WR, int WC, int TR, int TC>
-int launch_wgrad_cfg(WgradArgs a, void* stream) {
+int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     constexpr int RT = WR * TR * 32, CT = WC * TC * 32, SLAB = 4 * T::kEPC;
     const int gx = (a.K + RT - 1) / RT, gy = (a.Cout + CT - 1) / CT;
     const int slabs_total = (a.M + SLAB - 1) / SLAB;
-    // enough workgroups to cover 256 CUs a few times over, at least 8 slabs of work each
-    int splits = (1024 + gx * gy - 1) / (gx * gy);
+    // about two workgroups per CU (256 CUs), at least 8 slabs of work each, and the slabs must fit the workspace
+    int splits = (512 + gx * gy - 1) / (gx * gy);
     const int max_splits = (slabs_total + 7) / 8;
     if (splits > max_splits) splits = max_splits;
+    const long long slab_bytes = (long long)a.Cout * a.K * 4;
+    if (a.part == nullptr) splits = 1;
+    else if ((long long)splits * slab_bytes > ws_bytes) splits = (int)(ws_bytes / slab_bytes);
     if (splits < 1) splits = 1;
     a.slabs_per_split = (slabs_total + splits - 1) / splits;
     splits = (slabs_total + a.slabs_per_split - 1) / a.slabs_per_split;
+    a.splits = splits;
     SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
+    if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
+    if (splits > 1) {
+        long long work = (long long)a.Cout * a.K;
+        int blocks = (int)((work + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        SY_LAUNCH(wgrad_fold_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K, a.Cin,
+                  a.KH * a.KW, splits, a.oihw);
+    }
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
 template <typename T>
-int launch_wgrad_typed(const WgradArgs& a, void* stream) {
-    if (a.Cout > 64) return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, stream);     // 128 k x 128 co
-    if (a.Cout > 32) return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, stream);     // 128 k x  64 co
-    return launch_wgrad_cfg<T, 4, 1, 1, 1>(a, stream);                      // 128 k x  32 co
+int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
+    if (a.Cout > 64) return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);     // 128 k x 128 co
+    if (a.Cout > 32) return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);     // 128 k x  64 co
+    return launch_wgrad_cfg<T, 4, 1, 1, 1>(a, ws_bytes, stream);                      // 128 k x  32 co
 }
 
 }  // namespace
@@ -288,9 +328,12 @@ extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
     a.ldx = d->ldx; a.lddy = d->lddy; a.xbs = d->xbs; a.dybs = d->dybs;
     a.M = d->N * d->Ho * d->Wo; a.K = d->KH * d->KW * d->Cin; a.slabs_per_split = 0;
     a.oihw = d->dw_oihw;
+    a.part = (float*)d->workspace;
+    a.splits = 1;
+    const long long wsb = d->workspace != nullptr ? (long long)d->workspace_bytes : 0;
     switch (d->dtype) {
-        case SY_DT_BF16: return launch_wgrad_typed<BF16>(a, stream);
-        case SY_DT_F16: return launch_wgrad_typed<F16>(a, stream);
-        default: return launch_wgrad_typed<F32>(a, stream);
+        case SY_DT_BF16: return launch_wgrad_typed<BF16>(a, wsb, stream);
+        case SY_DT_F16: return launch_wgrad_typed<F16>(a, wsb, stream);
+        default: return launch_wgrad_typed<F32>(a, wsb, stream);
     }
 }

@@ -1,0 +1,345 @@
+// train_ops.hip — SPP pooling (forward + arg-max-routed backward) and the training-mode
+// BatchNorm + SiLU passes around the MFMA convolutions.  All HBM-bound: 16 bytes per lane along the
+// NHWC channel axis; a thread's channel chunk is FIXED across its grid-stride loop (the stride is a
+// multiple of the chunks-per-pixel), so per-channel parameters live in registers.
+//
+// Replaces nn.BatchNorm2d (training mode, eps/momentum patched by init_yolo — cfgs/<name>.py:40-44 of
+// the reference), nn.SiLU, SPPBottleneck's three nn.MaxPool2d + cat (exps/model/darknet.py:156) and
+// their autograd backward kernels.
+#include "sy_pointwise.h"
+
+namespace {
+
+// ---- SPP: max over 5x5, 9x9, 13x13 windows, stride 1, -inf padding (nested windows share loads) ----
+// Optional arg-max record (training): for level l and channel c the window offset (dh+6)*13+(dw+6)
+// of the FIRST maximum in row-major scan order, one byte per (pixel, level, channel).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spp_pool_kernel(typename T::elem* buf, int N, int H, int W, int C, int ld,
+                                                          long long bs, unsigned char* argmax) {
+    const int cpp = C / T::kEPC;
+    const long long total = (long long)N * H * W * cpp;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int cc = (int)(i % cpp);
+        long long pix = i / cpp;
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long long)W * H));
+        float m5[T::kEPC], m9[T::kEPC], m13[T::kEPC];
+        unsigned char a5[T::kEPC], a9[T::kEPC], a13[T::kEPC];
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) { m5[j] = -INFINITY; m9[j] = -INFINITY; m13[j] = -INFINITY; a5[j] = 0; a9[j] = 0; a13[j] = 0; }
+        const typename T::elem* base = buf + n * bs + cc * T::kEPC;
+        for (int dh = -6; dh <= 6; ++dh) {
+            const int hh = h + dh;
+            if (hh < 0 || hh >= H) continue;
+            const int ah = dh < 0 ? -dh : dh;
+            for (int dw = -6; dw <= 6; ++dw) {
+                const int ww = w + dw;
+                if (ww < 0 || ww >= W) continue;
+                const int aw = dw < 0 ? -dw : dw;
+                const int d = ah > aw ? ah : aw;            // Chebyshev ring index
+                const unsigned char code = (unsigned char)((dh + 6) * 13 + (dw + 6));
+                Chunk<T> c = Chunk<T>::load(base + ((long long)hh * W + ww) * ld);
+#pragma unroll
+                for (int j = 0; j < T::kEPC; ++j) {
+                    const float v = T::to_f32(c.e[j]);
+                    if (v > m13[j]) { m13[j] = v; a13[j] = code; }
+                    if (d <= 4 && v > m9[j]) { m9[j] = v; a9[j] = code; }
+                    if (d <= 2 && v > m5[j]) { m5[j] = v; a5[j] = code; }
+                }
+            }
+        }
+        Chunk<T> o5, o9, o13;
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) { o5.e[j] = T::from_f32(m5[j]); o9.e[j] = T::from_f32(m9[j]); o13.e[j] = T::from_f32(m13[j]); }
+        typename T::elem* dst = buf + n * bs + ((long long)h * W + w) * ld + cc * T::kEPC;
+        o5.store(dst + C);
+        o9.store(dst + 2 * C);
+        o13.store(dst + 3 * C);
+        if (argmax != nullptr) {
+            unsigned char* am = argmax + (pix * 3) * C + cc * T::kEPC;
+#pragma unroll
+            for (int j = 0; j < T::kEPC; ++j) { am[j] = a5[j]; am[C + j] = a9[j]; am[2 * C + j] = a13[j]; }
+        }
+    }
+}
+
+// backward (gather form, deterministic, no atomics): source pixel (h,w) collects the pooled gradient of
+// every window whose recorded arg-max is (h,w), and adds it onto slice 0's gradient.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spp_pool_bwd_kernel(typename T::elem* dbuf, const unsigned char* argmax, int N,
+                                                              int H, int W, int C, int ld, long long bs) {
+    const int cpp = C / T::kEPC;
+    const long long total = (long long)N * H * W * cpp;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int cc = (int)(i % cpp);
+        long long pix = i / cpp;
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const int n = (int)(pix / ((long long)W * H));
+        typename T::elem* gslot0 = dbuf + n * bs + ((long long)h * W + w) * ld + cc * T::kEPC;
+        Chunk<T> g0 = Chunk<T>::load(gslot0);
+        float acc[T::kEPC];
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) acc[j] = T::to_f32(g0.e[j]);
+        for (int dh = -6; dh <= 6; ++dh) {
+            const int ch = h - dh;                                  // window centre such that (h,w) sits at offset (dh,dw)
+            if (ch < 0 || ch >= H) continue;
+            const int ah = dh < 0 ? -dh : dh;
+            for (int dw = -6; dw <= 6; ++dw) {
+                const int cw = w - dw;
+                if (cw < 0 || cw >= W) continue;
+                const int aw = dw < 0 ? -dw : dw;
+                const int d = ah > aw ? ah : aw;
+                const unsigned char code = (unsigned char)((dh + 6) * 13 + (dw + 6));
+                const long long cpix = ((long long)n * H + ch) * W + cw;
+                const unsigned char* am = argmax + (cpix * 3) * C + cc * T::kEPC;
+                const typename T::elem* gp = dbuf + n * bs + ((long long)ch * W + cw) * ld + cc * T::kEPC;
+                const int l0 = d <= 2 ? 0 : (d <= 4 ? 1 : 2);       // smallest level whose window reaches (dh,dw)
+                for (int l = l0; l < 3; ++l) {
+                    unsigned char cb[8];
+                    __builtin_memcpy(cb, am + l * C, T::kEPC);
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < T::kEPC; ++j) any = any || (cb[j] == code);
+                    if (!any) continue;
+                    Chunk<T> g = Chunk<T>::load(gp + (l + 1) * C);
+#pragma unroll
+                    for (int j = 0; j < T::kEPC; ++j)
+                        if (cb[j] == code) acc[j] += T::to_f32(g.e[j]);
+                }
+            }
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(acc[j]);
+        o.store(gslot0);
+    }
+}
+
+// ---- training-mode BatchNorm -------------------------------------------------------------------------
+// The conv epilogue spreads its per-channel partial sums over `copies` replicas (contention control);
+// finalize folds them, updates the running statistics and emits the per-channel affine.
+__global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, const float* sqsum, int C, int copies,
+                                                             double count, const float* gamma, const float* beta,
+                                                             float eps, float momentum, float* running_mean,
+                                                             float* running_var, float* scale, float* shift,
+                                                             float* mean_out, float* invstd_out) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < copies; ++k) { s += (double)sum[(long long)k * C + c]; q += (double)sqsum[(long long)k * C + c]; }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (mean_out != nullptr) mean_out[c] = (float)mean;
+    if (invstd_out != nullptr) invstd_out[c] = invstd;
+    if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T::elem* y, int ldy, const float* scale,
+                                                               const float* shift, const typename T::elem* res, int ldr,
+                                                               typename T::elem* out, int ldo, long long pixels, int C) {
+    const int cpp = C / T::kEPC;
+    const int cc = threadIdx.x % cpp;
+    const int c0 = cc * T::kEPC;
+    const int rows = kBlock / cpp;
+    if ((int)threadIdx.x >= rows * cpp) return;        // idle tail when cpp does not divide the workgroup
+    float sc[T::kEPC], sh[T::kEPC];
+#pragma unroll
+    for (int j = 0; j < T::kEPC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+    for (long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp; pix < pixels; pix += (long long)gridDim.x * rows) {
+        Chunk<T> v = Chunk<T>::load(y + pix * ldy + c0);
+        Chunk<T> o;
+        float r[T::kEPC];
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) r[j] = 0.0f;
+        if (res != nullptr) {
+            Chunk<T> rv = Chunk<T>::load(res + pix * ldr + c0);
+#pragma unroll
+            for (int j = 0; j < T::kEPC; ++j) r[j] = T::to_f32(rv.e[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
+        o.store(out + pix * ldo + c0);
+    }
+}
+
+// reduce: sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat.  Thread = (pixel row, channel chunk); register
+// partials, LDS tree over the rows of the workgroup, then ONE atomic per channel per workgroup.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typename T::elem* y, int ldy,
+                                                                    const typename T::elem* da, int ldda,
+                                                                    const float* scale, const float* shift,
+                                                                    const float* mean, const float* invstd, float* sums,
+                                                                    long long pixels, int C) {
+    __shared__ float red[kBlock * 2 * 8];
+    const int cpp = C / T::kEPC;
+    const int rows = kBlock / cpp;
+    const int cc = threadIdx.x % cpp;
+    const int pr = threadIdx.x / cpp;
+    const int c0 = cc * T::kEPC;
+    float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], s0[T::kEPC], s1[T::kEPC];
+#pragma unroll
+    for (int j = 0; j < T::kEPC; ++j) {
+        sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
+        s0[j] = 0.0f; s1[j] = 0.0f;
+    }
+    const long long first = pr < rows ? (long long)blockIdx.x * rows + pr : pixels;     // idle tail threads skip the loop
+    for (long long pix = first; pix < pixels; pix += (long long)gridDim.x * rows) {
+        Chunk<T> yv = Chunk<T>::load(y + pix * ldy + c0);
+        Chunk<T> gv = Chunk<T>::load(da + pix * ldda + c0);
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) {
+            const float yy = T::to_f32(yv.e[j]);
+            const float dz = T::to_f32(gv.e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
+            s0[j] += dz;
+            s1[j] += dz * ((yy - mu[j]) * is[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T::kEPC; ++j) {
+        red[(j * 2 + 0) * kBlock + threadIdx.x] = s0[j];
+        red[(j * 2 + 1) * kBlock + threadIdx.x] = s1[j];
+    }
+    __syncthreads();
+    // thread t < cpp*EPC*2 folds one (chunk, element, kind) column over the `rows` pixel rows
+    for (int t = threadIdx.x; t < cpp * T::kEPC * 2; t += kBlock) {
+        const int kind = t & 1, j = (t >> 1) % T::kEPC, ch = (t >> 1) / T::kEPC;
+        float v = 0.0f;
+        for (int r = 0; r < rows; ++r) v += red[(j * 2 + kind) * kBlock + r * cpp + ch];
+        atomicAdd(sums + kind * C + ch * T::kEPC + j, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typename T::elem* y, int ldy,
+                                                                   const typename T::elem* da, int ldda,
+                                                                   const float* scale, const float* shift,
+                                                                   const float* mean, const float* invstd,
+                                                                   const float* gamma, const float* sums,
+                                                                   typename T::elem* dy, int lddy, long long pixels,
+                                                                   int C, float* dgamma, float* dbeta) {
+    const int cpp = C / T::kEPC;
+    const int rows = kBlock / cpp;
+    const int cc = threadIdx.x % cpp;
+    const int c0 = cc * T::kEPC;
+    const float inv_m = 1.0f / (float)pixels;
+    if (blockIdx.x == 0 && dgamma != nullptr) {        // launches on one stream are ordered: plain += is race free
+        for (int c = threadIdx.x; c < C; c += kBlock) { dgamma[c] += sums[C + c]; dbeta[c] += sums[c]; }
+    }
+    if ((int)threadIdx.x >= rows * cpp) return;
+    float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], gi[T::kEPC], m0[T::kEPC], m1[T::kEPC];
+#pragma unroll
+    for (int j = 0; j < T::kEPC; ++j) {
+        const int c = c0 + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+        gi[j] = gamma[c] * invstd[c];
+        m0[j] = sums[c] * inv_m;
+        m1[j] = sums[C + c] * inv_m;
+    }
+    for (long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp; pix < pixels; pix += (long long)gridDim.x * rows) {
+        Chunk<T> yv = Chunk<T>::load(y + pix * ldy + c0);
+        Chunk<T> gv = Chunk<T>::load(da + pix * ldda + c0);
+        Chunk<T> o;
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) {
+            const float yy = T::to_f32(yv.e[j]);
+            const float dz = T::to_f32(gv.e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
+            o.e[j] = T::from_f32(gi[j] * (dz - m0[j] - (yy - mu[j]) * is[j] * m1[j]));
+        }
+        o.store(dy + pix * lddy + c0);
+    }
+}
+
+inline bool chunk_rows_ok(int C, int e) { const int cpp = C / e; return cpp >= 1 && cpp <= kBlock; }
+
+inline int row_grid(long long pixels, int C, int e, int cap) {
+    const int rows = kBlock / (C / e);
+    long long b = (pixels + rows - 1) / rows;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, void* argmax, int dtype,
+                           void* stream) {
+    if (buf == nullptr || N <= 0 || C <= 0 || ld < 4 * C) return SY_ERR_ARG;
+    const int e = epc_of(dtype);
+    if (C % e || ld % e) return SY_ERR_UNSUPPORTED;
+    const long long work = (long long)N * H * W * (C / e);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((spp_pool_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream,
+                                       (typename T::elem*)buf, N, H, W, C, ld, (long long)bs, (unsigned char*)argmax));
+}
+
+extern "C" int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int W, int C, int ld, int64_t bs, int dtype,
+                               void* stream) {
+    if (argmax == nullptr || dbuf == nullptr || N <= 0 || C <= 0 || ld < 4 * C) return SY_ERR_ARG;
+    const int e = epc_of(dtype);
+    if (C % e || ld % e) return SY_ERR_UNSUPPORTED;
+    const long long work = (long long)N * H * W * (C / e);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((spp_pool_bwd_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream,
+                                       (typename T::elem*)dbuf, (const unsigned char*)argmax, N, H, W, C, ld,
+                                       (long long)bs));
+}
+
+extern "C" int sy_bn_finalize(const float* sum, const float* sqsum, int C, int copies, double count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    if (sum == nullptr || sqsum == nullptr || gamma == nullptr || beta == nullptr || scale == nullptr ||
+        shift == nullptr || C <= 0 || copies <= 0 || count <= 0.0)
+        return SY_ERR_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SY_ERR_ARG;
+    SY_LAUNCH(bn_finalize_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sum, sqsum, C, copies, count,
+              gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr,
+                                void* out, int ldo, int64_t pixels, int C, int dtype, void* stream) {
+    if (y == nullptr || out == nullptr || scale == nullptr || shift == nullptr || pixels <= 0 || C <= 0) return SY_ERR_ARG;
+    const int e = epc_of(dtype);
+    if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
+    if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
+                                       (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
+                                       (typename T::elem*)out, ldo, (long long)pixels, C));
+}
+
+extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd, float* sums,
+                                     int64_t pixels, int C, int dtype, void* stream) {
+    if (y == nullptr || da == nullptr || sums == nullptr || pixels <= 0 || C <= 0) return SY_ERR_ARG;
+    const int e = epc_of(dtype);
+    if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
+    if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, 512)), dim3(kBlock), 0, stream,
+                                       (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
+                                       mean, invstd, sums, (long long)pixels, C));
+}
+
+extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                    const float* sums, void* dy, int lddy, int64_t pixels, int C, float* dgamma,
+                                    float* dbeta, int dtype, void* stream) {
+    if (y == nullptr || da == nullptr || sums == nullptr || dy == nullptr || pixels <= 0 || C <= 0) return SY_ERR_ARG;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
+    const int e = epc_of(dtype);
+    if (C % e || ldy % e || ldda % e || lddy % e) return SY_ERR_UNSUPPORTED;
+    if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
+                                       (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
+                                       mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, dgamma,
+                                       dbeta));
+}

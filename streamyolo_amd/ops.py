@@ -99,6 +99,7 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.scale, d.shift = _p(scale), _p(shift)
     d.res = None if res is None else res.ptr()
     d.stat_sum, d.stat_sqsum = (None, None) if stats is None else (stats[0].data_ptr(), stats[1].data_ptr())
+    d.stat_copies = 1 if stats is None else max(1, stats[0].numel() // (y.C if cout is None else cout))
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     if y is not None:
         d.y, d.Ho, d.Wo, d.Cout = y.ptr(), y.H, y.W, y.C
@@ -120,8 +121,9 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
-def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, cin=None):
-    """dw fp32 += wgrad(x, dy): [Cout, k*k*Cin] packed layout, or the OIHW parameter layout."""
+def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None):
+    """dw fp32 += wgrad(x, dy): [Cout, k*k*Cin] packed layout, or the OIHW parameter layout.
+    workspace: optional uint8/fp32 device tensor for the split-K slabs (more parallelism on big layers)."""
     d = WgradDesc()
     d.x, d.dy, d.dw = x.ptr(), dy.ptr(), dw.data_ptr()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
@@ -131,6 +133,8 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, cin=None):
     d.ldx, d.lddy, d.xbs, d.dybs = x.ld, dy.ld, x.bs, dy.bs
     d.dtype = x.dtype
     d.dw_oihw = 1 if oihw else 0
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")
 
 
@@ -155,16 +159,18 @@ def resize_nearest_bwd(ddst, dsrc, accumulate):
                                            stream_of(ddst.buf)), "sy_resize_nearest_bwd")
 
 
-def spp_pool(v):
-    """v: View of the 4C-wide SPP concat buffer (C = v.C // 4 channels already hold x)."""
+def spp_pool(v, argmax=None):
+    """v: View of the 4C-wide SPP concat buffer (C = v.C // 4 channels already hold x).
+    argmax: optional uint8 tensor [N,H,W,3,C] recording the pooled maxima's window offsets (training)."""
     c = v.C // 4
-    check(_lib.lib().sy_spp_pool(v.ptr(), v.N, v.H, v.W, c, v.ld, v.bs, v.dtype, stream_of(v.buf)), "sy_spp_pool")
+    check(_lib.lib().sy_spp_pool(v.ptr(), v.N, v.H, v.W, c, v.ld, v.bs, _p(argmax), v.dtype, stream_of(v.buf)),
+          "sy_spp_pool")
 
 
-def spp_pool_bwd(v, dv):
-    c = v.C // 4
-    check(_lib.lib().sy_spp_pool_bwd(v.ptr(), dv.ptr(), v.N, v.H, v.W, c, v.ld, v.bs, v.dtype, stream_of(v.buf)),
-          "sy_spp_pool_bwd")
+def spp_pool_bwd(dv, argmax):
+    c = dv.C // 4
+    check(_lib.lib().sy_spp_pool_bwd(dv.ptr(), argmax.data_ptr(), dv.N, dv.H, dv.W, c, dv.ld, dv.bs, dv.dtype,
+                                     stream_of(dv.buf)), "sy_spp_pool_bwd")
 
 
 def view_copy(src, dst, accumulate=False):
@@ -174,7 +180,8 @@ def view_copy(src, dst, accumulate=False):
 
 
 def bn_finalize(ssum, ssq, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd):
-    check(_lib.lib().sy_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), ssum.numel(), float(count), gamma.data_ptr(),
+    C_ = gamma.numel()
+    check(_lib.lib().sy_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), C_, ssum.numel() // C_, float(count), gamma.data_ptr(),
                                     beta.data_ptr(), float(eps), float(momentum), _p(running_mean), _p(running_var),
                                     scale.data_ptr(), shift.data_ptr(), _p(mean), _p(invstd), stream_of(ssum)),
           "sy_bn_finalize")
@@ -223,3 +230,34 @@ def postprocess(pred, num_classes, conf_thre, nms_thre, ws=None):
                                     ws.max_det, ws.det.data_ptr(), ws.index.data_ptr(), ws.count.data_ptr(),
                                     ws.ws.data_ptr(), stream_of(pred)), "sy_postprocess")
     return ws.det, ws.index, ws.count
+
+
+class TalLossWorkspace:
+    """Device buffers of sy_tal_loss for a given (B, A): workspace, d_raw, losses[8], fg mask, level tables."""
+
+    def __init__(self, B, A, nch, hw_list, strides, device, max_labels=120):
+        self.B, self.A, self.max_labels = B, A, max_labels
+        self.ws = torch.empty(_lib.lib().sy_tal_loss_workspace_bytes(B, A, max_labels), dtype=torch.uint8, device=device)
+        self.d_raw = torch.empty((B, A, nch), dtype=torch.float32, device=device)
+        self.losses = torch.zeros(8, dtype=torch.float32, device=device)
+        self.fg = torch.zeros((B, A), dtype=torch.int32, device=device)
+        # the level tables are read on the HOST by the launcher (tiny, by-value kernel argument)
+        self.lh = (C.c_int32 * len(hw_list))(*[int(h) for h, _ in hw_list])
+        self.lw = (C.c_int32 * len(hw_list))(*[int(w) for _, w in hw_list])
+        self.ls = (C.c_float * len(hw_list))(*[float(s) for s in strides])
+        self.nlevels = len(hw_list)
+
+
+def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value, use_l1, ws):
+    """SimOTA + Trend-Aware loss forward and gradient (sy_tal_loss).  raw [B,A,5+nc] fp32 contiguous;
+    labels/support [B, max_labels, 5] fp32.  Returns (losses[8], d_raw, fg_mask) device tensors."""
+    assert raw.dtype == torch.float32 and raw.is_contiguous()
+    labels = labels.to(raw.device, torch.float32).contiguous()
+    support = support.to(raw.device, torch.float32).contiguous()
+    assert labels.shape[1] == ws.max_labels and support.shape == labels.shape
+    check(_lib.lib().sy_tal_loss(raw.data_ptr(), ws.B, ws.A, num_classes, labels.data_ptr(), support.data_ptr(),
+                                 ws.max_labels, C.cast(ws.lh, C.c_void_p), C.cast(ws.lw, C.c_void_p),
+                                 C.cast(ws.ls, C.c_void_p), ws.nlevels, float(gamma), float(ignore_thr),
+                                 float(ignore_value), 1 if use_l1 else 0, ws.d_raw.data_ptr(), ws.losses.data_ptr(),
+                                 ws.fg.data_ptr(), ws.ws.data_ptr(), stream_of(raw)), "sy_tal_loss")
+    return ws.losses, ws.d_raw, ws.fg

@@ -27,7 +27,6 @@ from .engine import (ConvOp, PredOp, ResizeOp, SppOp, ParamCache, _Builder, buil
                      build_head_net)
 from .model.packing import pack_conv_weight
 from .model.plan_cache import compute_dtype_for
-from .model.tal_loss import tal_loss
 from .ops import View, EPI_LINEAR, CONV_DGRAD
 
 
@@ -82,6 +81,9 @@ class _GradSpace:
 
 
 class TrainPlan:
+    STAT_COPIES = 32             # replicas of each conv's sum / sum^2 arrays (atomic-contention control)
+    WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
+
     def __init__(self, model, B, H, W, dtype, device):
         self.model, self.B, self.H, self.W, self.device = model, B, H, W, device
         self.dtype = ops.dtype_code(dtype)
@@ -104,20 +106,27 @@ class TrainPlan:
         # ---- per-op training state carved out of flat arenas (zeroed with one memset each) ---------
         convs = [op for op in self.ops if op.kind == "conv"]
         tot_c = sum(op.y.C for op in convs)
-        self.stat_arena = torch.zeros(2 * tot_c, dtype=torch.float32, device=device)      # sum | sumsq
+        SC = self.STAT_COPIES
+        self.stat_arena = torch.zeros(2 * SC * tot_c, dtype=torch.float32, device=device)  # [sum | sumsq] x copies
         self.bwd_arena = torch.zeros(2 * tot_c, dtype=torch.float32, device=device)       # sum dz | sum dz*xhat
         self.aff_arena = torch.empty(4 * tot_c, dtype=torch.float32, device=device)       # scale|shift|mean|invstd
         off = 0
         max_raw = 0
         for op in convs:
             C = op.y.C
-            op.stat = (self.stat_arena[off:off + C], self.stat_arena[tot_c + off:tot_c + off + C])
+            op.stat = (self.stat_arena[SC * off:SC * (off + C)],
+                       self.stat_arena[SC * (tot_c + off):SC * (tot_c + off + C)])
             op.bsum = self.bwd_arena[2 * off:2 * off + 2 * C]
             op.aff = tuple(self.aff_arena[k * tot_c + off:k * tot_c + off + C] for k in range(4))
             op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
             max_raw = max(max_raw, op.y.pixels * C)
             off += C
         self.dyraw_scratch = torch.empty(max_raw, dtype=self.tdtype, device=device)
+        self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=device)
+        for op in self.ops:
+            if op.kind == "spp":
+                op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
+        self.loss_ws = None
         self.grads = _GradSpace()
 
         # ---- flat gradient arena in parameter layout ------------------------------------------------
@@ -155,7 +164,7 @@ class TrainPlan:
             elif k == "resize":
                 ops.resize_nearest(op.src, op.dst)
             elif k == "spp":
-                ops.spp_pool(op.v)
+                ops.spp_pool(op.v, op.argmax)
             else:   # pred: raw logits (tal_head.py:174: cat[reg, obj, cls]), decoded later by the loss
                 w_ro, b_ro, w_c, b_c = self.cache.pred(op)[:4]
                 base = self.raw.data_ptr() + op.a0 * nch * 4
@@ -172,6 +181,20 @@ class TrainPlan:
             ts, cs = zip(*counts.values())
             torch._foreach_add_(list(ts), list(cs))
         return self.raw
+
+    # ------------------------------------------------------------------------------------------------
+    def loss(self, labels, support):
+        """SimOTA + Trend-Aware loss and d(total)/d(raw) in two HIP kernels, no host sync (sy_tal_loss).
+        Returns (loss dict of 0-dim device tensors, d_raw [B, A, 5+nc])."""
+        head = self.head
+        if self.loss_ws is None or self.loss_ws.max_labels != labels.shape[1]:
+            self.loss_ws = ops.TalLossWorkspace(self.B, self.A, 5 + self.nc, self.hw, head.strides, self.device,
+                                                max_labels=labels.shape[1])
+        losses, d_raw, _ = ops.tal_loss(self.raw, labels, support, self.nc, head.gamma, head.ignore_thr,
+                                        head.ignore_value, head.use_l1, self.loss_ws)
+        out = {"total_loss": losses[0], "iou_loss": losses[1], "l1_loss": losses[2], "conf_loss": losses[3],
+               "cls_loss": losses[4], "num_fg": losses[5]}
+        return out, d_raw
 
     # ------------------------------------------------------------------------------------------------
     def backward(self, d_raw):
@@ -194,7 +217,7 @@ class TrainPlan:
                 dsrc, acc = G.target(op.src)
                 ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
             elif k == "spp":
-                ops.spp_pool_bwd(op.v, G.view(op.v))
+                ops.spp_pool_bwd(G.view(op.v), op.argmax)
         return self.arena
 
     def _pred_backward(self, op, d_raw):
@@ -236,12 +259,12 @@ class TrainPlan:
                               self.gview[id(bn.weight)], self.gview[id(bn.bias)])
         w = op.mod.conv.weight
         if w.shape[1] == op.x.C:
-            ops.conv2d_wgrad(op.x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True)
+            ops.conv2d_wgrad(op.x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self.wgrad_ws)
         else:                                                        # Focus stem: 12 real + 4 zero-padded channels
             if self.stem_scratch is None:
                 self.stem_scratch = torch.zeros((w.shape[0], op.x.C, op.k, op.k), dtype=torch.float32, device=self.device)
             self.stem_scratch.zero_()
-            ops.conv2d_wgrad(op.x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True)
+            ops.conv2d_wgrad(op.x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True, workspace=self.wgrad_ws)
             self.gview[id(w)].add_(self.stem_scratch[:, :w.shape[1]])
         if op.need_dx:
             dx, acc = G.target(op.x)
@@ -275,9 +298,8 @@ class TrainPlan:
             for n, fn in real.items():
                 setattr(ops, n, wrap(n, fn))
             for _ in range(iters):
-                raw = self.forward(x).detach().requires_grad_(True)
-                loss = tal_loss(raw, self.hw, targets[0], targets[1], self.head)["total_loss"]
-                (d_raw,) = torch.autograd.grad(loss, raw)
+                self.forward(x)
+                _, d_raw = self.loss(targets[0], targets[1])
                 self.backward(d_raw)
         finally:
             for n, fn in real.items():
@@ -301,23 +323,30 @@ def get_train_plan(model, x):
 
 
 class _PlanFunction(torch.autograd.Function):
-    """raw = plan.forward(x); backward runs the HIP backward plan and hands each parameter its slice
-    of the gradient arena (so DDP hooks, GradScaler and optimizers see ordinary .grad tensors)."""
+    """total_loss = TAL(plan.forward(x)); the forward pass also produces d(total)/d(raw) (closed form in
+    sy_tal_loss), so backward only scales it by the incoming gradient (GradScaler's loss scale) and
+    runs the HIP backward plan, handing each parameter its slice of the gradient arena — DDP hooks,
+    GradScaler and optimizers see ordinary .grad tensors."""
 
     @staticmethod
-    def forward(ctx, plan, x, *params):
+    def forward(ctx, plan, x, labels, support, *params):
         ctx.plan = plan
-        return plan.forward(x).clone()
+        plan.forward(x)
+        out, d_raw = plan.loss(labels, support)
+        ctx.d_raw = d_raw
+        stats = torch.stack([out[k] for k in ("iou_loss", "l1_loss", "conf_loss", "cls_loss", "num_fg")]).clone()
+        ctx.mark_non_differentiable(stats)
+        return out["total_loss"].clone(), stats
 
     @staticmethod
-    def backward(ctx, d_raw):
+    def backward(ctx, g_total, _g_stats):
         plan = ctx.plan
-        arena = plan.backward(d_raw.float().contiguous()).clone()
+        arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
         outs, o = [], 0
         for p in plan.params:
             outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
             o += p.numel()
-        return (None, None) + tuple(outs)
+        return (None, None, None, None) + tuple(outs)
 
 
 def train_forward(model, x, targets):
@@ -326,9 +355,10 @@ def train_forward(model, x, targets):
         x = torch.cat([x, x], dim=1)
     assert x.size()[1] == 6
     plan = get_train_plan(model, x)
-    raw = _PlanFunction.apply(plan, x, *plan.params)
     labels, support = targets
-    return tal_loss(raw, plan.hw, labels, support, model.head)
+    total, stats = _PlanFunction.apply(plan, x, labels, support, *plan.params)
+    return {"total_loss": total, "iou_loss": stats[0], "l1_loss": stats[1], "conf_loss": stats[2],
+            "cls_loss": stats[3], "num_fg": stats[4]}
 
 
 class TrainStep:
@@ -351,9 +381,8 @@ class TrainStep:
     def step(self, x, targets):
         plan = self._ensure(x)
         self._last = (x, targets)
-        raw = plan.forward(x).detach().requires_grad_(True)
-        out = tal_loss(raw, plan.hw, targets[0], targets[1], self.model.head)
-        (d_raw,) = torch.autograd.grad(out["total_loss"], raw)
+        plan.forward(x)
+        out, d_raw = plan.loss(targets[0], targets[1])
         plan.backward(d_raw)
         if self.world > 1:
             self.dist.all_reduce(plan.arena)        # RCCL over xGMI: one collective over the whole arena

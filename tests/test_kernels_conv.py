@@ -83,6 +83,17 @@ def test_conv_stats_dgrad_wgrad(backend, dt, cin, cout, k, stride, H, W, N):
     ops.conv2d_wgrad(xv, dyv, dw, k, stride)
     ref_dw = w.grad.permute(0, 2, 3, 1).reshape(cout, -1)
     assert _rel(dw.cpu(), ref_dw) < TOL[dt]
+    # split-K slabs + fold, parameter (OIHW) layout, accumulating on top of the first result
+    ws = torch.empty(1 << 22, dtype=torch.uint8, device=backend)
+    dw2 = torch.zeros(cout, cin, k, k, device=backend)
+    ops.conv2d_wgrad(xv, dyv, dw2, k, stride, oihw=True, workspace=ws)
+    ops.conv2d_wgrad(xv, dyv, dw2, k, stride, oihw=True, workspace=ws)
+    assert _rel(dw2.cpu(), 2 * w.grad) < TOL[dt]
+    # statistics spread over replicas
+    s2 = torch.zeros(4 * cout, device=backend); q2 = torch.zeros(4 * cout, device=backend)
+    ops.conv2d(xv, pack_conv_weight(w.detach(), code).to(backend), yv, k, stride, stats=(s2, q2))
+    assert _rel(s2.view(4, cout).sum(0).cpu(), ssum.cpu()) < 1e-4 or float(ssum.abs().max()) < 1e-2
+    assert _rel(q2.view(4, cout).sum(0).cpu(), ssq.cpu()) < 1e-5
 
 
 def test_head_prediction_epilogues(backend):

@@ -55,13 +55,14 @@ def test_spp_pool_fwd_bwd(backend, dt):
     ref = torch.cat([x] + pools, 1)
     v = View.alloc(1, H, W, 4 * C, dt, backend, zero=True)
     v.slice(0, C).set_nchw(x.detach().to(backend))
-    ops.spp_pool(v)
+    am = torch.zeros((1, H, W, 3, C), dtype=torch.uint8, device=backend)
+    ops.spp_pool(v, am)
     assert torch.equal(v.nchw().cpu(), ref.detach())
     if dt == "fp32":        # tie-free inputs: arg-max routing is well defined
         dref = torch.randn(ref.shape, generator=g)
         ref.backward(dref)
         dv = View.alloc(1, H, W, 4 * C, dt, backend); dv.set_nchw(dref.to(backend))
-        ops.spp_pool_bwd(v, dv)
+        ops.spp_pool_bwd(dv, am)
         assert _rel(dv.slice(0, C).nchw().cpu(), x.grad) < 1e-6
 
 
