@@ -42,8 +42,11 @@ struct ConvArgs {
     int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
 };
 
-constexpr int kPitch = 80;          // LDS row pitch in bytes: 64 B of K + 16 B pad
+constexpr int kRowB = 64;           // bytes of K per LDS row per slab; unpadded because LDS-DMA lands lane-linear
 constexpr int kThreads = 256;
+constexpr int kStages = 4;          // LDS ring depth: three slabs of loads in flight while one feeds the MFMAs
+
+__device__ uint4 g_zero16[4] = {};  // source of every predicated-off (padding / out-of-range) 16-byte chunk
 
 template <typename T, int WC, int WP, int TC, int TP>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
@@ -56,9 +59,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
     constexpr int WCH = (CT * 4 + kThreads - 1) / kThreads;   // weight chunks per thread per slab
     constexpr int XCH = (PT * 4 + kThreads - 1) / kThreads;   // pixel chunks per thread per slab
     static_assert(WC * WP == 4, "4 waves per workgroup");
+    static_assert(PT % 64 == 0, "every wave stages pixel rows");
 
-    __shared__ __attribute__((aligned(16))) unsigned char sW[CT * kPitch];
-    __shared__ __attribute__((aligned(16))) unsigned char sX[PT * kPitch];
+    // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue before every ds_read — guide §5)
+    SY_DYN_SMEM(smem);
+    unsigned char* const sW = smem;                               // [kStages][CT][64 B]
+    unsigned char* const sX = smem + kStages * CT * kRowB;        // [kStages][PT][64 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,10 +74,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
     const int c0 = blockIdx.x * CT;
     const int m0 = blockIdx.y * PT;
 
-    // ---- staging assignment: chunk id = tid + i*256 -> (row = id>>2, kc = id&3); kc is the same
-    //      for every chunk of a thread, so (tap, ci) is tracked once per thread.
-    const int kc = tid & 3;
+    // ---- staging assignment.  One LDS-DMA instruction of a wave fills 16 rows x 64 B (lane l -> row l/4,
+    //      physical 16-byte slot l%4).  Thread t owns rows (t>>2) + 64*i.  Bank conflicts of the ds_read_b128
+    //      fragment reads are removed by an XOR swizzle applied on the SOURCE side: physical slot s of row r
+    //      holds logical K-chunk s ^ ((r>>2)&3).  For a thread's rows (r>>2)&3 == (t>>4)&3, so its logical
+    //      chunk — and with it (tap, ci) — is the same for every row and is tracked once per thread.
+    const int kc = (tid & 3) ^ ((tid >> 4) & 3);
     const int row0 = tid >> 2;
+    const bool w_active = (wave * 16) < CT;      // narrow weight tiles are staged by the first waves only
 
     // pixel rows handled by this thread
     int px_h0[XCH], px_w0[XCH];
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
     for (int i = 0; i < XCH; ++i) {
         const int r = row0 + i * 64;
         const int m = m0 + r;
-        const bool ok = (r < PT) && (m < p.M);
+        const bool ok = (m < p.M);
         const int mm = ok ? m : 0;
         const int n = mm / p.HoWo;
         const int rem = mm - n * p.HoWo;
@@ -98,23 +108,25 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
-    int k_el = kc * EPC;            // this thread's element offset inside the current slab's K range
+    int k_el = kc * EPC;            // this thread's element offset inside the K range of the slab being issued
     int tap = k_el / p.Cin;
     int ci = k_el - tap * p.Cin;
+    int issued = 0;                 // slabs whose loads have been issued
 
-    uint4 rw[WCH], rx[XCH];
+    const unsigned char* const zero = reinterpret_cast<const unsigned char*>(g_zero16);
 
-    auto load_slab = [&]() {
+    auto issue_slab = [&]() {
+        const int stage = issued % kStages;
         const bool k_ok = k_el < p.K;
-        // weights: row-major [Cout][K]
+        if (w_active) {
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int r = row0 + i * 64;
-            const int co = c0 + r;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (k_ok && r < CT && co < p.Cout)
-                v = *reinterpret_cast<const uint4*>(p.w + ((long long)co * p.K + k_el) * ESZ);
-            rw[i] = v;
+            for (int i = 0; i < WCH; ++i) {
+                const int r = row0 + i * 64;
+                const int co = c0 + r;
+                const unsigned char* src = zero;
+                if (k_ok && co < p.Cout) src = p.w + ((long long)co * p.K + k_el) * ESZ;
+                sy_glds16(src, sW + (stage * CT + wave * 16 + i * 64) * kRowB);
+            }
         }
         const int kh = tap / p.KW;
         const int kw = tap - kh * p.KW;
@@ -135,28 +147,22 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
                 }
             }
             ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok)
-                v = *reinterpret_cast<const uint4*>(
-                    p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ);
-            rx[i] = v;
+            const unsigned char* src = zero;
+            if (ok) src = p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ;
+            sy_glds16(src, sX + (stage * PT + wave * 16 + i * 64) * kRowB);
         }
-    };
-    auto advance_k = [&]() {
         k_el += BK;
         ci += BK;
         while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        ++issued;
     };
-    auto store_slab = [&]() {
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int r = row0 + i * 64;
-            if (r < CT) *reinterpret_cast<uint4*>(sW + r * kPitch + kc * 16) = rw[i];
-        }
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int r = row0 + i * 64;
-            if (r < PT) *reinterpret_cast<uint4*>(sX + r * kPitch + kc * 16) = rx[i];
+    // wait until at most `ahead` later slabs of THIS wave's loads are still in flight
+    auto wait_slab = [&](int ahead) {
+        constexpr int LA = WCH + XCH, LI = XCH;      // loads per slab of a wave that does / does not stage weights
+        if (w_active) {
+            if (ahead >= 2) sy_wait_vmcnt<2 * LA>(); else if (ahead == 1) sy_wait_vmcnt<LA>(); else sy_wait_vmcnt<0>();
+        } else {
+            if (ahead >= 2) sy_wait_vmcnt<2 * LI>(); else if (ahead == 1) sy_wait_vmcnt<LI>(); else sy_wait_vmcnt<0>();
         }
     };
 
@@ -170,37 +176,34 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
 
     const int nslab = (p.K + BK - 1) / BK;
     const int l31 = lane & 31;
-    const int hi16 = (lane >> 5) * 16;
+    const int half = lane >> 5;
+    const int swz = (l31 >> 2) & 3;              // (row>>2)&3 of the fragment row this lane reads
 
-    load_slab();
-    store_slab();
-    __syncthreads();
+    for (int j = 0; j < kStages - 1 && j < nslab; ++j) issue_slab();
     for (int s = 0; s < nslab; ++s) {
-        const bool more = (s + 1 < nslab);
-        if (more) { advance_k(); load_slab(); }
+        wait_slab(issued - s - 1);               // slab s has landed (this wave's part) ...
+        sy_barrier();                            // ... and everybody's; all waves are also done reading slab s-1
+        if (issued < nslab) issue_slab();        // refill the buffer slab s-1 occupied
+        const unsigned char* bw = sW + (s % kStages) * CT * kRowB;
+        const unsigned char* bx = sX + (s % kStages) * PT * kRowB;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+            const int slot = ((g * 2 + half) ^ swz) * 16;
             uint4 a[TC], b[TP];
 #pragma unroll
             for (int t = 0; t < TC; ++t)
-                a[t] = *reinterpret_cast<const uint4*>(sW + ((wc * TC + t) * 32 + l31) * kPitch + g * 32 + hi16);
+                a[t] = *reinterpret_cast<const uint4*>(bw + ((wc * TC + t) * 32 + l31) * kRowB + slot);
 #pragma unroll
             for (int u = 0; u < TP; ++u)
-                b[u] = *reinterpret_cast<const uint4*>(sX + ((wp * TP + u) * 32 + l31) * kPitch + g * 32 + hi16);
+                b[u] = *reinterpret_cast<const uint4*>(bx + ((wp * TP + u) * 32 + l31) * kRowB + slot);
 #pragma unroll
             for (int t = 0; t < TC; ++t)
 #pragma unroll
                 for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
         }
-        __syncthreads();
-        if (more) {
-            store_slab();
-            __syncthreads();
-        }
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
-    const int half = lane >> 5;
     const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
                         (p.res == nullptr || (p.ldr & 3) == 0);
     const bool want_stats = (p.stat_sum != nullptr);
@@ -342,7 +345,17 @@ template <typename T, int WC, int WP, int TC, int TP>
 int launch_cfg(const ConvArgs& a, void* stream) {
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
     dim3 grid((a.Cout + CT - 1) / CT, (a.M + PT - 1) / PT, 1);
-    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(kThreads), 0, stream, a);
+    constexpr size_t smem = (size_t)kStages * (CT + PT) * kRowB;
+#ifndef SY_EMU
+    static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return SY_ERR_LAUNCH;
+        attr_done = true;
+    }
+#endif
+    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(kThreads), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 

@@ -88,6 +88,34 @@ __device__ __forceinline__ f32x16 sy_mfma_group(F32, uint4 a, uint4 b, f32x16 c)
 }
 #endif
 
+// ---- LDS-DMA (global -> LDS without a VGPR round trip) and counted waits ----------------------------
+// sy_glds16: every lane copies 16 bytes from its own global address to (wave-uniform LDS base + lane*16).
+// The copy is asynchronous on hardware: it retires on the VM counter, so the consumer does
+// sy_wait_vmcnt<N>() (N = loads allowed to stay in flight) and then a raw barrier before reading.
+#ifdef SY_EMU
+static inline void sy_glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_memcpy(lds_wave_base + emu::lane_id() * 16, gsrc, 16);
+}
+template <int N> static inline void sy_wait_vmcnt() {}
+static inline void sy_barrier() { __syncthreads(); }
+#else
+// Issued through inline asm on purpose: when hipcc sees an LDS-DMA it cannot prove disjoint from a later
+// ds_read it drains the whole VM queue (s_waitcnt vmcnt(0)) in front of that read, which serialises a
+// multi-stage ring.  Hidden in asm, the loads are ours to count (guide §5.7): M0 carries the wave-uniform
+// LDS destination, is saved/restored inside the statement, and completion is awaited with sy_wait_vmcnt.
+__device__ __forceinline__ void sy_glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void sy_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void sy_barrier() { __builtin_amdgcn_s_barrier(); }
+#endif
+
 // ---- small math ---------------------------------------------------------------------------------
 #ifdef SY_EMU
 static inline float sy_exp(float x) { return expf(x); }

@@ -120,17 +120,27 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_kernel(typename T::elem* 
 // ---- training-mode BatchNorm -------------------------------------------------------------------------
 // The conv epilogue spreads its per-channel partial sums over `copies` replicas (contention control);
 // finalize folds them, updates the running statistics and emits the per-channel affine.
+// One workgroup = 32 channels; thread = (channel c = tid & 31, replica group r = tid >> 5): the replica
+// loads of a channel are independent and run in parallel, then an LDS fold.
 __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, const float* sqsum, int C, int copies,
                                                              double count, const float* gamma, const float* beta,
                                                              float eps, float momentum, float* running_mean,
                                                              float* running_var, float* scale, float* shift,
                                                              float* mean_out, float* invstd_out) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < copies; ++k) { s += (double)sum[(long long)k * C + c]; q += (double)sqsum[(long long)k * C + c]; }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
+    __shared__ float s_s[8][32], s_q[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.0f, q = 0.0f;
+    if (c < C)
+        for (int k = rg; k < copies; k += 8) { s += sum[(long long)k * C + c]; q += sqsum[(long long)k * C + c]; }
+    s_s[rg][cl] = s;
+    s_q[rg][cl] = q;
+    __syncthreads();
+    if (rg != 0 || c >= C) return;
+    double ds = 0.0, dq = 0.0;
+    for (int k = 0; k < 8; ++k) { ds += (double)s_s[k][cl]; dq += (double)s_q[k][cl]; }
+    const double mean = ds / count;
+    double var = dq / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
@@ -301,7 +311,7 @@ extern "C" int sy_bn_finalize(const float* sum, const float* sqsum, int C, int c
         shift == nullptr || C <= 0 || copies <= 0 || count <= 0.0)
         return SY_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SY_ERR_ARG;
-    SY_LAUNCH(bn_finalize_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sum, sqsum, C, copies, count,
+    SY_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, sum, sqsum, C, copies, count,
               gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }

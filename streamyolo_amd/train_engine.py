@@ -233,8 +233,8 @@ class TrainPlan:
         ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c)
         sc = self.pred_scratch
         sc.zero_()
-        ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1)
-        ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1)
+        ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1, workspace=self.wgrad_ws)
+        ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1, workspace=self.wgrad_ws)
         cin = op.reg_x.C
         self.gview[id(op.reg_mod.weight)].view(4, cin).add_(sc[0, 0:4, :cin])
         self.gview[id(op.obj_mod.weight)].view(1, cin).add_(sc[0, 4:5, :cin])
