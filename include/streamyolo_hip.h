@@ -37,6 +37,9 @@ enum {
     SY_EPI_DECODE = 3       /* ch0,1: (v+grid)*stride; ch2,3: exp(v)*stride; ch4: sigmoid (reg+obj preds) */
 };
 
+/* workgroup tiles of sy_conv2d (output channels x output pixels) */
+enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x128 = 3, SY_TILE_64x256 = 4, SY_TILE_32x256 = 5 };
+
 /* gather modes of sy_conv2d */
 enum {
     SY_CONV_FWD = 0,        /* out(ho,wo) <- in(ho*s - p + kh, wo*s - p + kw)                  */
@@ -67,6 +70,7 @@ typedef struct sy_conv_desc {
     int32_t accumulate;                 /* 1: y += result (gradient fan-in)                      */
     float dec_stride;                   /* SY_EPI_DECODE: the level's stride (8/16/32)           */
     int32_t stat_copies;                /* stat arrays hold this many replicas [copies][Cout] (>=1) */
+    int32_t tile;                       /* SY_TILE_AUTO or a forced workgroup tile (channels x pixels) */
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.

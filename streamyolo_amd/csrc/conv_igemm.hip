@@ -40,16 +40,18 @@ struct ConvArgs {
     float dec_stride;
     int M, K, HoWo;
     int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
+    int tile;                   // 0 = heuristic, 1..5 = forced tile configuration (tests / tuning)
 };
 
 constexpr int kRowB = 64;           // bytes of K per LDS row per slab; unpadded because LDS-DMA lands lane-linear
-constexpr int kThreads = 256;
 constexpr int kStages = 4;          // LDS ring depth: three slabs of loads in flight while one feeds the MFMAs
 
 __device__ uint4 g_zero16[4] = {};  // source of every predicated-off (padding / out-of-range) 16-byte chunk
 
 template <typename T, int WC, int WP, int TC, int TP>
-__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int kThreads = WC * WP * 64;       // 4 or 8 waves
+    constexpr int RPI = kThreads / 4;            // rows staged per sweep of the workgroup (one 16-byte chunk per lane)
     typedef typename T::elem elem;
     constexpr int EPC = T::kEPC;                 // elements per 16-byte chunk
     constexpr int ESZ = 16 / EPC;                // bytes per element
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
     constexpr int PT = WP * TP * 32;             // pixels per workgroup
     constexpr int WCH = (CT * 4 + kThreads - 1) / kThreads;   // weight chunks per thread per slab
     constexpr int XCH = (PT * 4 + kThreads - 1) / kThreads;   // pixel chunks per thread per slab
-    static_assert(WC * WP == 4, "4 waves per workgroup");
-    static_assert(PT % 64 == 0, "every wave stages pixel rows");
+    static_assert(WC * WP == 4 || WC * WP == 8, "4 or 8 waves per workgroup");
+    static_assert(PT % RPI == 0, "every wave stages pixel rows");
 
     // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue before every ds_read — guide §5)
     SY_DYN_SMEM(smem);
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
     bool px_ok[XCH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-        const int r = row0 + i * 64;
+        const int r = row0 + i * RPI;
         const int m = m0 + r;
         const bool ok = (m < p.M);
         const int mm = ok ? m : 0;
@@ -121,11 +123,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
         if (w_active) {
 #pragma unroll
             for (int i = 0; i < WCH; ++i) {
-                const int r = row0 + i * 64;
+                const int r = row0 + i * RPI;
                 const int co = c0 + r;
                 const unsigned char* src = zero;
                 if (k_ok && co < p.Cout) src = p.w + ((long long)co * p.K + k_el) * ESZ;
-                sy_glds16(src, sW + (stage * CT + wave * 16 + i * 64) * kRowB);
+                sy_glds16(src, sW + (stage * CT + wave * 16 + i * RPI) * kRowB);
             }
         }
         const int kh = tap / p.KW;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
             ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
             const unsigned char* src = zero;
             if (ok) src = p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ;
-            sy_glds16(src, sX + (stage * PT + wave * 16 + i * 64) * kRowB);
+            sy_glds16(src, sX + (stage * PT + wave * 16 + i * RPI) * kRowB);
         }
         k_el += BK;
         ci += BK;
@@ -207,8 +209,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
     const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
                         (p.res == nullptr || (p.ldr & 3) == 0);
     const bool want_stats = (p.stat_sum != nullptr);
-#pragma unroll
-    for (int t = 0; t < TC; ++t) {
+    // compile-time loop over the wave's channel tiles: accumulator indices must be constants (a runtime
+    // index would push the 128-register accumulator file of the 256x256 tile into scratch)
+    sy_static_for<0, TC>([&](auto tc_) {
+        constexpr int t = decltype(tc_)::value;
         float ssum[16], ssq[16];
         if (want_stats) {
 #pragma unroll
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
                     }
                     v[j] = z;
                 }
-                if (!m_ok || cb >= p.Cout) continue;
+                if (!m_ok || cb >= p.Cout) continue;   // (inside the q loop)
                 if (vec_ok) {
                     if (p.res != nullptr) {
                         const elem* rp = reinterpret_cast<const elem*>(p.res) + roff + cb;
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs p) {
                 }
             }
         }
-    }
+    });
     if (want_stats) {
         __syncthreads();
         const float* red = reinterpret_cast<const float*>(sW);
@@ -355,16 +359,32 @@ int launch_cfg(const ConvArgs& a, void* stream) {
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(kThreads), smem, stream, a);
+    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(WC * WP * 64), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
-    // tile choice by output-channel count: wide layers 128ch x 128px, narrow ones trade channels for pixels
-    if (a.Cout > 64) return launch_cfg<T, 2, 2, 2, 2>(a, stream);       // 128 ch x 128 px
-    if (a.Cout > 32) return launch_cfg<T, 1, 4, 2, 2>(a, stream);       //  64 ch x 256 px
-    return launch_cfg<T, 1, 4, 1, 2>(a, stream);                        //  32 ch x 256 px
+    // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide
+    // layers use 256 ch x 256 px (8 waves, 128 accumulator registers per lane).  Layers too small to give
+    // every CU a large tile fall back to 128 x 128 (4 waves); narrow layers trade channels for pixels.
+    switch (a.tile) {
+        case SY_TILE_256x256: return launch_cfg<T, 2, 4, 4, 2>(a, stream);
+        case SY_TILE_128x256: return launch_cfg<T, 1, 8, 4, 1>(a, stream);
+        case SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2>(a, stream);
+        case SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2>(a, stream);
+        case SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2>(a, stream);
+        default: break;
+    }
+    const long long big_tiles = (long long)((a.Cout + 255) / 256) * ((a.M + 255) / 256);
+    if (a.Cout > 128 && big_tiles >= 192) return launch_cfg<T, 2, 4, 4, 2>(a, stream);     // 256 ch x 256 px
+    if (a.Cout > 64) {
+        const long long mid_tiles = (long long)((a.Cout + 127) / 128) * ((a.M + 255) / 256);
+        if (a.Cout <= 128 && mid_tiles >= 192) return launch_cfg<T, 1, 8, 4, 1>(a, stream); // 128 ch x 256 px
+        return launch_cfg<T, 2, 2, 2, 2>(a, stream);                                        // 128 ch x 128 px
+    }
+    if (a.Cout > 32) return launch_cfg<T, 1, 4, 2, 2>(a, stream);                           //  64 ch x 256 px
+    return launch_cfg<T, 1, 4, 1, 2>(a, stream);                                            //  32 ch x 256 px
 }
 
 }  // namespace
@@ -391,6 +411,7 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.y_f32 = d->y_f32; a.mode = d->mode; a.epilogue = d->epilogue; a.accumulate = d->accumulate;
     a.dec_stride = d->dec_stride;
     a.stat_copies = d->stat_copies > 0 ? d->stat_copies : 1;
+    a.tile = d->tile;
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return launch_typed<BF16>(a, stream);

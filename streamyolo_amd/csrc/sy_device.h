@@ -127,6 +127,15 @@ __device__ __forceinline__ float sy_silu(float z) { return z * sy_sigmoid(z); }
 // d silu(z)/dz = s * (1 + z * (1 - s))
 __device__ __forceinline__ float sy_silu_grad(float z) { float s = sy_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
 
+// compile-time for: f(std::integral_constant<int, I>) for I in [B, E)
+template <int I> struct sy_int { static constexpr int value = I; };
+template <int B, int E, typename F> __device__ __forceinline__ void sy_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(sy_int<B>());
+        sy_static_for<B + 1, E>(f);
+    }
+}
+
 template <typename T> __device__ __forceinline__ T sy_min(T a, T b) { return a < b ? a : b; }
 template <typename T> __device__ __forceinline__ T sy_max(T a, T b) { return a > b ? a : b; }
 

@@ -91,7 +91,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None):
+           cout=None, tile=0):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -118,6 +118,7 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.y_f32 = 1 if y_f32 else 0
     d.mode, d.epilogue, d.accumulate = mode, epilogue, 1 if accumulate else 0
     d.dec_stride = float(dec_stride)
+    d.tile = int(tile)
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 

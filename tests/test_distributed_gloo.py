@@ -1,0 +1,86 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes (one per "GPU"), SIMT-emulator build of the kernels.
+
+Checks (a) TrainStep's single all-reduce over the flat gradient arena and (b) the drop-in path under
+torch's DistributedDataParallel wrapper (what the reference trainer does, double_trainer.py:171):
+after one step both ranks hold the MEAN of the two ranks' gradients, and `.grad` of shared
+backbone weights (used by both frames) fires its DDP hook exactly once."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, emu_lib, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SY_EMU_THREADS="4")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import streamyolo_amd as sy
+    from streamyolo_amd import _lib
+    from streamyolo_amd.train_engine import TrainStep
+    from oracle import streamyolo_oracle as O
+    from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
+    _lib.use_library(emu_lib)
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+
+    def fresh():
+        m = sy.build_model("nano")
+        m.load_state_dict(sd, strict=True)
+        m.train().set_compute_dtype("fp32")
+        m.head.use_l1 = True
+        return m
+    x = synth_frames(1, 64, 96, seed=20 + rank)
+    lab, sup = synth_labels(1, 64, 96, 8, num_gt=4, seed=30 + rank)
+
+    # (a) fast path: one all-reduce over the arena
+    m = fresh()
+    st = TrainStep(m, world_size=world, process_group=dist)
+    st.step(x, (lab, sup))
+    fast = st.plan.arena.clone()
+
+    # local (un-reduced) gradients of this rank, for the expected mean
+    m1 = fresh()
+    s1 = TrainStep(m1)
+    s1.step(x, (lab, sup))
+    local = s1.plan.arena.clone()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean = sum(gathered) / world
+    err_fast = float((fast - mean).abs().max() / mean.abs().max())
+
+    # (b) drop-in path under DDP
+    m2 = fresh()
+    ddp = torch.nn.parallel.DistributedDataParallel(m2, broadcast_buffers=False)
+    out = ddp(x, (lab, sup))
+    out["total_loss"].backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in m2.parameters()])
+    err_ddp = float((flat - mean).abs().max() / mean.abs().max())
+    torch.save({"err_fast": err_fast, "err_ddp": err_ddp, "nonzero": bool(mean.abs().max() > 0)},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_and_ddp(tmp_path):
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "streamyolo_amd", "csrc"), "-j8", "emu"], check=True)
+    emu_lib = os.path.join(ROOT, "tests", "emu", "_build", "libstreamyolo_emu.so")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, emu_lib, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        assert res["nonzero"]
+        assert res["err_fast"] < 1e-5, res
+        assert res["err_ddp"] < 1e-5, res

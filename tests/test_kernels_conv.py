@@ -50,6 +50,34 @@ def test_conv_fwd_silu_residual(backend, dt, cin, cout, k, stride, H, W, N):
     assert float(yb.buf[..., :16].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "dgrad")])
+def test_conv_every_tile_configuration(backend, tile, dt, mode):
+    """Each workgroup tile (256x256 / 128x256 on 8 waves, 128x128 / 64x256 / 32x256 on 4) on a shape with
+    ragged channel and pixel edges, forward (with BN statistics) and data-gradient gathers."""
+    g = torch.Generator().manual_seed(tile)
+    N, cin, cout, k, stride, H, W = 1, 24, 264, 3, 2, 21, 27
+    code = ops.dtype_code(dt)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt).requires_grad_(True)
+    w = _q(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, dt)
+    y = F.conv2d(x, w, None, stride, 1)
+    Ho, Wo = y.shape[2:]
+    xv = View.alloc(N, H, W, cin, dt, backend); xv.set_nchw(x.detach().to(backend))
+    if mode == "fwd":
+        yv = View.alloc(N, Ho, Wo, cout, dt, backend)
+        ssum = torch.zeros(2 * cout, device=backend); ssq = torch.zeros(2 * cout, device=backend)
+        ops.conv2d(xv, pack_conv_weight(w, code).to(backend), yv, k, stride, stats=(ssum, ssq), tile=tile)
+        assert _rel(yv.nchw().cpu(), y.detach()) < TOL[dt]
+        assert _rel(ssq.view(2, cout).sum(0).cpu(), (y.detach() ** 2).sum((0, 2, 3))) < 1e-3
+    else:
+        dy = _q(torch.randn(y.shape, generator=g), dt)
+        y.backward(dy)
+        dyv = View.alloc(N, Ho, Wo, cout, dt, backend); dyv.set_nchw(dy.to(backend))
+        dxv = View.alloc(N, H, W, cin, dt, backend, zero=True)
+        ops.conv2d(dyv, pack_conv_weight(w, code, transpose=True).to(backend), dxv, k, stride, mode=ops.CONV_DGRAD, tile=tile)
+        assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [(32, 48, 3, 1, 8, 7, 2), (32, 64, 3, 2, 9, 12, 1), (64, 32, 1, 1, 5, 6, 2)])
 def test_conv_stats_dgrad_wgrad(backend, dt, cin, cout, k, stride, H, W, N):
