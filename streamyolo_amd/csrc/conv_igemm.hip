@@ -48,7 +48,12 @@ constexpr int kStages = 4;          // LDS ring depth: three slabs of loads in f
 
 __device__ uint4 g_zero16[4] = {};  // source of every predicated-off (padding / out-of-range) 16-byte chunk
 
-template <typename T, int WC, int WP, int TC, int TP>
+constexpr int kPitchRS = 80;        // register-staged variant: 64 B of K + 16 B pad per LDS row (conflict-free ds_read_b128)
+
+// RS = 0: LDS-DMA ring (above).  RS = 1: register-staged variant — one slab of 16-byte global loads held in
+// VGPRs while the previous slab feeds the MFMAs, single LDS buffer, two barriers per slab; it needs only
+// 20-25 KiB of LDS, so 4-5 workgroups share a CU and hide each other's memory latency.
+template <typename T, int WC, int WP, int TC, int TP, int RS>
 __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
     constexpr int kThreads = WC * WP * 64;       // 4 or 8 waves
     constexpr int RPI = kThreads / 4;            // rows staged per sweep of the workgroup (one 16-byte chunk per lane)
@@ -65,8 +70,8 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
 
     // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue before every ds_read — guide §5)
     SY_DYN_SMEM(smem);
-    unsigned char* const sW = smem;                               // [kStages][CT][64 B]
-    unsigned char* const sX = smem + kStages * CT * kRowB;        // [kStages][PT][64 B]
+    unsigned char* const sW = smem;                               // [kStages][CT][64 B]   (RS: [CT][80 B])
+    unsigned char* const sX = smem + (RS ? CT * kPitchRS : kStages * CT * kRowB);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
     //      fragment reads are removed by an XOR swizzle applied on the SOURCE side: physical slot s of row r
     //      holds logical K-chunk s ^ ((r>>2)&3).  For a thread's rows (r>>2)&3 == (t>>4)&3, so its logical
     //      chunk — and with it (tap, ci) — is the same for every row and is tracked once per thread.
-    const int kc = (tid & 3) ^ ((tid >> 4) & 3);
+    const int kc = RS ? (tid & 3) : ((tid & 3) ^ ((tid >> 4) & 3));
     const int row0 = tid >> 2;
     const bool w_active = (wave * 16) < CT;      // narrow weight tiles are staged by the first waves only
 
@@ -181,27 +186,107 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
     const int half = lane >> 5;
     const int swz = (l31 >> 2) & 3;              // (row>>2)&3 of the fragment row this lane reads
 
-    for (int j = 0; j < kStages - 1 && j < nslab; ++j) issue_slab();
-    for (int s = 0; s < nslab; ++s) {
-        wait_slab(issued - s - 1);               // slab s has landed (this wave's part) ...
-        sy_barrier();                            // ... and everybody's; all waves are also done reading slab s-1
-        if (issued < nslab) issue_slab();        // refill the buffer slab s-1 occupied
-        const unsigned char* bw = sW + (s % kStages) * CT * kRowB;
-        const unsigned char* bx = sX + (s % kStages) * PT * kRowB;
+    if constexpr (RS) {
+        uint4 rw[WCH], rx[XCH];
+        auto load_slab = [&]() {
+            const bool k_ok = k_el < p.K;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int slot = ((g * 2 + half) ^ swz) * 16;
-            uint4 a[TC], b[TP];
+            for (int i = 0; i < WCH; ++i) {
+                const int r = row0 + i * RPI;
+                const int co = c0 + r;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (k_ok && r < CT && co < p.Cout)
+                    v = *reinterpret_cast<const uint4*>(p.w + ((long long)co * p.K + k_el) * ESZ);
+                rw[i] = v;
+            }
+            const int kh = tap / p.KW;
+            const int kw = tap - kh * p.KW;
 #pragma unroll
-            for (int t = 0; t < TC; ++t)
-                a[t] = *reinterpret_cast<const uint4*>(bw + ((wc * TC + t) * 32 + l31) * kRowB + slot);
+            for (int i = 0; i < XCH; ++i) {
+                int hi, wi;
+                bool ok = k_ok && px_ok[i];
+                if (p.mode == SY_CONV_FWD) {
+                    hi = px_h0[i] + kh;
+                    wi = px_w0[i] + kw;
+                } else {
+                    hi = px_h0[i] - kh;
+                    wi = px_w0[i] - kw;
+                    if (p.stride == 2) {
+                        ok = ok && ((hi & 1) == 0) && ((wi & 1) == 0);
+                        hi >>= 1;
+                        wi >>= 1;
+                    }
+                }
+                ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint4*>(p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ);
+                rx[i] = v;
+            }
+            k_el += BK;
+            ci += BK;
+            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        };
+        auto store_slab = [&]() {
 #pragma unroll
-            for (int u = 0; u < TP; ++u)
-                b[u] = *reinterpret_cast<const uint4*>(bx + ((wp * TP + u) * 32 + l31) * kRowB + slot);
+            for (int i = 0; i < WCH; ++i) {
+                const int r = row0 + i * RPI;
+                if (r < CT) *reinterpret_cast<uint4*>(sW + r * kPitchRS + kc * 16) = rw[i];
+            }
 #pragma unroll
-            for (int t = 0; t < TC; ++t)
+            for (int i = 0; i < XCH; ++i) {
+                const int r = row0 + i * RPI;
+                *reinterpret_cast<uint4*>(sX + r * kPitchRS + kc * 16) = rx[i];
+            }
+        };
+        load_slab();
+        store_slab();
+        __syncthreads();
+        for (int s = 0; s < nslab; ++s) {
+            const bool more = (s + 1 < nslab);
+            if (more) load_slab();
 #pragma unroll
-                for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
+            for (int g = 0; g < 2; ++g) {
+                uint4 a[TC], b[TP];
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+                    a[t] = *reinterpret_cast<const uint4*>(sW + ((wc * TC + t) * 32 + l31) * kPitchRS + g * 32 + half * 16);
+#pragma unroll
+                for (int u = 0; u < TP; ++u)
+                    b[u] = *reinterpret_cast<const uint4*>(sX + ((wp * TP + u) * 32 + l31) * kPitchRS + g * 32 + half * 16);
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
+            }
+            __syncthreads();
+            if (more) {
+                store_slab();
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int j = 0; j < kStages - 1 && j < nslab; ++j) issue_slab();
+        for (int s = 0; s < nslab; ++s) {
+            wait_slab(issued - s - 1);               // slab s has landed (this wave's part) ...
+            sy_barrier();                            // ... and everybody's; all waves are also done reading slab s-1
+            if (issued < nslab) issue_slab();        // refill the buffer slab s-1 occupied
+            const unsigned char* bw = sW + (s % kStages) * CT * kRowB;
+            const unsigned char* bx = sX + (s % kStages) * PT * kRowB;
+    #pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int slot = ((g * 2 + half) ^ swz) * 16;
+                uint4 a[TC], b[TP];
+    #pragma unroll
+                for (int t = 0; t < TC; ++t)
+                    a[t] = *reinterpret_cast<const uint4*>(bw + ((wc * TC + t) * 32 + l31) * kRowB + slot);
+    #pragma unroll
+                for (int u = 0; u < TP; ++u)
+                    b[u] = *reinterpret_cast<const uint4*>(bx + ((wp * TP + u) * 32 + l31) * kRowB + slot);
+    #pragma unroll
+                for (int t = 0; t < TC; ++t)
+    #pragma unroll
+                    for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
+            }
         }
     }
 
@@ -345,21 +430,21 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <typename T, int WC, int WP, int TC, int TP>
+template <typename T, int WC, int WP, int TC, int TP, int RS = 0>
 int launch_cfg(const ConvArgs& a, void* stream) {
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
     dim3 grid((a.Cout + CT - 1) / CT, (a.M + PT - 1) / PT, 1);
-    constexpr size_t smem = (size_t)kStages * (CT + PT) * kRowB;
+    constexpr size_t smem = RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB;
 #ifndef SY_EMU
     static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP>,
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP, RS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(WC * WP * 64), smem, stream, a);
+    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP, RS>), grid, dim3(WC * WP * 64), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
@@ -374,6 +459,11 @@ int launch_typed(const ConvArgs& a, void* stream) {
         case SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2>(a, stream);
         case SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2>(a, stream);
         case SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2>(a, stream);
+        case SY_TILE_RS + SY_TILE_256x256: return launch_cfg<T, 2, 4, 4, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_128x256: return launch_cfg<T, 1, 8, 4, 1, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2, 1>(a, stream);
         default: break;
     }
     const long long big_tiles = (long long)((a.Cout + 255) / 256) * ((a.M + 255) / 256);

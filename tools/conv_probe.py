@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Time every sy_conv2d kernel variant (workgroup tile x staging strategy) on representative layer
+shapes of StreamYOLO-l at batch 8.  Usage: python tools/conv_probe.py [--shapes i,j] [--tiles 1,3,19] [--reps 10]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from streamyolo_amd import ops                                        # noqa: E402
+from streamyolo_amd.ops import View                                   # noqa: E402
+
+# (name, N, H(out), W(out), Cin, Cout, k, stride)
+SHAPES = [
+    ("stem", 16, 300, 480, 16, 64, 3, 1),
+    ("dark2.0", 16, 150, 240, 64, 128, 3, 2),
+    ("d2.m.c1", 16, 150, 240, 64, 64, 1, 1),
+    ("d2.m.c2", 16, 150, 240, 64, 64, 3, 1),
+    ("d2.conv3", 16, 150, 240, 128, 128, 1, 1),
+    ("d3.m.c1", 16, 75, 120, 128, 128, 1, 1),
+    ("d3.m.c2", 16, 75, 120, 128, 128, 3, 1),
+    ("d3.conv3", 16, 75, 120, 256, 256, 1, 1),
+    ("dark4.0", 16, 38, 60, 256, 512, 3, 2),
+    ("d4.m.c1", 16, 38, 60, 256, 256, 1, 1),
+    ("d4.m.c2", 16, 38, 60, 256, 256, 3, 1),
+    ("d5.m.c2", 16, 19, 30, 512, 512, 3, 1),
+    ("spp.c2", 16, 19, 30, 2048, 1024, 1, 1),
+    ("head0.3x3", 8, 75, 120, 256, 256, 3, 1),
+    ("head1.3x3", 8, 38, 60, 256, 256, 3, 1),
+    ("head2.3x3", 8, 19, 30, 256, 256, 3, 1),
+]
+NAMES = {1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256",
+         17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="")
+    ap.add_argument("--tiles", default="1,2,3,4,17,18,19,20")
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    tiles = [int(t) for t in a.tiles.split(",")]
+    sel = [int(i) for i in a.shapes.split(",")] if a.shapes else range(len(SHAPES))
+    print("%-10s %-28s " % ("layer", "shape") + " ".join("%11s" % NAMES[t] for t in tiles) + "   (TFLOP/s, median of %d)" % a.reps)
+    for i in sel:
+        name, N, Ho, Wo, cin, cout, k, st = SHAPES[i]
+        H, W = Ho * st, Wo * st
+        g = torch.Generator().manual_seed(i)
+        x = View.alloc(N, H, W, cin, a.dtype, dev)
+        x.buf.copy_(torch.randn(x.buf.shape, generator=g).to(x.buf.dtype))
+        w = (torch.randn(cout, k * k * cin, generator=g) / (cin * k * k) ** 0.5).to(x.buf.dtype).to(dev)
+        y = View.alloc(N, ops.conv_out_size(H, k, st), ops.conv_out_size(W, k, st), cout, a.dtype, dev)
+        scale = torch.ones(cout, device=dev)
+        shift = torch.zeros(cout, device=dev)
+        flops = 2.0 * cin * cout * k * k * y.pixels
+        res = []
+        for t in tiles:
+            if (t & 15) in (4, 5) and cout > 64:
+                res.append(float("nan"))
+                continue
+            try:
+                for _ in range(2):
+                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(a.reps):
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t)
+                    e.record()
+                    torch.cuda.synchronize()
+                    ts.append(s.elapsed_time(e))
+                ts.sort()
+                res.append(flops / (ts[len(ts) // 2] * 1e-3) / 1e12)
+            except Exception as ex:                                    # noqa: BLE001
+                res.append(float("nan"))
+                print("   tile %d failed: %s" % (t, ex))
+        shp = "N%d %dx%d %d->%d k%d s%d" % (N, y.H, y.W, cin, cout, k, st)
+        print("%-10s %-28s " % (name, shp) + " ".join("%11.1f" % r for r in res))
+
+
+if __name__ == "__main__":
+    main()
