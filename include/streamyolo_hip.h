@@ -39,6 +39,7 @@ enum {
 
 /* workgroup tiles of sy_conv2d (output channels x output pixels) */
 enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x128 = 3, SY_TILE_64x256 = 4, SY_TILE_32x256 = 5,
+       SY_TILE_128x64 = 6, SY_TILE_64x64 = 7,
        SY_TILE_RS = 16 /* add to a tile code: register-staged variant instead of the LDS-DMA ring */ };
 
 /* gather modes of sy_conv2d */

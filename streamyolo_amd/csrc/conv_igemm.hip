@@ -115,10 +115,26 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
+    // K traversal.  Packed K index = tap * Cin + ci.  When Cin is a whole number of slabs the taps are the
+    // INNER loop: the kh*kw gathers of one 64-byte channel slab touch the same (plus halo) cache lines one
+    // slab apart, so they hit L1/L2 instead of being re-fetched from the fabric a whole Cin sweep later
+    // (measured on a 256->256 3x3 layer: 0.25 GB fetched per launch for a 37 MB input in tap-major order).
+    const int ntaps = p.KH * p.KW;
+    const bool tap_inner = (ntaps > 1) && (p.Cin % BK == 0);
     int k_el = kc * EPC;            // this thread's element offset inside the K range of the slab being issued
-    int tap = k_el / p.Cin;
-    int ci = k_el - tap * p.Cin;
+    int tap = tap_inner ? 0 : k_el / p.Cin;
+    int ci = tap_inner ? k_el : k_el - tap * p.Cin;
     int issued = 0;                 // slabs whose loads have been issued
+    auto advance_k = [&]() {
+        if (tap_inner) {
+            if (++tap == ntaps) { tap = 0; ci += BK; }
+            k_el = (ci < p.Cin) ? tap * p.Cin + ci : p.K;
+        } else {
+            k_el += BK;
+            ci += BK;
+            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        }
+    };
 
     const unsigned char* const zero = reinterpret_cast<const unsigned char*>(g_zero16);
 
@@ -158,9 +174,7 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
             if (ok) src = p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ;
             sy_glds16(src, sX + (stage * PT + wave * 16 + i * RPI) * kRowB);
         }
-        k_el += BK;
-        ci += BK;
-        while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        advance_k();
         ++issued;
     };
     // wait until at most `ahead` later slabs of THIS wave's loads are still in flight
@@ -222,9 +236,7 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
                 if (ok) v = *reinterpret_cast<const uint4*>(p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ);
                 rx[i] = v;
             }
-            k_el += BK;
-            ci += BK;
-            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+            advance_k();
         };
         auto store_slab = [&]() {
 #pragma unroll
@@ -459,6 +471,10 @@ int launch_typed(const ConvArgs& a, void* stream) {
         case SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2>(a, stream);
         case SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2>(a, stream);
         case SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2>(a, stream);
+        case SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2>(a, stream);
+        case SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_256x256: return launch_cfg<T, 2, 4, 4, 2, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_128x256: return launch_cfg<T, 1, 8, 4, 1, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 1>(a, stream);
@@ -466,15 +482,15 @@ int launch_typed(const ConvArgs& a, void* stream) {
         case SY_TILE_RS + SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2, 1>(a, stream);
         default: break;
     }
-    const long long big_tiles = (long long)((a.Cout + 255) / 256) * ((a.M + 255) / 256);
-    if (a.Cout > 128 && big_tiles >= 192) return launch_cfg<T, 2, 4, 4, 2>(a, stream);     // 256 ch x 256 px
-    if (a.Cout > 64) {
-        const long long mid_tiles = (long long)((a.Cout + 127) / 128) * ((a.M + 255) / 256);
-        if (a.Cout <= 128 && mid_tiles >= 192) return launch_cfg<T, 1, 8, 4, 1>(a, stream); // 128 ch x 256 px
-        return launch_cfg<T, 2, 2, 2, 2>(a, stream);                                        // 128 ch x 128 px
-    }
-    if (a.Cout > 32) return launch_cfg<T, 1, 4, 2, 2>(a, stream);                           //  64 ch x 256 px
-    return launch_cfg<T, 1, 4, 1, 2>(a, stream);                                            //  32 ch x 256 px
+    // Heuristic (tools/conv_probe.py on MI355X): the register-staged variant wins at every layer shape of the
+    // path because 4-5 of its workgroups share a CU; pick the largest tile that still yields >= 2 workgroups
+    // per CU (256 CUs), trading channels for pixels on narrow layers.
+    auto blocks = [&](int ct, int pt) { return (long long)((a.Cout + ct - 1) / ct) * ((a.M + pt - 1) / pt); };
+    if (a.Cout <= 32) return launch_cfg<T, 1, 4, 1, 2, 1>(a, stream);                       //  32 ch x 256 px
+    if (a.Cout <= 64) return launch_cfg<T, 1, 4, 2, 2, 1>(a, stream);                       //  64 ch x 256 px
+    if (blocks(128, 128) >= 512) return launch_cfg<T, 2, 2, 2, 2, 1>(a, stream);            // 128 ch x 128 px
+    if (blocks(128, 64) >= 512) return launch_cfg<T, 4, 1, 1, 2, 1>(a, stream);             // 128 ch x  64 px
+    return launch_cfg<T, 2, 2, 1, 1, 1>(a, stream);                                         //  64 ch x  64 px
 }
 
 }  // namespace

@@ -30,14 +30,15 @@ SHAPES = [
     ("head1.3x3", 8, 38, 60, 256, 256, 3, 1),
     ("head2.3x3", 8, 19, 30, 256, 256, 3, 1),
 ]
-NAMES = {1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256",
-         17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256"}
+NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256", 6: "dma128x64",
+         7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
+         22: "rs128x64", 23: "rs64x64"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="")
-    ap.add_argument("--tiles", default="1,2,3,4,17,18,19,20")
+    ap.add_argument("--tiles", default="0,3,19,20,22,23,6,7")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
