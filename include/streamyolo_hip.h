@@ -135,15 +135,17 @@ SY_API int sy_bn_finalize(const float* sum, const float* sqsum, int C, int copie
 SY_API int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res,
                      int ldr, void* out, int ldo, int64_t pixels, int C, int dtype, void* stream);
 /* Backward of (BN-train + SiLU): reduce pass then apply pass.
- * reduce: sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat, with dz = da * silu'(scale*y+shift). */
+ * reduce: sums[r][0][c] += sum dz, sums[r][1][c] += sum dz*xhat over replica r = workgroup % copies,
+ * with dz = da * silu'(scale*y+shift). */
 SY_API int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,
-                          const float* shift, const float* mean, const float* invstd, float* sums,
-                          int64_t pixels, int C, int dtype, void* stream);
-/* apply: dy = gamma*invstd*(dz - sums0/M - xhat*sums1/M); optionally dgamma += sums1, dbeta += sums0. */
+                                 const float* shift, const float* mean, const float* invstd, float* sums,
+                                 int copies, int64_t pixels, int C, int dtype, void* stream);
+/* apply: dy = gamma*invstd*(dz - S0/M - xhat*S1/M) with S = sums folded over its `copies` replicas
+ * ([copies][2][C]); optionally dgamma += S1, dbeta += S0. */
 SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
-                         const float* shift, const float* mean, const float* invstd,
-                         const float* gamma, const float* sums, void* dy, int lddy, int64_t pixels,
-                         int C, float* dgamma, float* dbeta, int dtype, void* stream);
+                                const float* shift, const float* mean, const float* invstd,
+                                const float* gamma, const float* sums, int copies, void* dy, int lddy,
+                                int64_t pixels, int C, float* dgamma, float* dbeta, int dtype, void* stream);
 
 /* SimOTA assignment + Trend-Aware loss, forward and gradient, for a whole batch, no host sync.
  * raw [B, A, 5+nc] fp32 raw head logits (reg4, obj, cls); labels/support [B, max_labels, 5] fp32 rows

@@ -41,6 +41,7 @@ struct ConvArgs {
     int M, K, HoWo;
     int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
     int tile;                   // 0 = heuristic, 1..5 = forced tile configuration (tests / tuning)
+    int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads
 };
 
 constexpr int kRowB = 64;           // bytes of K per LDS row per slab; unpadded because LDS-DMA lands lane-linear
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
                 const int r = row0 + i * RPI;
                 const int co = c0 + r;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (k_ok && r < CT && co < p.Cout)
+                if (k_ok && r < CT && co < p.Cout && !(p.ablate & 2))
                     v = *reinterpret_cast<const uint4*>(p.w + ((long long)co * p.K + k_el) * ESZ);
                 rw[i] = v;
             }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
                 }
                 ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) v = *reinterpret_cast<const uint4*>(p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ);
+                if (ok && !(p.ablate & 1)) v = *reinterpret_cast<const uint4*>(p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ);
                 rx[i] = v;
             }
             advance_k();
@@ -517,7 +518,8 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.y_f32 = d->y_f32; a.mode = d->mode; a.epilogue = d->epilogue; a.accumulate = d->accumulate;
     a.dec_stride = d->dec_stride;
     a.stat_copies = d->stat_copies > 0 ? d->stat_copies : 1;
-    a.tile = d->tile;
+    a.tile = d->tile & 0xff;
+    a.ablate = (d->tile >> 8) & 3;
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return launch_typed<BF16>(a, stream);

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
                                                                     const typename T::elem* da, int ldda,
                                                                     const float* scale, const float* shift,
                                                                     const float* mean, const float* invstd, float* sums,
-                                                                    long long pixels, int C) {
+                                                                    long long pixels, int C, int copies) {
     __shared__ float red[kBlock * 2 * 8];
     const int cpp = C / T::kEPC;
     const int rows = kBlock / cpp;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         const int kind = t & 1, j = (t >> 1) % T::kEPC, ch = (t >> 1) / T::kEPC;
         float v = 0.0f;
         for (int r = 0; r < rows; ++r) v += red[(j * 2 + kind) * kBlock + r * cpp + ch];
-        atomicAdd(sums + kind * C + ch * T::kEPC + j, v);
+        atomicAdd(sums + (long long)(blockIdx.x % copies) * 2 * C + kind * C + ch * T::kEPC + j, v);
     }
 }
 
@@ -238,14 +238,19 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
                                                                    const float* mean, const float* invstd,
                                                                    const float* gamma, const float* sums,
                                                                    typename T::elem* dy, int lddy, long long pixels,
-                                                                   int C, float* dgamma, float* dbeta) {
+                                                                   int C, int copies, float* dgamma, float* dbeta) {
     const int cpp = C / T::kEPC;
     const int rows = kBlock / cpp;
     const int cc = threadIdx.x % cpp;
     const int c0 = cc * T::kEPC;
     const float inv_m = 1.0f / (float)pixels;
     if (blockIdx.x == 0 && dgamma != nullptr) {        // launches on one stream are ordered: plain += is race free
-        for (int c = threadIdx.x; c < C; c += kBlock) { dgamma[c] += sums[C + c]; dbeta[c] += sums[c]; }
+        for (int c = threadIdx.x; c < C; c += kBlock) {
+            float a = 0.0f, b = 0.0f;
+            for (int k = 0; k < copies; ++k) { a += sums[(long long)k * 2 * C + c]; b += sums[(long long)k * 2 * C + C + c]; }
+            dbeta[c] += a;
+            dgamma[c] += b;
+        }
     }
     if ((int)threadIdx.x >= rows * cpp) return;
     float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], gi[T::kEPC], m0[T::kEPC], m1[T::kEPC];
@@ -254,8 +259,10 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         const int c = c0 + j;
         sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
         gi[j] = gamma[c] * invstd[c];
-        m0[j] = sums[c] * inv_m;
-        m1[j] = sums[C + c] * inv_m;
+        float a = 0.0f, b = 0.0f;
+        for (int k = 0; k < copies; ++k) { a += sums[(long long)k * 2 * C + c]; b += sums[(long long)k * 2 * C + C + c]; }
+        m0[j] = a * inv_m;
+        m1[j] = b * inv_m;
     }
     for (long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp; pix < pixels; pix += (long long)gridDim.x * rows) {
         Chunk<T> yv = Chunk<T>::load(y + pix * ldy + c0);
@@ -329,27 +336,28 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
 
 extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                      const float* shift, const float* mean, const float* invstd, float* sums,
-                                     int64_t pixels, int C, int dtype, void* stream) {
-    if (y == nullptr || da == nullptr || sums == nullptr || pixels <= 0 || C <= 0) return SY_ERR_ARG;
+                                     int copies, int64_t pixels, int C, int dtype, void* stream) {
+    if (y == nullptr || da == nullptr || sums == nullptr || pixels <= 0 || C <= 0 || copies <= 0) return SY_ERR_ARG;
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, 512)), dim3(kBlock), 0, stream,
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
-                                       mean, invstd, sums, (long long)pixels, C));
+                                       mean, invstd, sums, (long long)pixels, C, copies));
 }
 
 extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                     const float* shift, const float* mean, const float* invstd, const float* gamma,
-                                    const float* sums, void* dy, int lddy, int64_t pixels, int C, float* dgamma,
-                                    float* dbeta, int dtype, void* stream) {
-    if (y == nullptr || da == nullptr || sums == nullptr || dy == nullptr || pixels <= 0 || C <= 0) return SY_ERR_ARG;
+                                    const float* sums, int copies, void* dy, int lddy, int64_t pixels, int C,
+                                    float* dgamma, float* dbeta, int dtype, void* stream) {
+    if (y == nullptr || da == nullptr || sums == nullptr || dy == nullptr || pixels <= 0 || C <= 0 || copies <= 0)
+        return SY_ERR_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e || lddy % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
-                                       mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, dgamma,
-                                       dbeta));
+                                       mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
+                                       dgamma, dbeta));
 }

@@ -196,14 +196,16 @@ def bn_silu_apply(y, scale, shift, out, res=None):
 
 def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums):
     check(_lib.lib().sy_bn_silu_bwd_reduce(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
-                                           mean.data_ptr(), invstd.data_ptr(), sums.data_ptr(), y.pixels, y.C,
-                                           y.dtype, stream_of(y.buf)), "sy_bn_silu_bwd_reduce")
+                                           mean.data_ptr(), invstd.data_ptr(), sums.data_ptr(),
+                                           sums.numel() // (2 * y.C), y.pixels, y.C, y.dtype, stream_of(y.buf)),
+          "sy_bn_silu_bwd_reduce")
 
 
 def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None):
     check(_lib.lib().sy_bn_silu_bwd_apply(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
-                                          dy.ptr(), dy.ld, y.pixels, y.C, _p(dgamma), _p(dbeta), y.dtype,
+                                          sums.numel() // (2 * y.C), dy.ptr(), dy.ld, y.pixels, y.C, _p(dgamma),
+                                          _p(dbeta), y.dtype,
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 

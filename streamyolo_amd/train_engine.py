@@ -81,6 +81,7 @@ class _GradSpace:
 
 
 class TrainPlan:
+    BWD_COPIES = 16              # replicas of each BN-backward reduction (same reason)
     STAT_COPIES = 32             # replicas of each conv's sum / sum^2 arrays (atomic-contention control)
     WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
 
@@ -108,7 +109,8 @@ class TrainPlan:
         tot_c = sum(op.y.C for op in convs)
         SC = self.STAT_COPIES
         self.stat_arena = torch.zeros(2 * SC * tot_c, dtype=torch.float32, device=device)  # [sum | sumsq] x copies
-        self.bwd_arena = torch.zeros(2 * tot_c, dtype=torch.float32, device=device)       # sum dz | sum dz*xhat
+        BC = self.BWD_COPIES
+        self.bwd_arena = torch.zeros(2 * BC * tot_c, dtype=torch.float32, device=device)  # [copies][sum dz | sum dz*xhat]
         self.aff_arena = torch.empty(4 * tot_c, dtype=torch.float32, device=device)       # scale|shift|mean|invstd
         off = 0
         max_raw = 0
@@ -116,7 +118,7 @@ class TrainPlan:
             C = op.y.C
             op.stat = (self.stat_arena[SC * off:SC * (off + C)],
                        self.stat_arena[SC * (tot_c + off):SC * (tot_c + off + C)])
-            op.bsum = self.bwd_arena[2 * off:2 * off + 2 * C]
+            op.bsum = self.bwd_arena[2 * BC * off:2 * BC * (off + C)]
             op.aff = tuple(self.aff_arena[k * tot_c + off:k * tot_c + off + C] for k in range(4))
             op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
             max_raw = max(max_raw, op.y.pixels * C)

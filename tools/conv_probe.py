@@ -45,7 +45,9 @@ def main():
     dev = torch.device("cuda:0")
     tiles = [int(t) for t in a.tiles.split(",")]
     sel = [int(i) for i in a.shapes.split(",")] if a.shapes else range(len(SHAPES))
-    print("%-10s %-28s " % ("layer", "shape") + " ".join("%11s" % NAMES[t] for t in tiles) + "   (TFLOP/s, median of %d)" % a.reps)
+    def nm(t):
+        return NAMES[t & 255] + {0: "", 1: "-noX", 2: "-noW", 3: "-noXW"}[t >> 8]
+    print("%-10s %-28s " % ("layer", "shape") + " ".join("%15s" % nm(t) for t in tiles) + "   (TFLOP/s, median of %d)" % a.reps)
     for i in sel:
         name, N, Ho, Wo, cin, cout, k, st = SHAPES[i]
         H, W = Ho * st, Wo * st
@@ -80,7 +82,7 @@ def main():
                 res.append(float("nan"))
                 print("   tile %d failed: %s" % (t, ex))
         shp = "N%d %dx%d %d->%d k%d s%d" % (N, y.H, y.W, cin, cout, k, st)
-        print("%-10s %-28s " % (name, shp) + " ".join("%11.1f" % r for r in res))
+        print("%-10s %-28s " % (name, shp) + " ".join("%15.1f" % r for r in res))
 
 
 if __name__ == "__main__":
