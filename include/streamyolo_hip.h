@@ -73,6 +73,7 @@ typedef struct sy_conv_desc {
     float dec_stride;                   /* SY_EPI_DECODE: the level's stride (8/16/32)           */
     int32_t stat_copies;                /* stat arrays hold this many replicas [copies][Cout] (>=1) */
     int32_t tile;                       /* SY_TILE_AUTO or a forced workgroup tile (channels x pixels) */
+    int64_t x_bytes, w_bytes;           /* bytes addressable from x / w (buffer bounds of the fast gather; 0 = unknown) */
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.

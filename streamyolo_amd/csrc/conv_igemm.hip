@@ -41,6 +41,7 @@ struct ConvArgs {
     int M, K, HoWo;
     int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
     int tile;                   // 0 = heuristic, 1..5 = forced tile configuration (tests / tuning)
+    unsigned x_extent, w_extent; // bytes addressable from x / w (0 = unknown: generic loader only)
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads
 };
 
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
     // (measured on a 256->256 3x3 layer: 0.25 GB fetched per launch for a 37 MB input in tap-major order).
     const int ntaps = p.KH * p.KW;
     const bool tap_inner = (ntaps > 1) && (p.Cin % BK == 0);
+    const bool tap_inner_or_1x1 = (p.Cin % BK == 0);
     int k_el = kc * EPC;            // this thread's element offset inside the K range of the slab being issued
     int tap = tap_inner ? 0 : k_el / p.Cin;
     int ci = tap_inner ? k_el : k_el - tap * p.Cin;
@@ -239,6 +241,56 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
             }
             advance_k();
         };
+        // ---- fast loader: taps inner, every address = per-row 32-bit offset + ONE wave-uniform offset, padding and
+        //      ragged edges via the buffer bounds check.  ~2 VALU per 16-byte load instead of ~40: the generic
+        //      loader above made the whole kernel instruction-issue bound (tools/conv_probe.py ablation: no
+        //      speed-up with all global loads removed).
+        const bool fast = tap_inner_or_1x1 && p.x_extent != 0 && p.w_extent != 0 && ntaps <= 32 && !p.ablate;
+        const sy_buffer bx = sy_make_buffer(p.x, p.x_extent);
+        const sy_buffer bwt = sy_make_buffer(p.w, p.w_extent);
+        unsigned f_xoff[XCH], f_xmask[XCH], f_woff[WCH];
+        if (fast) {
+            const bool half_res = (p.mode != SY_CONV_FWD) && p.stride == 2;
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                unsigned mask = 0u;
+                for (int t = 0; t < ntaps; ++t) {
+                    const int kh = t / p.KW, kw = t - kh * p.KW;
+                    int hi, wi;
+                    bool ok = px_ok[i];
+                    if (p.mode == SY_CONV_FWD) { hi = px_h0[i] + kh; wi = px_w0[i] + kw; }
+                    else {
+                        hi = px_h0[i] - kh; wi = px_w0[i] - kw;
+                        if (half_res) { ok = ok && ((hi & 1) == 0) && ((wi & 1) == 0); hi >>= 1; wi >>= 1; }
+                    }
+                    if (ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) mask |= (1u << t);
+                }
+                f_xmask[i] = mask;
+                const int hb = half_res ? (px_h0[i] >> 1) : px_h0[i], wb = half_res ? (px_w0[i] >> 1) : px_w0[i];
+                f_xoff[i] = (unsigned)((px_base[i] + ((long long)hb * p.W + wb) * p.ldx + kc * EPC) * ESZ);
+            }
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                const int r = row0 + i * RPI;
+                const int co = c0 + r;
+                f_woff[i] = (r < CT && co < p.Cout) ? (unsigned)(((long long)co * p.K + kc * EPC) * ESZ) : 0xFFFFFFFFu;
+            }
+        }
+        int f_kh = 0, f_kw = 0, f_c = 0, f_t = 0;          // wave-uniform K position of the slab being loaded
+        auto load_slab_fast = [&]() {
+            int dpix;
+            if (p.mode == SY_CONV_FWD) dpix = f_kh * p.W + f_kw;
+            else if (p.stride == 2) dpix = -((f_kh >> 1) * p.W + (f_kw >> 1));
+            else dpix = -(f_kh * p.W + f_kw);
+            const unsigned s_x = (unsigned)((dpix * p.ldx + f_c) * ESZ);
+            const unsigned s_w = (unsigned)((f_t * p.Cin + f_c) * ESZ);
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) rw[i] = sy_buffer_load16(bwt, f_woff[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : f_woff[i] + s_w);
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) rx[i] = sy_buffer_load16(bx, ((f_xmask[i] >> f_t) & 1u) ? f_xoff[i] + s_x : 0xFFFFFFFFu);
+            ++f_t;
+            if (++f_kw == p.KW) { f_kw = 0; if (++f_kh == p.KH) { f_kh = 0; f_t = 0; f_c += BK; } }
+        };
         auto store_slab = [&]() {
 #pragma unroll
             for (int i = 0; i < WCH; ++i) {
@@ -251,12 +303,12 @@ __global__ __launch_bounds__(WC * WP * 64) void conv_igemm_kernel(ConvArgs p) {
                 *reinterpret_cast<uint4*>(sX + r * kPitchRS + kc * 16) = rx[i];
             }
         };
-        load_slab();
+        if (fast) load_slab_fast(); else load_slab();
         store_slab();
         __syncthreads();
         for (int s = 0; s < nslab; ++s) {
             const bool more = (s + 1 < nslab);
-            if (more) load_slab();
+            if (more) { if (fast) load_slab_fast(); else load_slab(); }
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 uint4 a[TC], b[TP];
@@ -518,6 +570,8 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.y_f32 = d->y_f32; a.mode = d->mode; a.epilogue = d->epilogue; a.accumulate = d->accumulate;
     a.dec_stride = d->dec_stride;
     a.stat_copies = d->stat_copies > 0 ? d->stat_copies : 1;
+    a.x_extent = (d->x_bytes > 0 && d->x_bytes < 0xFFFFFFF0LL) ? (unsigned)d->x_bytes : 0u;
+    a.w_extent = (d->w_bytes > 0 && d->w_bytes < 0xFFFFFFF0LL) ? (unsigned)d->w_bytes : 0u;
     a.tile = d->tile & 0xff;
     a.ablate = (d->tile >> 8) & 3;
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;

@@ -116,6 +116,29 @@ template <int N> __device__ __forceinline__ void sy_wait_vmcnt() { asm volatile(
 __device__ __forceinline__ void sy_barrier() { __builtin_amdgcn_s_barrier(); }
 #endif
 
+// ---- bounds-checked 16-byte buffer loads -------------------------------------------------------------
+// A buffer descriptor (base, extent) + a 32-bit byte offset per lane: the address math of a gather is one
+// integer add, and an offset >= extent (we use 0xFFFFFFFF) returns zeros — convolution padding for free.
+#ifdef SY_EMU
+struct sy_buffer { const unsigned char* base; unsigned extent; };
+static inline sy_buffer sy_make_buffer(const void* p, unsigned extent) { return sy_buffer{(const unsigned char*)p, extent}; }
+static inline uint4 sy_buffer_load16(const sy_buffer& b, unsigned voff) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned long long)voff + 16ull <= (unsigned long long)b.extent) __builtin_memcpy(&v, b.base + voff, 16);
+    return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t sy_buffer;
+typedef unsigned int sy_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ sy_buffer sy_make_buffer(const void* p, unsigned extent) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, extent, 0x00020000);
+}
+__device__ __forceinline__ uint4 sy_buffer_load16(const sy_buffer& b, unsigned voff) {
+    sy_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
+
 // ---- small math ---------------------------------------------------------------------------------
 #ifdef SY_EMU
 static inline float sy_exp(float x) { return expf(x); }

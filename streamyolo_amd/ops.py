@@ -62,6 +62,11 @@ class View:
     def ptr(self):
         return self.buf.data_ptr() + self.c_off * self.buf.element_size()
 
+    def bytes_from_ptr(self):
+        """Bytes of the underlying allocation addressable from ptr() (buffer bounds for the kernels)."""
+        st = self.buf.untyped_storage()
+        return st.nbytes() - (self.ptr() - st.data_ptr())
+
     def slice(self, c0, c):
         assert 0 <= c0 and c0 + c <= self.C
         return View(self.buf, self.N, self.H, self.W, c, self.ld, self.c_off + c0, self.bs_)
@@ -119,6 +124,8 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.mode, d.epilogue, d.accumulate = mode, epilogue, 1 if accumulate else 0
     d.dec_stride = float(dec_stride)
     d.tile = int(tile)
+    d.x_bytes = x.bytes_from_ptr()
+    d.w_bytes = w.numel() * w.element_size()
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
