@@ -1,0 +1,572 @@
+// conv_igemm_impl.h — NHWC implicit-GEMM convolution on the CDNA4 matrix cores, fused epilogue.
+//
+// Replaces (reference, per call): nn.Conv2d -> nn.BatchNorm2d -> nn.SiLU of yolox BaseConv, three
+// cuDNN/ATen kernels plus the cat/add kernels around them, and cuDNN's
+// backward-data under autograd.
+//
+// GEMM view:  D[co][p] = sum_k Wp[co][k] * X[p][k],   k = (tap, ci),  p = (n, ho, wo)
+//   * MFMA "A/row" operand = packed weights [Cout][K] (K-contiguous), "B/col" operand = pixels:
+//     each lane then owns 4 CONSECUTIVE output channels of one pixel per accumulator quad, so the
+//     epilogue stores 8 B (16-bit types) / 16 B (fp32) per lane straight from registers — NHWC
+//     output needs no LDS transpose.
+//   * K is walked in 64-byte slabs per row (32 bf16/f16 or 16 fp32 elements), 16-byte chunks.
+//   * wave64: 4 or 8 waves per workgroup arranged WC x WP over (channels x pixels); each wave owns
+//     TC x TP accumulator tiles of 32x32 (16 fp32 registers each).
+//   * gather modes: forward (stride 1/2, zero padding) and data-gradient (transposed conv).
+//   * two loaders (template FAST):
+//       FAST    Cin is a whole number of slabs: taps are the INNER loop (the kh*kw gathers of one channel
+//               slab hit the same cache lines one slab apart) and every address is a per-row 32-bit
+//               offset + ONE wave-uniform offset, fetched with bounds-checked buffer loads: out-of-image
+//               taps and ragged edges get offset 0xFFFFFFFF and read zeros.  ~2 VALU per 16-byte load.
+//       generic any Cin % 8 == 0 (stem: 16 channels, taps straddle slabs): per-chunk (tap, ci) tracking and
+//               64-bit address math (~40 VALU per load; made the first version instruction-issue bound).
+//   * two staging strategies (template RS):
+//       RS = 1  register-staged: one slab of loads held in VGPRs while the previous one feeds the MFMAs,
+//               single padded LDS buffer (80-byte pitch), two barriers per slab; ~20 KiB of LDS so several
+//               workgroups share a CU and hide each other's latency.  Fastest on MI355X today.
+//       RS = 0  4-stage LDS ring filled by LDS-DMA (global/buffer_load ... lds in inline asm, counted
+//               s_waitcnt vmcnt(N), raw s_barrier, XOR swizzle applied on the source side so the
+//               ds_read_b128 fragment reads stay conflict free).
+//   * epilogue (all fp32): z = acc*scale[co] + shift[co]; linear | SiLU | sigmoid | box decode;
+//     optional residual add, optional += into the destination, optional per-channel sum / sum of
+//     squares of the raw accumulator for training-mode BatchNorm (wave shuffles, LDS fold over the
+//     waves, one atomic per channel per workgroup into one of `stat_copies` replicas).
+#pragma once
+#include "sy_device.h"
+#include "../../include/streamyolo_hip.h"
+
+namespace sy_conv {
+
+struct ConvArgs {
+    const unsigned char* x;
+    const unsigned char* w;
+    const float* scale;
+    const float* shift;
+    const unsigned char* res;
+    unsigned char* y;
+    float* stat_sum;
+    float* stat_sq;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int ldx, ldy, ldr;
+    long long xbs, ybs, rbs;
+    int y_f32, mode, epilogue, accumulate;
+    float dec_stride;
+    int M, K, HoWo;
+    int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
+    int tile;                   // 0 = heuristic, else a forced tile configuration (tests / tuning)
+    unsigned x_extent, w_extent; // bytes addressable from x / w (FAST loader's buffer bounds)
+    int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads
+};
+
+constexpr int kRowB = 64;           // DMA ring: bytes of K per LDS row per slab (unpadded: LDS-DMA lands lane-linear)
+constexpr int kStages = 4;          // DMA ring depth: three slabs of loads in flight while one feeds the MFMAs
+constexpr int kPitchRS = 80;        // register-staged: 64 B of K + 16 B pad per LDS row (conflict-free ds_read_b128)
+
+static __device__ uint4 g_zero16[4] = {};  // DMA generic loader: source of every predicated-off 16-byte chunk
+
+template <typename T, int WC, int WP, int TC, int TP, int RS, int FAST>
+__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
+    typedef typename T::elem elem;
+    constexpr int kThreads = WC * WP * 64;       // 4 or 8 waves
+    constexpr int RPI = kThreads / 4;            // rows staged per sweep of the workgroup (one 16-byte chunk per lane)
+    constexpr int EPC = T::kEPC;                 // elements per 16-byte chunk
+    constexpr int ESZ = 16 / EPC;                // bytes per element
+    constexpr int BK = 4 * EPC;                  // elements per 64-byte K slab
+    constexpr int CT = WC * TC * 32;             // channels per workgroup
+    constexpr int PT = WP * TP * 32;             // pixels per workgroup
+    constexpr int WCH = (CT * 4 + kThreads - 1) / kThreads;   // weight chunks per thread per slab
+    constexpr int XCH = (PT * 4 + kThreads - 1) / kThreads;   // pixel chunks per thread per slab
+    static_assert(WC * WP == 4 || WC * WP == 8, "4 or 8 waves per workgroup");
+    static_assert(PT % RPI == 0, "every wave stages pixel rows");
+
+    // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue before every ds_read — guide §5)
+    SY_DYN_SMEM(smem);
+    unsigned char* const sW = smem;
+    unsigned char* const sX = smem + (RS ? CT * kPitchRS : kStages * CT * kRowB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave / WP;
+    const int wp = wave % WP;
+    const int c0 = blockIdx.x * CT;
+    const int m0 = blockIdx.y * PT;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    // ---- staging assignment.  Thread t owns rows (t>>2) + RPI*i and 16-byte slot t&3 of each.  In the DMA
+    //      ring one wave instruction fills 16 rows x 64 B lane-linearly, and the physical slot s of row r holds
+    //      logical K-chunk s ^ ((r>>2)&3) (XOR swizzle on the source side); for a thread's rows (r>>2)&3 ==
+    //      (t>>4)&3, so its logical chunk is the same for every row.
+    const int kc = RS ? (tid & 3) : ((tid & 3) ^ ((tid >> 4) & 3));
+    const int row0 = tid >> 2;
+    const bool w_active = (wave * 16) < CT;      // DMA: narrow weight tiles are staged by the first waves only
+    const int ntaps = p.KH * p.KW;
+
+    // output pixel of staged row i -> image index and gather origin
+    auto row_geom = [&](int i, bool& ok, long long& base, int& h0, int& w0) {
+        const int m = m0 + row0 + i * RPI;
+        ok = (m < p.M);
+        const int mm = ok ? m : 0;
+        const int n = mm / p.HoWo;
+        const int rem = mm - n * p.HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        base = (long long)n * p.xbs;
+        if (p.mode == SY_CONV_FWD) { h0 = ho * p.stride - p.pad; w0 = wo * p.stride - p.pad; }
+        else { h0 = ho + p.pad; w0 = wo + p.pad; }
+    };
+    auto tap_coords = [&](int h0, int w0, int kh, int kw, int& hi, int& wi) -> bool {   // gather source of one tap
+        bool ok = true;
+        if (p.mode == SY_CONV_FWD) { hi = h0 + kh; wi = w0 + kw; }
+        else {
+            hi = h0 - kh; wi = w0 - kw;
+            if (p.stride == 2) { ok = ((hi & 1) == 0) && ((wi & 1) == 0); hi >>= 1; wi >>= 1; }
+        }
+        return ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int u = 0; u < TP; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    const int nslab = (p.K + BK - 1) / BK;
+
+    // one slab of MFMAs from LDS rows `bw`/`bx` with row pitch PITCH and per-lane 16-byte slot selector
+    auto compute_slab = [&](const unsigned char* bw, const unsigned char* bx, int pitch, int swz) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int slot = ((g * 2 + half) ^ swz) * 16;
+            uint4 a[TC], b[TP];
+#pragma unroll
+            for (int t = 0; t < TC; ++t) a[t] = *reinterpret_cast<const uint4*>(bw + ((wc * TC + t) * 32 + l31) * pitch + slot);
+#pragma unroll
+            for (int u = 0; u < TP; ++u) b[u] = *reinterpret_cast<const uint4*>(bx + ((wp * TP + u) * 32 + l31) * pitch + slot);
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
+        }
+    };
+
+    if constexpr (FAST) {
+        // ================= FAST loader: per-row 32-bit offsets + one wave-uniform offset per slab =================
+        const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
+        const sy_buffer bufw = sy_make_buffer(p.w, p.w_extent);
+        const bool half_res = (p.mode != SY_CONV_FWD) && p.stride == 2;
+        unsigned xoff[XCH], xmask[XCH], woff[WCH];
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            bool ok; long long base; int h0, w0;
+            row_geom(i, ok, base, h0, w0);
+            unsigned mask = 0u;
+            for (int t = 0; t < ntaps; ++t) {
+                const int kh = t / p.KW, kw = t - kh * p.KW;
+                int hi, wi;
+                if (ok && tap_coords(h0, w0, kh, kw, hi, wi)) mask |= (1u << t);
+            }
+            xmask[i] = mask;
+            const int hb = half_res ? (h0 >> 1) : h0, wb = half_res ? (w0 >> 1) : w0;
+            xoff[i] = (unsigned)((base + ((long long)hb * p.W + wb) * p.ldx + kc * EPC) * ESZ);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int r = row0 + i * RPI;
+            const int co = c0 + r;
+            woff[i] = (r < CT && co < p.Cout) ? (unsigned)(((long long)co * p.K + kc * EPC) * ESZ) : 0xFFFFFFFFu;
+        }
+        int f_kh = 0, f_kw = 0, f_c = 0, f_t = 0;          // wave-uniform K position of the next slab to fetch
+        unsigned s_x = 0, s_w = 0;
+        auto slab_offsets = [&]() {                          // uniform offsets of slab (f_t, f_c); then advance
+            int dpix;
+            if (p.mode == SY_CONV_FWD) dpix = f_kh * p.W + f_kw;
+            else if (p.stride == 2) dpix = -((f_kh >> 1) * p.W + (f_kw >> 1));
+            else dpix = -(f_kh * p.W + f_kw);
+            s_x = (unsigned)((dpix * p.ldx + f_c) * ESZ);
+            s_w = (unsigned)((f_t * p.Cin + f_c) * ESZ);
+        };
+        auto advance = [&]() {
+            ++f_t;
+            if (++f_kw == p.KW) { f_kw = 0; if (++f_kh == p.KH) { f_kh = 0; f_t = 0; f_c += BK; } }
+        };
+        if constexpr (RS) {
+            uint4 rw[WCH], rx[XCH];
+            auto load_slab = [&]() {
+                slab_offsets();
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) rw[i] = sy_buffer_load16(bufw, woff[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : woff[i] + s_w);
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) rx[i] = sy_buffer_load16(bufx, ((xmask[i] >> f_t) & 1u) ? xoff[i] + s_x : 0xFFFFFFFFu);
+                advance();
+            };
+            auto store_slab = [&]() {
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) {
+                    const int r = row0 + i * RPI;
+                    if (r < CT) *reinterpret_cast<uint4*>(sW + r * kPitchRS + kc * 16) = rw[i];
+                }
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) *reinterpret_cast<uint4*>(sX + (row0 + i * RPI) * kPitchRS + kc * 16) = rx[i];
+            };
+            load_slab();
+            store_slab();
+            __syncthreads();
+            for (int s = 0; s < nslab; ++s) {
+                const bool more = (s + 1 < nslab);
+                if (more) load_slab();
+                compute_slab(sW, sX, kPitchRS, 0);
+                __syncthreads();
+                if (more) {
+                    store_slab();
+                    __syncthreads();
+                }
+            }
+        } else {
+            int issued = 0;
+            auto issue_slab = [&]() {
+                const int stage = issued % kStages;
+                slab_offsets();
+                if (w_active) {
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i)
+                        sy_glds16_buf(bufw, woff[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : woff[i] + s_w,
+                                      sW + (stage * CT + wave * 16 + i * RPI) * kRowB);
+                }
+#pragma unroll
+                for (int i = 0; i < XCH; ++i)
+                    sy_glds16_buf(bufx, ((xmask[i] >> f_t) & 1u) ? xoff[i] + s_x : 0xFFFFFFFFu,
+                                  sX + (stage * PT + wave * 16 + i * RPI) * kRowB);
+                advance();
+                ++issued;
+            };
+            auto wait_slab = [&](int ahead) {      // at most `ahead` later slabs of THIS wave's loads still in flight
+                constexpr int LA = WCH + XCH, LI = XCH;
+                if (w_active) {
+                    if (ahead >= 2) sy_wait_vmcnt<2 * LA>(); else if (ahead == 1) sy_wait_vmcnt<LA>(); else sy_wait_vmcnt<0>();
+                } else {
+                    if (ahead >= 2) sy_wait_vmcnt<2 * LI>(); else if (ahead == 1) sy_wait_vmcnt<LI>(); else sy_wait_vmcnt<0>();
+                }
+            };
+            const int swz = (l31 >> 2) & 3;
+            for (int j = 0; j < kStages - 1 && j < nslab; ++j) issue_slab();
+            for (int s = 0; s < nslab; ++s) {
+                wait_slab(issued - s - 1);               // slab s has landed (this wave's part) ...
+                sy_barrier();                            // ... and everybody's; all waves are done reading slab s-1
+                if (issued < nslab) issue_slab();        // refill the buffer slab s-1 occupied
+                compute_slab(sW + (s % kStages) * CT * kRowB, sX + (s % kStages) * PT * kRowB, kRowB, swz);
+            }
+        }
+    } else {
+        // ================= generic loader: per-chunk (tap, ci), 64-bit addresses =================
+        int px_h0[XCH], px_w0[XCH];
+        long long px_base[XCH];
+        bool px_ok[XCH];
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) row_geom(i, px_ok[i], px_base[i], px_h0[i], px_w0[i]);
+        const bool tap_inner = (ntaps > 1) && (p.Cin % BK == 0);
+        int k_el = kc * EPC;            // this thread's element offset inside the K range of the slab being fetched
+        int tap = tap_inner ? 0 : k_el / p.Cin;
+        int ci = tap_inner ? k_el : k_el - tap * p.Cin;
+        auto advance_k = [&]() {
+            if (tap_inner) {
+                if (++tap == ntaps) { tap = 0; ci += BK; }
+                k_el = (ci < p.Cin) ? tap * p.Cin + ci : p.K;
+            } else {
+                k_el += BK;
+                ci += BK;
+                while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+            }
+        };
+        auto w_src = [&](int i) -> const unsigned char* {       // nullptr = zeros
+            const int r = row0 + i * RPI;
+            const int co = c0 + r;
+            if (k_el < p.K && r < CT && co < p.Cout && !(p.ablate & 2)) return p.w + ((long long)co * p.K + k_el) * ESZ;
+            return nullptr;
+        };
+        auto x_src = [&](int i, int kh, int kw) -> const unsigned char* {
+            int hi, wi;
+            if (k_el < p.K && px_ok[i] && tap_coords(px_h0[i], px_w0[i], kh, kw, hi, wi) && !(p.ablate & 1))
+                return p.x + (px_base[i] + ((long long)hi * p.W + wi) * p.ldx + ci) * ESZ;
+            return nullptr;
+        };
+        if constexpr (RS) {
+            uint4 rw[WCH], rx[XCH];
+            auto load_slab = [&]() {
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) {
+                    const unsigned char* src = w_src(i);
+                    rw[i] = src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0u, 0u, 0u, 0u);
+                }
+                const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const unsigned char* src = x_src(i, kh, kw);
+                    rx[i] = src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0u, 0u, 0u, 0u);
+                }
+                advance_k();
+            };
+            auto store_slab = [&]() {
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) {
+                    const int r = row0 + i * RPI;
+                    if (r < CT) *reinterpret_cast<uint4*>(sW + r * kPitchRS + kc * 16) = rw[i];
+                }
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) *reinterpret_cast<uint4*>(sX + (row0 + i * RPI) * kPitchRS + kc * 16) = rx[i];
+            };
+            load_slab();
+            store_slab();
+            __syncthreads();
+            for (int s = 0; s < nslab; ++s) {
+                const bool more = (s + 1 < nslab);
+                if (more) load_slab();
+                compute_slab(sW, sX, kPitchRS, 0);
+                __syncthreads();
+                if (more) {
+                    store_slab();
+                    __syncthreads();
+                }
+            }
+        } else {
+            const unsigned char* const zero = reinterpret_cast<const unsigned char*>(g_zero16);
+            int issued = 0;
+            auto issue_slab = [&]() {
+                const int stage = issued % kStages;
+                if (w_active) {
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) {
+                        const unsigned char* src = w_src(i);
+                        sy_glds16(src ? src : zero, sW + (stage * CT + wave * 16 + i * RPI) * kRowB);
+                    }
+                }
+                const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const unsigned char* src = x_src(i, kh, kw);
+                    sy_glds16(src ? src : zero, sX + (stage * PT + wave * 16 + i * RPI) * kRowB);
+                }
+                advance_k();
+                ++issued;
+            };
+            auto wait_slab = [&](int ahead) {
+                constexpr int LA = WCH + XCH, LI = XCH;
+                if (w_active) {
+                    if (ahead >= 2) sy_wait_vmcnt<2 * LA>(); else if (ahead == 1) sy_wait_vmcnt<LA>(); else sy_wait_vmcnt<0>();
+                } else {
+                    if (ahead >= 2) sy_wait_vmcnt<2 * LI>(); else if (ahead == 1) sy_wait_vmcnt<LI>(); else sy_wait_vmcnt<0>();
+                }
+            };
+            const int swz = (l31 >> 2) & 3;
+            for (int j = 0; j < kStages - 1 && j < nslab; ++j) issue_slab();
+            for (int s = 0; s < nslab; ++s) {
+                wait_slab(issued - s - 1);
+                sy_barrier();
+                if (issued < nslab) issue_slab();
+                compute_slab(sW + (s % kStages) * CT * kRowB, sX + (s % kStages) * PT * kRowB, kRowB, swz);
+            }
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
+                        (p.res == nullptr || (p.ldr & 3) == 0);
+    const bool want_stats = (p.stat_sum != nullptr);
+    // compile-time loop over the wave's channel tiles: accumulator indices must be constants (a runtime
+    // index would push the 128-register accumulator file of the 256x256 tile into scratch)
+    sy_static_for<0, TC>([&](auto tc_) {
+        constexpr int t = decltype(tc_)::value;
+        float ssum[16], ssq[16];
+        if (want_stats) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+        }
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            const int m = m0 + (wp * TP + u) * 32 + l31;
+            const bool m_ok = m < p.M;
+            const int mm = m_ok ? m : 0;
+            const int n = mm / p.HoWo;
+            const int rem = mm - n * p.HoWo;
+            const long long yoff = (long long)n * p.ybs + (long long)rem * p.ldy;
+            const long long roff = (long long)n * p.rbs + (long long)rem * p.ldr;
+            int gy = 0, gx = 0;
+            if (p.epilogue == SY_EPI_DECODE) { gy = rem / p.Wo; gx = rem - gy * p.Wo; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cb = c0 + (wc * TC + t) * 32 + q * 8 + half * 4;   // first of 4 channels
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[t][u][q * 4 + j];
+                    if (want_stats) { ssum[q * 4 + j] += a; ssq[q * 4 + j] += a * a; }
+                    const int co = cb + j;
+                    const float sc = (p.scale != nullptr && co < p.Cout) ? p.scale[co] : 1.0f;
+                    const float sh = (p.shift != nullptr && co < p.Cout) ? p.shift[co] : 0.0f;
+                    float z = a * sc + sh;
+                    if (p.epilogue == SY_EPI_SILU) z = sy_silu(z);
+                    else if (p.epilogue == SY_EPI_SIGMOID) z = sy_sigmoid(z);
+                    else if (p.epilogue == SY_EPI_DECODE) {
+                        if (co == 0) z = (z + (float)gx) * p.dec_stride;
+                        else if (co == 1) z = (z + (float)gy) * p.dec_stride;
+                        else if (co == 2 || co == 3) z = sy_exp(z) * p.dec_stride;
+                        else z = sy_sigmoid(z);
+                    }
+                    v[j] = z;
+                }
+                if (!m_ok || cb >= p.Cout) continue;   // (inside the q loop)
+                if (vec_ok) {
+                    if (p.res != nullptr) {
+                        const elem* rp = reinterpret_cast<const elem*>(p.res) + roff + cb;
+                        if (ESZ == 2) {
+                            uint2 rv = *reinterpret_cast<const uint2*>(rp);
+                            elem e[4];
+                            __builtin_memcpy(e, &rv, 8);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += T::to_f32(e[j]);
+                        } else {
+                            float4 rv = *reinterpret_cast<const float4*>(rp);
+                            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                        }
+                    }
+                    if (p.y_f32 || ESZ == 4) {
+                        float* yp = reinterpret_cast<float*>(p.y) + yoff + cb;
+                        if (p.accumulate) {
+                            float4 o = *reinterpret_cast<const float4*>(yp);
+                            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                        }
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        elem* yp = reinterpret_cast<elem*>(p.y) + yoff + cb;
+                        elem e[4];
+                        if (p.accumulate) {
+                            uint2 o = *reinterpret_cast<const uint2*>(yp);
+                            __builtin_memcpy(e, &o, 8);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += T::to_f32(e[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e[j] = T::from_f32(v[j]);
+                        uint2 o;
+                        __builtin_memcpy(&o, e, 8);
+                        *reinterpret_cast<uint2*>(yp) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = cb + j;
+                        if (co >= p.Cout) continue;
+                        float z = v[j];
+                        if (p.res != nullptr) z += T::to_f32(reinterpret_cast<const elem*>(p.res)[roff + co]);
+                        if (p.y_f32 || ESZ == 4) {
+                            float* yp = reinterpret_cast<float*>(p.y) + yoff + co;
+                            if (p.accumulate) z += *yp;
+                            *yp = z;
+                        } else {
+                            elem* yp = reinterpret_cast<elem*>(p.y) + yoff + co;
+                            if (p.accumulate) z += T::to_f32(*yp);
+                            *yp = T::from_f32(z);
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            // reduce over the 32 pixels held by lanes with equal `half`; park the wave's 32 channel sums in LDS
+            // (the K loop is over: sW is free after the barrier below), fold the WP waves, one atomic per channel.
+            float* red = reinterpret_cast<float*>(sW);            // [WP][CT][2]
+            if (t == 0) __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = ssum[r], b = ssq[r];
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    a += __shfl_xor(a, off);
+                    b += __shfl_xor(b, off);
+                }
+                const int cl = (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
+                if (l31 == 0) {
+                    red[(wp * CT + cl) * 2 + 0] = a;
+                    red[(wp * CT + cl) * 2 + 1] = b;
+                }
+            }
+        }
+    });
+    if (want_stats) {
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(sW);
+        const int copy = (int)(blockIdx.y % (unsigned)p.stat_copies);
+        for (int cl = tid; cl < CT; cl += kThreads) {
+            const int co = c0 + cl;
+            if (co >= p.Cout) continue;
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WP; ++w) { a += red[(w * CT + cl) * 2]; b += red[(w * CT + cl) * 2 + 1]; }
+            atomicAdd(p.stat_sum + (long long)copy * p.Cout + co, a);
+            atomicAdd(p.stat_sq + (long long)copy * p.Cout + co, b);
+        }
+    }
+}
+
+template <typename T, int WC, int WP, int TC, int TP, int RS, int FAST>
+int launch_one(const ConvArgs& a, void* stream) {
+    constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
+    dim3 grid((a.Cout + CT - 1) / CT, (a.M + PT - 1) / PT, 1);
+    constexpr size_t smem = RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB;
+#ifndef SY_EMU
+    static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP, RS, FAST>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return SY_ERR_LAUNCH;
+        attr_done = true;
+    }
+#endif
+    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP, RS, FAST>), grid, dim3(WC * WP * 64), smem, stream, a);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+template <typename T, int WC, int WP, int TC, int TP, int RS = 0>
+int launch_cfg(const ConvArgs& a, void* stream) {
+    // FAST loader preconditions: whole slabs per tap, 32-bit addressable operands, taps fit the validity mask
+    const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32 && !a.ablate;
+    return fast ? launch_one<T, WC, WP, TC, TP, RS, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, RS, 0>(a, stream);
+}
+
+template <typename T>
+int launch_typed(const ConvArgs& a, void* stream) {
+    // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide
+    // layers use 256 ch x 256 px (8 waves, 128 accumulator registers per lane).  Layers too small to give
+    // every CU a large tile fall back to 128 x 128 (4 waves); narrow layers trade channels for pixels.
+    switch (a.tile) {
+        case SY_TILE_256x256: return launch_cfg<T, 2, 4, 4, 2>(a, stream);
+        case SY_TILE_128x256: return launch_cfg<T, 1, 8, 4, 1>(a, stream);
+        case SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2>(a, stream);
+        case SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2>(a, stream);
+        case SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2>(a, stream);
+        case SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2>(a, stream);
+        case SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_256x256: return launch_cfg<T, 2, 4, 4, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_128x256: return launch_cfg<T, 1, 8, 4, 1, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 1>(a, stream);
+        case SY_TILE_RS + SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2, 1>(a, stream);
+        default: break;
+    }
+    // Heuristic (tools/conv_probe.py on MI355X): the register-staged variant wins at every layer shape of the
+    // path because 4-5 of its workgroups share a CU; pick the largest tile that still yields >= 2 workgroups
+    // per CU (256 CUs), trading channels for pixels on narrow layers.
+    auto blocks = [&](int ct, int pt) { return (long long)((a.Cout + ct - 1) / ct) * ((a.M + pt - 1) / pt); };
+    if (a.Cout <= 32) return launch_cfg<T, 1, 4, 1, 2, 1>(a, stream);                       //  32 ch x 256 px
+    if (a.Cout <= 64) return launch_cfg<T, 1, 4, 2, 2, 1>(a, stream);                       //  64 ch x 256 px
+    if (blocks(128, 128) >= 512) return launch_cfg<T, 2, 2, 2, 2, 1>(a, stream);            // 128 ch x 128 px
+    if (blocks(128, 64) >= 512) return launch_cfg<T, 4, 1, 1, 2, 1>(a, stream);             // 128 ch x  64 px
+    return launch_cfg<T, 2, 2, 1, 1, 1>(a, stream);                                         //  64 ch x  64 px
+}
+
+}  // namespace sy_conv

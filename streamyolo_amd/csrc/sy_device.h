@@ -98,6 +98,7 @@ static inline void sy_glds16(const void* gsrc, unsigned char* lds_wave_base) {
 }
 template <int N> static inline void sy_wait_vmcnt() {}
 static inline void sy_barrier() { __syncthreads(); }
+
 #else
 // Issued through inline asm on purpose: when hipcc sees an LDS-DMA it cannot prove disjoint from a later
 // ds_read it drains the whole VM queue (s_waitcnt vmcnt(0)) in front of that read, which serialises a
@@ -127,6 +128,10 @@ static inline uint4 sy_buffer_load16(const sy_buffer& b, unsigned voff) {
     if ((unsigned long long)voff + 16ull <= (unsigned long long)b.extent) __builtin_memcpy(&v, b.base + voff, 16);
     return v;
 }
+static inline void sy_glds16_buf(const sy_buffer& b, unsigned voff, unsigned char* lds_wave_base) {
+    const uint4 v = sy_buffer_load16(b, voff);
+    __builtin_memcpy(lds_wave_base + emu::lane_id() * 16, &v, 16);
+}
 #else
 typedef __amdgpu_buffer_rsrc_t sy_buffer;
 typedef unsigned int sy_u32x4 __attribute__((ext_vector_type(4)));
@@ -136,6 +141,17 @@ __device__ __forceinline__ sy_buffer sy_make_buffer(const void* p, unsigned exte
 __device__ __forceinline__ uint4 sy_buffer_load16(const sy_buffer& b, unsigned voff) {
     sy_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, voff, 0, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+// LDS-DMA through a buffer descriptor: out-of-range lanes deposit zeros.  Inline asm for the same reason as
+// sy_glds16 (the loads must stay invisible to hipcc's conservative vmcnt(0) before ds_read).
+__device__ __forceinline__ void sy_glds16_buf(const sy_buffer& b, unsigned voff, unsigned char* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(b), "s"(dst)
+                 : "memory");
 }
 #endif
 

@@ -239,18 +239,21 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
                                                                    const float* gamma, const float* sums,
                                                                    typename T::elem* dy, int lddy, long long pixels,
                                                                    int C, int copies, float* dgamma, float* dbeta) {
+    // fold the replicas of the two reduction sums once per workgroup, cooperatively, through LDS
+    __shared__ float s_fold[2 * 1024];
     const int cpp = C / T::kEPC;
     const int rows = kBlock / cpp;
     const int cc = threadIdx.x % cpp;
     const int c0 = cc * T::kEPC;
     const float inv_m = 1.0f / (float)pixels;
+    for (int i = threadIdx.x; i < 2 * C; i += kBlock) {
+        float a = 0.0f;
+        for (int k = 0; k < copies; ++k) a += sums[(long long)k * 2 * C + i];
+        s_fold[i] = a;
+    }
+    __syncthreads();
     if (blockIdx.x == 0 && dgamma != nullptr) {        // launches on one stream are ordered: plain += is race free
-        for (int c = threadIdx.x; c < C; c += kBlock) {
-            float a = 0.0f, b = 0.0f;
-            for (int k = 0; k < copies; ++k) { a += sums[(long long)k * 2 * C + c]; b += sums[(long long)k * 2 * C + C + c]; }
-            dbeta[c] += a;
-            dgamma[c] += b;
-        }
+        for (int c = threadIdx.x; c < C; c += kBlock) { dbeta[c] += s_fold[c]; dgamma[c] += s_fold[C + c]; }
     }
     if ((int)threadIdx.x >= rows * cpp) return;
     float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], gi[T::kEPC], m0[T::kEPC], m1[T::kEPC];
@@ -259,10 +262,8 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         const int c = c0 + j;
         sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
         gi[j] = gamma[c] * invstd[c];
-        float a = 0.0f, b = 0.0f;
-        for (int k = 0; k < copies; ++k) { a += sums[(long long)k * 2 * C + c]; b += sums[(long long)k * 2 * C + C + c]; }
-        m0[j] = a * inv_m;
-        m1[j] = b * inv_m;
+        m0[j] = s_fold[c] * inv_m;
+        m1[j] = s_fold[C + c] * inv_m;
     }
     for (long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp; pix < pixels; pix += (long long)gridDim.x * rows) {
         Chunk<T> yv = Chunk<T>::load(y + pix * ldy + c0);
@@ -355,7 +356,7 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e || lddy % e) return SY_ERR_UNSUPPORTED;
-    if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
+    if (!chunk_rows_ok(C, e) || C > 1024) return SY_ERR_UNSUPPORTED;
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
