@@ -169,7 +169,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
                 int hi, wi;
                 if (ok && tap_coords(h0, w0, kh, kw, hi, wi)) mask |= (1u << t);
             }
-            xmask[i] = mask;
+            xmask[i] = (p.ablate & 1) ? 0u : mask;
             const int hb = half_res ? (h0 >> 1) : h0, wb = half_res ? (w0 >> 1) : w0;
             xoff[i] = (unsigned)((base + ((long long)hb * p.W + wb) * p.ldx + kc * EPC) * ESZ);
         }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
         for (int i = 0; i < WCH; ++i) {
             const int r = row0 + i * RPI;
             const int co = c0 + r;
-            woff[i] = (r < CT && co < p.Cout) ? (unsigned)(((long long)co * p.K + kc * EPC) * ESZ) : 0xFFFFFFFFu;
+            woff[i] = (r < CT && co < p.Cout && !(p.ablate & 2)) ? (unsigned)(((long long)co * p.K + kc * EPC) * ESZ) : 0xFFFFFFFFu;
         }
         int f_kh = 0, f_kw = 0, f_c = 0, f_t = 0;          // wave-uniform K position of the next slab to fetch
         unsigned s_x = 0, s_w = 0;
@@ -532,7 +532,7 @@ int launch_one(const ConvArgs& a, void* stream) {
 template <typename T, int WC, int WP, int TC, int TP, int RS = 0>
 int launch_cfg(const ConvArgs& a, void* stream) {
     // FAST loader preconditions: whole slabs per tap, 32-bit addressable operands, taps fit the validity mask
-    const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32 && !a.ablate;
+    const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32;
     return fast ? launch_one<T, WC, WP, TC, TP, RS, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, RS, 0>(a, stream);
 }
 
