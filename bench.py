@@ -38,9 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, choices=[None, "train", "infer"])
+    ap.add_argument("--workload", default=None, choices=[None, "train", "infer", "stream"])
     ap.add_argument("--model", default="l")
-    ap.add_argument("--batch", type=int, default=8, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs (frames for stream) per GPU per step; default 8, stream 1")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=960)
@@ -129,12 +129,14 @@ def main():
     cfg = O.OracleConfig.named(args.model)
     flops_fwd = O.conv_flops_per_pair(cfg, args.height, args.width)
     flops_pair = flops_fwd * (3.0 if workload == "train" else 1.0)
+    if workload == "stream":
+        flops_pair = O.conv_flops_per_pair(cfg, args.height, args.width, mode="on_pipe")
 
     model = sy.build_model(args.model)
     bn = load_bn_stats(args.model) if args.model in ("nano", "s", "l") else None
     model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=bn), strict=True)
     model = model.to(dev).set_compute_dtype(args.dtype)
-    B = args.batch
+    B = args.batch if args.batch is not None else (1 if workload == "stream" else 8)
     x = synth_frames(B, args.height, args.width, seed=2 + rank).to(dev)
 
     if workload == "train":
@@ -146,6 +148,34 @@ def main():
         def step():
             return stepper.step(x, (lab, sup))
         profile = stepper.profile
+    elif workload == "stream":
+        # BASELINE.json configs[4]: on_pipe steady state, one 600x960 frame per step, decode + NMS included
+        from streamyolo_amd.postprocess import postprocess_device
+        model.eval()
+        frame = x[:, 0:3].contiguous()
+        plan = model._plans.inference(model.backbone, model.head, "on_pipe", frame, owner=model)
+        graph = None
+
+        def eager():
+            with torch.no_grad():
+                out = plan.run_stream(frame)
+                return postprocess_device(out, cfg.num_classes, 0.01, 0.65)
+        with torch.no_grad():
+            plan.run_stream(frame, first=True)
+        if args.graph:
+            for _ in range(2):
+                eager()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eager()
+
+        def step():
+            if graph is not None:
+                graph.replay()
+            else:
+                eager()
+        profile = lambda n: plan.profile(frame, n)                          # noqa: E731
     else:
         model.eval()
         plan = model._plans.inference(model.backbone, model.head, "off_pipe", x, owner=model)
@@ -209,14 +239,16 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "frame-pairs/sec (600x960) StreamYOLO-%s %s" % (args.model, "fwd+bwd" if workload == "train" else "fwd (eval)"),
-            "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("frames/sec (600x960) StreamYOLO-%s on_pipe fwd + decode + NMS" % args.model) if workload == "stream"
+            else "frame-pairs/sec (600x960) StreamYOLO-%s %s" % (args.model, "fwd+bwd" if workload == "train" else "fwd (eval)"),
+            "value": value, "unit": "frames/s" if workload == "stream" else "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "StreamYOLO-%s %dx%d %s, %d frame pairs/GPU/step, %s"
                                    % (args.model, args.height, args.width,
                                       "training step: dual-frame forward + TAL loss + backward" if workload == "train"
-                                      else "eval forward off_pipe + decode", B,
+                                      else ("streaming on_pipe forward + decode + NMS (conf 0.01, IoU 0.65)" if workload == "stream"
+                                            else "eval forward off_pipe + decode"), B,
                                       "random-init synthetic weights (utils/synth.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "hipgraph": bool(args.graph)},

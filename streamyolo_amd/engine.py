@@ -38,6 +38,20 @@ class ConvOp:
         # training state (allocated lazily by TrainState)
         self.yraw = None
         self.stat = None
+        self._tiles = {}
+
+    def tile(self, kind):
+        """Tuned kernel variant for this op: kind = 'fwd' (eval epilogue), 'fwd_stats' (training) or 'dgrad'."""
+        t = self._tiles.get(kind)
+        if t is None:
+            x, y = self.x, self.y
+            if kind == "dgrad":
+                t = ops.tuned_tile(CONV_DGRAD, y.dtype, y.N, y.H, y.W, y.C, x.C, self.k, self.stride, y.buf.device)
+            else:
+                t = ops.tuned_tile(ops.CONV_FWD, x.dtype, x.N, x.H, x.W, x.C, y.C, self.k, self.stride, x.buf.device,
+                                   with_stats=(kind == "fwd_stats"))
+            self._tiles[kind] = t
+        return t
 
 
 class PredOp:
@@ -281,7 +295,7 @@ class InferencePlan:
     def _run_op(self, op):
         if op.kind == "conv":
             w, scale, shift = self.cache.conv_eval(op.mod)
-            ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU)
+            ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU, tile=op.tile("fwd"))
         elif op.kind == "resize":
             ops.resize_nearest(op.src, op.dst)
         elif op.kind == "spp":
@@ -320,6 +334,25 @@ class InferencePlan:
         for op in self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]:
             self._run_op(op)
         return self.fused
+
+    def run_stream(self, x, first=False):
+        """Streaming step with plan-owned state (graph-capturable: no pointer swaps, no allocation):
+        fuse the current frame with the PRE-fusion PAN outputs kept from the previous call, then keep the
+        current ones for the next call.  `first=True` = node 'star' (fuse with itself)."""
+        assert not self.pair
+        ops.focus_pack(x.float().contiguous(), 0, self.f0)
+        n_fuse = 6
+        for op in self.ops[:self.n_backbone_ops - n_fuse]:
+            self._run_op(op)
+        if first:
+            for dst, s in zip(self.sup_in, self.cur_pans):
+                ops.view_copy(s, dst)
+        for op in self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]:
+            self._run_op(op)
+        out = self.run_head()
+        for dst, s in zip(self.sup_in, self.cur_pans):
+            ops.view_copy(s, dst)
+        return out
 
     def export_buffer(self):
         """The current frame's PRE-fusion PAN outputs as NCHW-shaped (channels-last memory) tensors:

@@ -271,3 +271,70 @@ def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value,
                                  float(ignore_value), 1 if use_l1 else 0, ws.d_raw.data_ptr(), ws.losses.data_ptr(),
                                  ws.fg.data_ptr(), ws.ws.data_ptr(), stream_of(raw)), "sy_tal_loss")
     return ws.losses, ws.d_raw, ws.fg
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-shape kernel-variant selection for sy_conv2d (measured once per shape on the device, cached)
+# ---------------------------------------------------------------------------------------------------
+TILE_RS = 16
+_TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging strategy codes, see include/streamyolo_hip.h
+    "wide": [19, 22, 23, 3, 6],         # rs128x128, rs128x64, rs64x64, dma128x128, dma128x64
+    "c64": [20, 23, 4, 7],              # rs64x256, rs64x64, dma64x256, dma64x64
+    "c32": [21, 23, 5],                 # rs32x256, rs64x64, dma32x256
+}
+_tile_cache = {}
+
+
+def autotune_enabled(device):
+    import os
+    return device.type == "cuda" and os.environ.get("STREAMYOLO_AUTOTUNE", "1") != "0"
+
+
+def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False):
+    """Fastest sy_conv2d variant for this problem shape (H, W = INPUT size of the launch), or 0 (the
+    library's static heuristic) when tuning is off.  Measured with HIP events on dummy tensors."""
+    if not autotune_enabled(device):
+        return 0
+    key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats), str(device))
+    hit = _tile_cache.get(key)
+    if hit is not None:
+        return hit
+    code = dtype_code(dtype)
+    if mode == CONV_FWD:
+        Ho, Wo = conv_out_size(H, k, stride), conv_out_size(W, k, stride)
+        x = View.alloc(N, H, W, Cin, code, device, zero=True)
+        y = View.alloc(N, Ho, Wo, Cout, code, device)
+        w = torch.zeros((Cout, k * k * Cin), dtype=TORCH_DTYPE[code], device=device)
+    else:       # data gradient: launch input = dy [N,H,W,Cin(=fwd Cout)], output = dx at the forward input size
+        Ho, Wo = (H, W) if stride == 1 else (H * 2, W * 2)
+        x = View.alloc(N, H, W, Cin, code, device, zero=True)
+        y = View.alloc(N, Ho, Wo, Cout, code, device)
+        w = torch.zeros((Cout, k * k * Cin), dtype=TORCH_DTYPE[code], device=device)
+    scale = torch.ones(Cout, device=device)
+    shift = torch.zeros(Cout, device=device)
+    stats = (torch.zeros(32 * Cout, device=device), torch.zeros(32 * Cout, device=device)) if with_stats else None
+    cands = _TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide"]
+    best, best_t = 0, float("inf")
+    for t in cands:
+        def run():
+            if with_stats:
+                conv2d(x, w, y, k, stride, stats=stats, mode=mode, tile=t)
+            else:
+                conv2d(x, w, y, k, stride, scale, shift, epilogue=EPI_SILU if mode == CONV_FWD else EPI_LINEAR,
+                       mode=mode, tile=t)
+        try:
+            run()
+            torch.cuda.synchronize(device)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                run()
+            e.record()
+            torch.cuda.synchronize(device)
+            dt = s.elapsed_time(e)
+        except _lib.HipLibraryError:
+            continue
+        if dt < best_t:
+            best, best_t = t, dt
+    _tile_cache[key] = best
+    return best

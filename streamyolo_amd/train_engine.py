@@ -157,7 +157,7 @@ class TrainPlan:
             if k == "conv":
                 bn = op.mod.bn
                 w = self.cache.conv_weight(op.mod)
-                ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat)
+                ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=op.tile("fwd_stats"))
                 scale, shift, mean, invstd = op.aff
                 mom = bn.momentum if bn.momentum is not None else 0.1
                 ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
@@ -271,7 +271,7 @@ class TrainPlan:
         if op.need_dx:
             dx, acc = G.target(op.x)
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
-                       mode=CONV_DGRAD, accumulate=acc)
+                       mode=CONV_DGRAD, accumulate=acc, tile=op.tile("dgrad"))
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, x, targets, iters=2):
