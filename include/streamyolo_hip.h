@@ -40,7 +40,9 @@ enum {
 /* workgroup tiles of sy_conv2d (output channels x output pixels) */
 enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x128 = 3, SY_TILE_64x256 = 4, SY_TILE_32x256 = 5,
        SY_TILE_128x64 = 6, SY_TILE_64x64 = 7,
-       SY_TILE_RS = 16 /* add to a tile code: register-staged variant instead of the LDS-DMA ring */ };
+       SY_TILE_RS = 16,   /* add to a tile code: register-staged variant instead of the 4-deep LDS-DMA ring */
+       SY_TILE_DMA2 = 32, /* add: 2-deep LDS-DMA ring */
+       SY_TILE_DMA3 = 48  /* add: 3-deep LDS-DMA ring */ };
 
 /* gather modes of sy_conv2d */
 enum {
@@ -94,6 +96,7 @@ typedef struct sy_wgrad_desc {
     int32_t dw_oihw;
     void* workspace;                    /* optional fp32 scratch for split-K slabs (NULL: one split) */
     int64_t workspace_bytes;
+    int32_t tile, target_blocks;        /* tuning knobs (0 = heuristic): workgroup tile, workgroups aimed for by split-K */
 } sy_wgrad_desc;
 SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
 

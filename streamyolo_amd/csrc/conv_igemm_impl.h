@@ -59,14 +59,17 @@ struct ConvArgs {
 };
 
 constexpr int kRowB = 64;           // DMA ring: bytes of K per LDS row per slab (unpadded: LDS-DMA lands lane-linear)
-constexpr int kStages = 4;          // DMA ring depth: three slabs of loads in flight while one feeds the MFMAs
 constexpr int kPitchRS = 80;        // register-staged: 64 B of K + 16 B pad per LDS row (conflict-free ds_read_b128)
 
 static __device__ uint4 g_zero16[4] = {};  // DMA generic loader: source of every predicated-off 16-byte chunk
 
-template <typename T, int WC, int WP, int TC, int TP, int RS, int FAST>
+// STG: staging strategy — 1 = register-staged; 2 / 3 / 4 (0 = 4) = LDS-DMA ring of that depth (depth-1 slabs of
+// loads in flight while one feeds the MFMAs; a shallow ring costs less LDS, so more workgroups share a CU).
+template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
     typedef typename T::elem elem;
+    constexpr int RS = (STG == 1) ? 1 : 0;
+    constexpr int kStages = (STG == 1) ? 1 : (STG == 0 ? 4 : STG);
     constexpr int kThreads = WC * WP * 64;       // 4 or 8 waves
     constexpr int RPI = kThreads / 4;            // rows staged per sweep of the workgroup (one 16-byte chunk per lane)
     constexpr int EPC = T::kEPC;                 // elements per 16-byte chunk
@@ -511,29 +514,31 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     }
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int RS, int FAST>
+template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
 int launch_one(const ConvArgs& a, void* stream) {
+    constexpr int RS = (STG == 1) ? 1 : 0;
+    constexpr int kStages = (STG == 1) ? 1 : (STG == 0 ? 4 : STG);
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
     dim3 grid((a.Cout + CT - 1) / CT, (a.M + PT - 1) / PT, 1);
     constexpr size_t smem = RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB;
 #ifndef SY_EMU
     static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP, RS, FAST>,
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP, RS, FAST>), grid, dim3(WC * WP * 64), smem, stream, a);
+    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST>), grid, dim3(WC * WP * 64), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int RS = 0>
+template <typename T, int WC, int WP, int TC, int TP, int STG = 0>
 int launch_cfg(const ConvArgs& a, void* stream) {
     // FAST loader preconditions: whole slabs per tap, 32-bit addressable operands, taps fit the validity mask
     const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32;
-    return fast ? launch_one<T, WC, WP, TC, TP, RS, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, RS, 0>(a, stream);
+    return fast ? launch_one<T, WC, WP, TC, TP, STG, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, STG, 0>(a, stream);
 }
 
 template <typename T>
@@ -551,6 +556,14 @@ int launch_typed(const ConvArgs& a, void* stream) {
         case SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 1>(a, stream);
+        case 32 + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 2>(a, stream);       // 2-deep DMA ring
+        case 32 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 2>(a, stream);
+        case 32 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 2>(a, stream);
+        case 32 + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 2>(a, stream);
+        case 48 + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 3>(a, stream);       // 3-deep DMA ring
+        case 48 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 3>(a, stream);
+        case 48 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 3>(a, stream);
+        case 48 + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 3>(a, stream);
         case SY_TILE_RS + SY_TILE_256x256: return launch_cfg<T, 2, 4, 4, 2, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_128x256: return launch_cfg<T, 1, 8, 4, 1, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 1>(a, stream);

@@ -29,6 +29,7 @@ struct WgradArgs {
     long long xbs, dybs;
     int M, K, slabs_per_split;
     int oihw;                   // 1: dW laid out [Cout][Cin][KH][KW] (the nn.Parameter layout), 0: [Cout][tap][Cin]
+    int tile, target_blocks;    // tuning knobs: 0 = heuristics
     float* part;                // split > 1: partial tiles [splits][Cout][K] (packed layout), folded by wgrad_fold_kernel
     int splits;
 };
@@ -282,7 +283,8 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     const int gx = (a.K + RT - 1) / RT, gy = (a.Cout + CT - 1) / CT;
     const int slabs_total = (a.M + SLAB - 1) / SLAB;
     // about two workgroups per CU (256 CUs), at least 8 slabs of work each, and the slabs must fit the workspace
-    int splits = (512 + gx * gy - 1) / (gx * gy);
+    const int target = a.target_blocks > 0 ? a.target_blocks : 512;
+    int splits = (target + gx * gy - 1) / (gx * gy);
     const int max_splits = (slabs_total + 7) / 8;
     if (splits > max_splits) splits = max_splits;
     const long long slab_bytes = (long long)a.Cout * a.K * 4;
@@ -306,6 +308,15 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
 
 template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
+    switch (a.tile) {          // (k rows x output channels) per workgroup
+        case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128
+        case 2: return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);   // 128 x  64
+        case 3: return launch_wgrad_cfg<T, 4, 1, 1, 1>(a, ws_bytes, stream);   // 128 x  32
+        case 4: return launch_wgrad_cfg<T, 2, 2, 1, 1>(a, ws_bytes, stream);   //  64 x  64
+        case 5: return launch_wgrad_cfg<T, 1, 4, 2, 1>(a, ws_bytes, stream);   //  64 x 128
+        case 6: return launch_wgrad_cfg<T, 2, 2, 1, 2>(a, ws_bytes, stream);   //  64 x 128 (2x2 waves)
+        default: break;
+    }
     if (a.Cout > 64) return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);     // 128 k x 128 co
     if (a.Cout > 32) return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);     // 128 k x  64 co
     return launch_wgrad_cfg<T, 4, 1, 1, 1>(a, ws_bytes, stream);                      // 128 k x  32 co
@@ -328,6 +339,8 @@ extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
     a.ldx = d->ldx; a.lddy = d->lddy; a.xbs = d->xbs; a.dybs = d->dybs;
     a.M = d->N * d->Ho * d->Wo; a.K = d->KH * d->KW * d->Cin; a.slabs_per_split = 0;
     a.oihw = d->dw_oihw;
+    a.tile = d->tile;
+    a.target_blocks = d->target_blocks;
     a.part = (float*)d->workspace;
     a.splits = 1;
     const long long wsb = d->workspace != nullptr ? (long long)d->workspace_bytes : 0;

@@ -279,6 +279,15 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
     }
 }
 
+// sums[0][i] = sum over replicas k of sums[k][i]  (i in [0, 2C)): run once before the apply pass
+__global__ __launch_bounds__(kBlock) void fold_replicas_kernel(float* sums, int n, int copies) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (int k = 0; k < copies; ++k) a += sums[(long long)k * n + i];
+    sums[i] = a;
+}
+
 inline bool chunk_rows_ok(int C, int e) { const int cpp = C / e; return cpp >= 1 && cpp <= kBlock; }
 
 inline int row_grid(long long pixels, int C, int e, int cap) {
@@ -357,6 +366,11 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e || lddy % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e) || C > 1024) return SY_ERR_UNSUPPORTED;
+    if (copies > 1) {       // fold once here instead of in every workgroup of the apply pass (sums is consumed by it)
+        SY_LAUNCH(fold_replicas_kernel, dim3((2 * C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, const_cast<float*>(sums),
+                  2 * C, copies);
+        copies = 1;
+    }
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,

@@ -129,7 +129,7 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
-def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None):
+def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, target_blocks=0):
     """dw fp32 += wgrad(x, dy): [Cout, k*k*Cin] packed layout, or the OIHW parameter layout.
     workspace: optional uint8/fp32 device tensor for the split-K slabs (more parallelism on big layers)."""
     d = WgradDesc()
@@ -141,6 +141,7 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None):
     d.ldx, d.lddy, d.xbs, d.dybs = x.ld, dy.ld, x.bs, dy.bs
     d.dtype = x.dtype
     d.dw_oihw = 1 if oihw else 0
+    d.tile, d.target_blocks = int(tile), int(target_blocks)
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")

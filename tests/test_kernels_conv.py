@@ -50,7 +50,7 @@ def test_conv_fwd_silu_residual(backend, dt, cin, cout, k, stride, H, W, N):
     assert float(yb.buf[..., :16].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 17, 18, 19, 20, 21, 22, 23, 35, 36, 38, 39, 51, 52, 54, 55])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "dgrad")])
 def test_conv_every_tile_configuration(backend, tile, dt, mode):
     """Each workgroup tile (256x256 / 128x256 on 8 waves, 128x128 / 64x256 / 32x256 on 4) on a shape with
@@ -117,6 +117,11 @@ def test_conv_stats_dgrad_wgrad(backend, dt, cin, cout, k, stride, H, W, N):
     ops.conv2d_wgrad(xv, dyv, dw2, k, stride, oihw=True, workspace=ws)
     ops.conv2d_wgrad(xv, dyv, dw2, k, stride, oihw=True, workspace=ws)
     assert _rel(dw2.cpu(), 2 * w.grad) < TOL[dt]
+    # every wgrad workgroup tile
+    for t in (1, 2, 3, 4, 5, 6):
+        dw3 = torch.zeros(cout, k * k * cin, device=backend)
+        ops.conv2d_wgrad(xv, dyv, dw3, k, stride, workspace=ws, tile=t, target_blocks=8)
+        assert _rel(dw3.cpu(), ref_dw) < TOL[dt], "wgrad tile %d" % t
     # statistics spread over replicas
     s2 = torch.zeros(4 * cout, device=backend); q2 = torch.zeros(4 * cout, device=backend)
     ops.conv2d(xv, pack_conv_weight(w.detach(), code).to(backend), yv, k, stride, stats=(s2, q2))

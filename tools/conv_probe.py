@@ -32,13 +32,14 @@ SHAPES = [
 ]
 NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256", 6: "dma128x64",
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
-         22: "rs128x64", 23: "rs64x64"}
+         22: "rs128x64", 23: "rs64x64", 35: "d2-128x128", 36: "d2-64x256", 38: "d2-128x64", 39: "d2-64x64",
+         51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="")
-    ap.add_argument("--tiles", default="0,19,3,22,6,23,20,1")
+    ap.add_argument("--tiles", default="0,19,22,23,35,38,39,51,54,55")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
