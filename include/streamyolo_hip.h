@@ -97,6 +97,7 @@ typedef struct sy_wgrad_desc {
     void* workspace;                    /* optional fp32 scratch for split-K slabs (NULL: one split) */
     int64_t workspace_bytes;
     int32_t tile, target_blocks;        /* tuning knobs (0 = heuristic): workgroup tile, workgroups aimed for by split-K */
+    int64_t x_bytes, dy_bytes;          /* bytes addressable from x / dy (buffer bounds; 0 = unknown) */
 } sy_wgrad_desc;
 SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
 

@@ -30,6 +30,7 @@ struct WgradArgs {
     int M, K, slabs_per_split;
     int oihw;                   // 1: dW laid out [Cout][Cin][KH][KW] (the nn.Parameter layout), 0: [Cout][tap][Cin]
     int tile, target_blocks;    // tuning knobs: 0 = heuristics
+    unsigned x_extent, dy_extent; // bytes addressable from x / dy (0: 64-bit pointer loads)
     float* part;                // split > 1: partial tiles [splits][Cout][K] (packed layout), folded by wgrad_fold_kernel
     int splits;
 };
@@ -120,11 +121,33 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
 
     uint4 ra[UA][PPU], rb[UB][PPU];
 
+    // Loads go through bounds-checked buffer descriptors with 32-bit byte offsets: the per-load address math is a
+    // handful of 32-bit integer ops and out-of-image taps / ragged tails read zeros (offset 0xFFFFFFFF).
+    const bool use_buf = p.x_extent != 0 && p.dy_extent != 0;
+    const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
+    const sy_buffer bufdy = sy_make_buffer(p.dy, p.dy_extent);
+    int a_rel[UA];                         // element offset of (tap, ci) relative to the gather origin
+#pragma unroll
+    for (int i = 0; i < UA; ++i) a_rel[i] = (a_tap_h[i] * p.W + a_tap_w[i]) * p.ldx + a_ci[i];
     auto load_slab = [&]() {
 #pragma unroll
         for (int q = 0; q < PPU; ++q) {
             const bool m_ok = cur[q].m < p.M;
             const int hb = cur[q].ho * p.stride - p.pad, wb = cur[q].wo * p.stride - p.pad;
+            if (use_buf) {
+                const int xo = cur[q].n * (int)p.xbs + (hb * p.W + wb) * p.ldx;
+                const int yo = cur[q].n * (int)p.dybs + (cur[q].ho * p.Wo + cur[q].wo) * p.lddy;
+#pragma unroll
+                for (int i = 0; i < UA; ++i) {
+                    const int hi = hb + a_tap_h[i], wi = wb + a_tap_w[i];
+                    const bool ok = m_ok && a_ok[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                    ra[i][q] = sy_buffer_load16(bufx, ok ? (unsigned)((xo + a_rel[i]) * ESZ) : 0xFFFFFFFFu);
+                }
+#pragma unroll
+                for (int i = 0; i < UB; ++i)
+                    rb[i][q] = sy_buffer_load16(bufdy, (m_ok && b_ok[i]) ? (unsigned)((yo + b_co[i]) * ESZ) : 0xFFFFFFFFu);
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < UA; ++i) {
                 const int hi = hb + a_tap_h[i], wi = wb + a_tap_w[i];
@@ -340,6 +363,8 @@ extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
     a.M = d->N * d->Ho * d->Wo; a.K = d->KH * d->KW * d->Cin; a.slabs_per_split = 0;
     a.oihw = d->dw_oihw;
     a.tile = d->tile;
+    a.x_extent = (d->x_bytes > 0 && d->x_bytes < 0x7FFFFFF0LL) ? (unsigned)d->x_bytes : 0u;
+    a.dy_extent = (d->dy_bytes > 0 && d->dy_bytes < 0x7FFFFFF0LL) ? (unsigned)d->dy_bytes : 0u;
     a.target_blocks = d->target_blocks;
     a.part = (float*)d->workspace;
     a.splits = 1;

@@ -142,6 +142,7 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, t
     d.dtype = x.dtype
     d.dw_oihw = 1 if oihw else 0
     d.tile, d.target_blocks = int(tile), int(target_blocks)
+    d.x_bytes, d.dy_bytes = x.bytes_from_ptr(), dy.bytes_from_ptr()
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")
@@ -279,9 +280,10 @@ def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value,
 # ---------------------------------------------------------------------------------------------------
 TILE_RS = 16
 _TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging strategy codes, see include/streamyolo_hip.h
-    "wide": [19, 22, 23, 3, 6],         # rs128x128, rs128x64, rs64x64, dma128x128, dma128x64
-    "c64": [20, 23, 4, 7],              # rs64x256, rs64x64, dma64x256, dma64x64
-    "c32": [21, 23, 5],                 # rs32x256, rs64x64, dma32x256
+    # rs = register-staged, d2/d3 = 2-/3-deep LDS-DMA ring (codes: include/streamyolo_hip.h)
+    "wide": [19, 22, 23, 35, 38, 51, 54],   # rs128x128, rs128x64, rs64x64, d2-128x128, d2-128x64, d3-128x128, d3-128x64
+    "c64": [20, 23, 39, 55, 36],            # rs64x256, rs64x64, d2-64x64, d3-64x64, d2-64x256
+    "c32": [21, 23, 39],                    # rs32x256, rs64x64, d2-64x64
 }
 _tile_cache = {}
 
@@ -338,4 +340,44 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
         if dt < best_t:
             best, best_t = t, dt
     _tile_cache[key] = best
+    return best
+
+
+_WGRAD_CANDIDATES = [(0, 0), (1, 1024), (1, 2048), (2, 512), (2, 1024), (4, 1024), (6, 1024)]
+_wgrad_cache = {}
+
+
+def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace):
+    """(tile, target_blocks) of the fastest sy_conv2d_wgrad variant for this shape (cached), (0, 0) when off."""
+    if not autotune_enabled(device):
+        return (0, 0)
+    key = (dtype_code(dtype), N, H, W, Cin, Ho, Wo, Cout, k, stride, str(device))
+    hit = _wgrad_cache.get(key)
+    if hit is not None:
+        return hit
+    code = dtype_code(dtype)
+    x = View.alloc(N, H, W, Cin, code, device, zero=True)
+    dy = View.alloc(N, Ho, Wo, Cout, code, device, zero=True)
+    dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
+    best, best_t = (0, 0), float("inf")
+    for (t, tb) in _WGRAD_CANDIDATES:
+        if t in (1, 6) and Cout < 128:
+            continue
+        if t == 2 and Cout < 64:
+            continue
+        try:
+            conv2d_wgrad(x, dy, dw, k, stride, oihw=True, workspace=workspace, tile=t, target_blocks=tb)
+            torch.cuda.synchronize(device)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                conv2d_wgrad(x, dy, dw, k, stride, oihw=True, workspace=workspace, tile=t, target_blocks=tb)
+            e.record()
+            torch.cuda.synchronize(device)
+            dt = s.elapsed_time(e)
+        except _lib.HipLibraryError:
+            continue
+        if dt < best_t:
+            best, best_t = (t, tb), dt
+    _wgrad_cache[key] = best
     return best

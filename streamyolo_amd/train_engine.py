@@ -260,13 +260,20 @@ class TrainPlan:
         ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, bn.weight, op.bsum, dyraw,
                               self.gview[id(bn.weight)], self.gview[id(bn.bias)])
         w = op.mod.conv.weight
+        wt = op._tiles.get("wgrad")
+        if wt is None:
+            wt = ops.tuned_wgrad(op.x.dtype, op.x.N, op.x.H, op.x.W, op.x.C, op.y.H, op.y.W, op.y.C, op.k, op.stride,
+                                 self.device, self.wgrad_ws)
+            op._tiles["wgrad"] = wt
         if w.shape[1] == op.x.C:
-            ops.conv2d_wgrad(op.x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self.wgrad_ws)
+            ops.conv2d_wgrad(op.x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
+                             tile=wt[0], target_blocks=wt[1])
         else:                                                        # Focus stem: 12 real + 4 zero-padded channels
             if self.stem_scratch is None:
                 self.stem_scratch = torch.zeros((w.shape[0], op.x.C, op.k, op.k), dtype=torch.float32, device=self.device)
             self.stem_scratch.zero_()
-            ops.conv2d_wgrad(op.x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True, workspace=self.wgrad_ws)
+            ops.conv2d_wgrad(op.x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
+                             tile=wt[0], target_blocks=wt[1])
             self.gview[id(w)].add_(self.stem_scratch[:, :w.shape[1]])
         if op.need_dx:
             dx, acc = G.target(op.x)
