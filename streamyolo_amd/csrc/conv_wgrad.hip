@@ -284,19 +284,38 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
 }
 
 // dW (+)= sum over splits of the partial slabs; also applies the packed -> OIHW layout change.
+// A workgroup = (256 / ZL) consecutive elements x ZL split lanes: many-split folds of small weight tensors are
+// latency bound, so the split loop is spread over ZL threads per element and combined through LDS.
+template <int ZL>
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, float* dw, int Cout, int K, int Cin, int taps,
                                                          int splits, int oihw) {
+    constexpr int E = 256 / ZL;
+    __shared__ float red[256];
     const long long total = (long long)Cout * K;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int e = threadIdx.x % E, zl = threadIdx.x / E;
+    for (long long base = (long long)blockIdx.x * E; base < total; base += (long long)gridDim.x * E) {
+        const long long i = base + e;
         float v = 0.0f;
-        for (int z = 0; z < splits; ++z) v += part[(long long)z * total + i];
-        long long o = i;
-        if (oihw) {
-            const int co = (int)(i / K), k = (int)(i - (long long)co * K);
-            const int tap = k / Cin, ci = k - tap * Cin;
-            o = (long long)co * K + (long long)ci * taps + tap;
+        if (i < total)
+            for (int z = zl; z < splits; z += ZL) v += part[(long long)z * total + i];
+        if (ZL > 1) {
+            red[threadIdx.x] = v;
+            __syncthreads();
+            if (zl == 0) {
+#pragma unroll
+                for (int k = 1; k < ZL; ++k) v += red[k * E + e];
+            }
+            __syncthreads();
         }
-        dw[o] += v;
+        if (zl == 0 && i < total) {
+            long long o = i;
+            if (oihw) {
+                const int co = (int)(i / K), k = (int)(i - (long long)co * K);
+                const int tap = k / Cin, ci = k - tap * Cin;
+                o = (long long)co * K + (long long)ci * taps + tap;
+            }
+            dw[o] += v;
+        }
     }
 }
 
@@ -320,11 +339,17 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
     if (splits > 1) {
-        long long work = (long long)a.Cout * a.K;
-        int blocks = (int)((work + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        SY_LAUNCH(wgrad_fold_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K, a.Cin,
-                  a.KH * a.KW, splits, a.oihw);
+        const long long work = (long long)a.Cout * a.K;
+        auto grid_for = [&](int e) { long long b = (work + e - 1) / e; return (int)(b > 4096 ? 4096 : b); };
+        if (splits >= 64)
+            SY_LAUNCH(wgrad_fold_kernel<16>, dim3(grid_for(16)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
+                      a.Cin, a.KH * a.KW, splits, a.oihw);
+        else if (splits >= 16)
+            SY_LAUNCH(wgrad_fold_kernel<4>, dim3(grid_for(64)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
+                      a.Cin, a.KH * a.KW, splits, a.oihw);
+        else
+            SY_LAUNCH(wgrad_fold_kernel<1>, dim3(grid_for(256)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
+                      a.Cin, a.KH * a.KW, splits, a.oihw);
     }
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }

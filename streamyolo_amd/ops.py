@@ -34,13 +34,14 @@ def stream_of(t):
 
 class View:
     """NHWC activation view: a channel slice [c_off, c_off+C) of a dense [N,H,W,ld] buffer."""
-    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c_off", "bs_")
+    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c_off", "bs_", "root")
 
-    def __init__(self, buf, N, H, W, C_, ld=None, c_off=0, bs=None):
+    def __init__(self, buf, N, H, W, C_, ld=None, c_off=0, bs=None, root=None):
         self.buf, self.N, self.H, self.W, self.C = buf, N, H, W, C_
         self.ld = C_ if ld is None else ld
         self.c_off = c_off            # element offset of the view's first element inside `buf`
         self.bs_ = bs                 # explicit batch stride (elements) when images are not densely packed
+        self.root = root              # (full tensor, first image) when `buf` is a batch slice of a frame-pair buffer
 
     @staticmethod
     def alloc(N, H, W, C_, dtype, device, zero=False):
@@ -69,12 +70,18 @@ class View:
 
     def slice(self, c0, c):
         assert 0 <= c0 and c0 + c <= self.C
-        return View(self.buf, self.N, self.H, self.W, c, self.ld, self.c_off + c0, self.bs_)
+        return View(self.buf, self.N, self.H, self.W, c, self.ld, self.c_off + c0, self.bs_, self.root)
 
     def like(self, zero=False):
         """A fresh dense buffer with the same full layout (used for gradient mirrors)."""
         fn = torch.zeros_like if zero else torch.empty_like
         return View(fn(self.buf), self.N, self.H, self.W, self.C, self.ld, self.c_off)
+
+    def pair(self):
+        """Both frames of a frame-pair buffer as ONE view of 2N images (self must be the first frame's slice)."""
+        full, n0 = self.root
+        assert n0 == 0 and full.shape[0] == 2 * self.N
+        return View(full, 2 * self.N, self.H, self.W, self.C, self.ld, self.c_off, self.bs_)
 
     def nchw(self):
         """Float32 NCHW copy (tests / debugging only)."""

@@ -41,6 +41,13 @@ class _GradSpace:
         self.written = {}
 
     def view(self, v):
+        if v.root is not None:                       # frame-pair buffer: one mirror for both frames, sliced
+            full, n0 = v.root
+            gf = self.mirror.get(id(full))
+            if gf is None:
+                gf = torch.empty_like(full)
+                self.mirror[id(full)] = gf
+            return View(gf[n0:n0 + v.N], v.N, v.H, v.W, v.C, v.ld, v.c_off, v.bs_, root=(gf, n0))
         g = self.mirror.get(id(v.buf))
         if g is None:
             g = torch.empty_like(v.buf)
@@ -49,7 +56,8 @@ class _GradSpace:
 
     def target(self, v):
         """(grad view, accumulate?) for writing the gradient of activation view `v`."""
-        iv = self.written.setdefault(id(v.buf), [])          # sorted, merged, disjoint [a, b) channel ranges
+        key = (id(v.root[0]), v.root[1]) if v.root is not None else id(v.buf)
+        iv = self.written.setdefault(key, [])                # sorted, merged, disjoint [a, b) channel ranges
         c0, c1 = v.c_off, v.c_off + v.C
         assert v.bs_ is None and c1 <= v.ld
         gaps, pos = [], c0
@@ -80,6 +88,30 @@ class _GradSpace:
         return g, accumulate
 
 
+class _PairBuilder(_Builder):
+    """Allocates every buffer of the per-frame network for BOTH frames at once ([2N, H, W, C]): the first pass
+    hands out the first halves, the replay pass the second halves in the same order.  The backward pass can
+    then run the shared-weight dgrad / wgrad of a layer over both frames in ONE launch."""
+
+    def __init__(self, dtype, device):
+        super().__init__(dtype, device)
+        self.fulls, self.replay, self.paired = [], None, True
+
+    def buf(self, N, H, W, C):
+        if not self.paired:
+            return super().buf(N, H, W, C)
+        if self.replay is None:
+            full = torch.empty((2 * N, H, W, C), dtype=ops.TORCH_DTYPE[ops.dtype_code(self.dtype)], device=self.device)
+            self.fulls.append(full)
+            half = 0
+        else:
+            full = self.fulls[self.replay]
+            self.replay += 1
+            half = 1
+            assert tuple(full.shape) == (2 * N, H, W, C)
+        return View(full[half * N:(half + 1) * N], N, H, W, C, root=(full, half * N))
+
+
 class TrainPlan:
     BWD_COPIES = 16              # replicas of each BN-backward reduction (same reason)
     STAT_COPIES = 32             # replicas of each conv's sum / sum^2 arrays (atomic-contention control)
@@ -92,9 +124,13 @@ class TrainPlan:
         pafpn, head = model.backbone, model.head
         self.head = head
         self.cache = ParamCache(self.dtype, device)
-        b = _Builder(self.dtype, device)
+        b = _PairBuilder(self.dtype, device)
         self.f0_cur, cur = build_frame_net(b, pafpn, B, H, W)          # current frame  (dfp_pafpn.py:120-140)
+        self.n_frame_ops = len(b.ops)
+        b.replay = 0
         self.f0_sup, sup = build_frame_net(b, pafpn, B, H, W)          # support frame  (:145-165), same weights
+        assert len(b.ops) == 2 * self.n_frame_ops and b.replay == len(b.fulls)
+        b.paired = False
         fused = build_fuse_net(b, pafpn, cur, sup)                      # (:168-170)
         self.preds, self.A = build_head_net(b, head, fused)
         self.hw = [(f.H, f.W) for f in fused]
@@ -114,14 +150,22 @@ class TrainPlan:
         self.aff_arena = torch.empty(4 * tot_c, dtype=torch.float32, device=device)       # scale|shift|mean|invstd
         off = 0
         max_raw = 0
+        nf = self.n_frame_ops
+        for i in range(nf):                                      # raw conv outputs of a frame pair share one tensor
+            a, b2 = self.ops[i], self.ops[nf + i]
+            if a.kind == "conv":
+                full = torch.empty((2 * a.y.N, a.y.H, a.y.W, a.y.C), dtype=self.tdtype, device=device)
+                a.yraw = View(full[:a.y.N], a.y.N, a.y.H, a.y.W, a.y.C, root=(full, 0))
+                b2.yraw = View(full[a.y.N:], a.y.N, a.y.H, a.y.W, a.y.C, root=(full, a.y.N))
         for op in convs:
             C = op.y.C
             op.stat = (self.stat_arena[SC * off:SC * (off + C)],
                        self.stat_arena[SC * (tot_c + off):SC * (tot_c + off + C)])
             op.bsum = self.bwd_arena[2 * BC * off:2 * BC * (off + C)]
             op.aff = tuple(self.aff_arena[k * tot_c + off:k * tot_c + off + C] for k in range(4))
-            op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
-            max_raw = max(max_raw, op.y.pixels * C)
+            if op.yraw is None:
+                op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
+            max_raw = max(max_raw, 2 * op.y.pixels * C)
             off += C
         self.dyraw_scratch = torch.empty(max_raw, dtype=self.tdtype, device=device)
         self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=device)
@@ -209,17 +253,23 @@ class TrainPlan:
         # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels
         self.dpad[..., 0:5] = d_raw[..., 0:5]
         self.dpad[..., 8:8 + nc] = d_raw[..., 5:]
-        for op in reversed(self.ops):
-            k = op.kind
-            if k == "pred":
+        nf = self.n_frame_ops
+        for op in reversed(self.ops[2 * nf:]):                   # head, then DFP fusion
+            if op.kind == "pred":
                 self._pred_backward(op, d_raw)
-            elif k == "conv":
+            else:
                 self._conv_backward(op)
-            elif k == "resize":
-                dsrc, acc = G.target(op.src)
-                ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
-            elif k == "spp":
-                ops.spp_pool_bwd(G.view(op.v), op.argmax)
+        for i in reversed(range(nf)):                            # the two frames' networks, layer by layer together
+            a, b2 = self.ops[i], self.ops[nf + i]
+            if a.kind == "conv":
+                self._conv_pair_backward(a, b2)
+            else:
+                for op in (b2, a):
+                    if op.kind == "resize":
+                        dsrc, acc = G.target(op.src)
+                        ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
+                    elif op.kind == "spp":
+                        ops.spp_pool_bwd(G.view(op.v), op.argmax)
         return self.arena
 
     def _pred_backward(self, op, d_raw):
@@ -246,7 +296,9 @@ class TrainPlan:
         self.gview[id(op.obj_mod.bias)].add_(db[4:5])
         self.gview[id(op.cls_mod.bias)].add_(db[5:])
 
-    def _conv_backward(self, op):
+    def _bn_backward(self, op, dyraw):
+        """Residual fan-in + BatchNorm/SiLU backward of one BaseConv call: fills `dyraw` (grad of the raw conv
+        output) and accumulates dgamma / dbeta."""
         G = self.grads
         bn = op.mod.bn
         dY = G.view(op.y)
@@ -255,26 +307,55 @@ class TrainPlan:
             ops.view_copy(dY, dres, accumulate=acc)
         scale, shift, mean, invstd = op.aff
         ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
-        C = op.y.C
-        dyraw = View(self.dyraw_scratch[:op.y.pixels * C].view(op.y.N, op.y.H, op.y.W, C), op.y.N, op.y.H, op.y.W, C)
         ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, bn.weight, op.bsum, dyraw,
                               self.gview[id(bn.weight)], self.gview[id(bn.bias)])
+
+    def _wgrad(self, op, x, dyraw):
         w = op.mod.conv.weight
-        wt = op._tiles.get("wgrad")
+        key = "wgrad%d" % x.N
+        wt = op._tiles.get(key)
         if wt is None:
-            wt = ops.tuned_wgrad(op.x.dtype, op.x.N, op.x.H, op.x.W, op.x.C, op.y.H, op.y.W, op.y.C, op.k, op.stride,
+            wt = ops.tuned_wgrad(x.dtype, x.N, x.H, x.W, x.C, dyraw.H, dyraw.W, dyraw.C, op.k, op.stride,
                                  self.device, self.wgrad_ws)
-            op._tiles["wgrad"] = wt
-        if w.shape[1] == op.x.C:
-            ops.conv2d_wgrad(op.x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
+            op._tiles[key] = wt
+        if w.shape[1] == x.C:
+            ops.conv2d_wgrad(x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
                              tile=wt[0], target_blocks=wt[1])
         else:                                                        # Focus stem: 12 real + 4 zero-padded channels
             if self.stem_scratch is None:
-                self.stem_scratch = torch.zeros((w.shape[0], op.x.C, op.k, op.k), dtype=torch.float32, device=self.device)
+                self.stem_scratch = torch.zeros((w.shape[0], x.C, op.k, op.k), dtype=torch.float32, device=self.device)
             self.stem_scratch.zero_()
-            ops.conv2d_wgrad(op.x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
+            ops.conv2d_wgrad(x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
                              tile=wt[0], target_blocks=wt[1])
             self.gview[id(w)].add_(self.stem_scratch[:, :w.shape[1]])
+
+    def _conv_pair_backward(self, a, b2):
+        """Layer i of the current-frame and support-frame networks together: per-frame BN backward (separate
+        statistics), then ONE wgrad and ONE dgrad launch over the 2B images (the weights are shared)."""
+        G = self.grads
+        N, H, W, C = a.y.N, a.y.H, a.y.W, a.y.C
+        full = self.dyraw_scratch[:2 * N * H * W * C].view(2 * N, H, W, C)
+        self._bn_backward(b2, View(full[N:], N, H, W, C))
+        self._bn_backward(a, View(full[:N], N, H, W, C))
+        dy2 = View(full, 2 * N, H, W, C)
+        self._wgrad(a, a.x.pair(), dy2)
+        if a.need_dx:
+            dxa, acca = G.target(a.x)
+            dxb, accb = G.target(b2.x)
+            assert acca == accb and dxa.root[0] is dxb.root[0]
+            t = a._tiles.get("dgrad2")
+            if t is None:
+                t = ops.tuned_tile(CONV_DGRAD, dy2.dtype, 2 * N, H, W, C, a.x.C, a.k, a.stride, self.device)
+                a._tiles["dgrad2"] = t
+            ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
+                       mode=CONV_DGRAD, accumulate=acca, tile=t)
+
+    def _conv_backward(self, op):
+        G = self.grads
+        C = op.y.C
+        dyraw = View(self.dyraw_scratch[:op.y.pixels * C].view(op.y.N, op.y.H, op.y.W, C), op.y.N, op.y.H, op.y.W, C)
+        self._bn_backward(op, dyraw)
+        self._wgrad(op, op.x, dyraw)
         if op.need_dx:
             dx, acc = G.target(op.x)
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,

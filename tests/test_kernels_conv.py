@@ -153,3 +153,18 @@ def test_head_prediction_epilogues(backend):
     got = out[:, A0:A0 + H * W].cpu()
     assert _rel(got, ref) < 1e-5
     assert float(out[:, :A0].abs().max()) == 0.0 and float(out[:, A0 + H * W:].abs().max()) == 0.0
+
+
+def test_wgrad_many_splits_fold(backend):
+    """>= 64 pixel splits: the ZL=16 fold path (small weight tensor, long pixel axis)."""
+    g = torch.Generator().manual_seed(5)
+    N, cin, cout, H, W = 1, 8, 8, 136, 128
+    x = torch.randn(N, cin, H, W, generator=g).requires_grad_(False)
+    dy = torch.randn(N, cout, H, W, generator=g)
+    ref = torch.einsum("nchw,ndhw->dc", x, dy)                       # 1x1 conv weight gradient [cout, cin]
+    xv = View.alloc(N, H, W, cin, "fp32", backend); xv.set_nchw(x.to(backend))
+    dv = View.alloc(N, H, W, cout, "fp32", backend); dv.set_nchw(dy.to(backend))
+    ws = torch.empty(1 << 22, dtype=torch.uint8, device=backend)
+    dw = torch.zeros(cout, cin, device=backend)
+    ops.conv2d_wgrad(xv, dv, dw, 1, 1, workspace=ws, tile=3, target_blocks=4096)
+    assert _rel(dw.cpu(), ref) < 1e-4
