@@ -42,7 +42,8 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
        SY_TILE_128x64 = 6, SY_TILE_64x64 = 7,
        SY_TILE_RS = 16,   /* add to a tile code: register-staged variant instead of the 4-deep LDS-DMA ring */
        SY_TILE_DMA2 = 32, /* add: 2-deep LDS-DMA ring */
-       SY_TILE_DMA3 = 48  /* add: 3-deep LDS-DMA ring */ };
+       SY_TILE_DMA3 = 48, /* add: 3-deep LDS-DMA ring */
+       SY_TILE_WR = 80    /* add: register-staged pixels + fragment-packed weights loaded straight into VGPRs */ };
 
 /* gather modes of sy_conv2d */
 enum {
@@ -76,6 +77,8 @@ typedef struct sy_conv_desc {
     int32_t stat_copies;                /* stat arrays hold this many replicas [copies][Cout] (>=1) */
     int32_t tile;                       /* SY_TILE_AUTO or a forced workgroup tile (channels x pixels) */
     int64_t x_bytes, w_bytes;           /* bytes addressable from x / w (buffer bounds of the fast gather; 0 = unknown) */
+    const void* wfrag;                  /* optional: weights re-packed in MFMA-fragment order (SY_TILE_WR variants) */
+    int64_t wfrag_bytes;
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.

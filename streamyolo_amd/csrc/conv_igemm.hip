@@ -31,6 +31,8 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.stat_copies = d->stat_copies > 0 ? d->stat_copies : 1;
     a.x_extent = (d->x_bytes > 0 && d->x_bytes < 0xFFFFFFF0LL) ? (unsigned)d->x_bytes : 0u;
     a.w_extent = (d->w_bytes > 0 && d->w_bytes < 0xFFFFFFF0LL) ? (unsigned)d->w_bytes : 0u;
+    a.wfrag = (const unsigned char*)d->wfrag;
+    a.wfrag_extent = (d->wfrag != nullptr && d->wfrag_bytes > 0 && d->wfrag_bytes < 0xFFFFFFF0LL) ? (unsigned)d->wfrag_bytes : 0u;
     a.tile = d->tile & 0xff;
     a.ablate = (d->tile >> 8) & 3;
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;

@@ -55,6 +55,8 @@ struct ConvArgs {
     int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
     int tile;                   // 0 = heuristic, else a forced tile configuration (tests / tuning)
     unsigned x_extent, w_extent; // bytes addressable from x / w (FAST loader's buffer bounds)
+    const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
+    unsigned wfrag_extent;
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads
 };
 
@@ -68,8 +70,9 @@ static __device__ uint4 g_zero16[4] = {};  // DMA generic loader: source of ever
 template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
     typedef typename T::elem elem;
-    constexpr int RS = (STG == 1) ? 1 : 0;
-    constexpr int kStages = (STG == 1) ? 1 : (STG == 0 ? 4 : STG);
+    constexpr int RS = (STG == 1 || STG == 5) ? 1 : 0;
+    constexpr int WR = (STG == 5) ? 1 : 0;          // weights: fragment-packed, global -> VGPR, never in LDS
+    constexpr int kStages = RS ? 1 : (STG == 0 ? 4 : STG);
     constexpr int kThreads = WC * WP * 64;       // 4 or 8 waves
     constexpr int RPI = kThreads / 4;            // rows staged per sweep of the workgroup (one 16-byte chunk per lane)
     constexpr int EPC = T::kEPC;                 // elements per 16-byte chunk
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue before every ds_read — guide §5)
     SY_DYN_SMEM(smem);
     unsigned char* const sW = smem;
-    unsigned char* const sX = smem + (RS ? CT * kPitchRS : kStages * CT * kRowB);
+    unsigned char* const sX = smem + (WR ? 0 : (RS ? CT * kPitchRS : kStages * CT * kRowB));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -196,7 +199,62 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
             ++f_t;
             if (++f_kw == p.KW) { f_kw = 0; if (++f_kh == p.KH) { f_kh = 0; f_t = 0; f_c += BK; } }
         };
-        if constexpr (RS) {
+        if constexpr (WR) {
+            // ---- weights straight to VGPRs.  The host packs them in MFMA-fragment order along the kernel's own
+            //      K traversal, so one wave instruction reads 1 KiB contiguous (perfectly coalesced, L2 resident)
+            //      and the weight operand costs no LDS write, no LDS read and no barrier traffic at all.
+            const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
+            const int ntile32 = (p.Cout + 31) / 32;
+            unsigned foff[TC];
+#pragma unroll
+            for (int t = 0; t < TC; ++t) {
+                const int ct = (int)blockIdx.x * (CT / 32) + wc * TC + t;
+                foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * nslab) * 128 + lane) * 16) : 0xFFFFFFFFu;
+            }
+            uint4 fa[TC][2], fn[TC][2], rx[XCH];
+            int seq = 0;
+            auto load_slab = [&]() {
+                slab_offsets();
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                        fn[t][g] = sy_buffer_load16(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + (unsigned)((seq * 2 + g) * 1024));
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) rx[i] = sy_buffer_load16(bufx, ((xmask[i] >> f_t) & 1u) ? xoff[i] + s_x : 0xFFFFFFFFu);
+                advance();
+                ++seq;
+            };
+            auto store_slab = [&]() {
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) *reinterpret_cast<uint4*>(sX + (row0 + i * RPI) * kPitchRS + kc * 16) = rx[i];
+#pragma unroll
+                for (int t = 0; t < TC; ++t) { fa[t][0] = fn[t][0]; fa[t][1] = fn[t][1]; }
+            };
+            load_slab();
+            store_slab();
+            __syncthreads();
+            for (int s = 0; s < nslab; ++s) {
+                const bool more = (s + 1 < nslab);
+                if (more) load_slab();
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    uint4 b[TP];
+#pragma unroll
+                    for (int u = 0; u < TP; ++u)
+                        b[u] = *reinterpret_cast<const uint4*>(sX + ((wp * TP + u) * 32 + l31) * kPitchRS + (g * 2 + half) * 16);
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+#pragma unroll
+                        for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), fa[t][g], b[u], acc[t][u]);
+                }
+                __syncthreads();
+                if (more) {
+                    store_slab();
+                    __syncthreads();
+                }
+            }
+        } else if constexpr (RS) {
             uint4 rw[WCH], rx[XCH];
             auto load_slab = [&]() {
                 slab_offsets();
@@ -516,11 +574,13 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
 
 template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
 int launch_one(const ConvArgs& a, void* stream) {
-    constexpr int RS = (STG == 1) ? 1 : 0;
-    constexpr int kStages = (STG == 1) ? 1 : (STG == 0 ? 4 : STG);
+    constexpr int RS = (STG == 1 || STG == 5) ? 1 : 0;
+    constexpr int kStages = RS ? 1 : (STG == 0 ? 4 : STG);
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
     dim3 grid((a.Cout + CT - 1) / CT, (a.M + PT - 1) / PT, 1);
-    constexpr size_t smem = RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB;
+    // STG 5 keeps only the pixel tile in LDS (the BN-statistics scratch [WP][CT][2] floats aliases it after the K loop)
+    constexpr size_t smem = (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
+                                       : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
 #ifndef SY_EMU
     static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
     if (!attr_done) {
@@ -538,7 +598,12 @@ template <typename T, int WC, int WP, int TC, int TP, int STG = 0>
 int launch_cfg(const ConvArgs& a, void* stream) {
     // FAST loader preconditions: whole slabs per tap, 32-bit addressable operands, taps fit the validity mask
     const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32;
-    return fast ? launch_one<T, WC, WP, TC, TP, STG, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, STG, 0>(a, stream);
+    if constexpr (STG == 5) {       // fragment-packed weights exist only for the FAST traversal; else plain register staging
+        if (fast && a.wfrag != nullptr && a.wfrag_extent != 0) return launch_one<T, WC, WP, TC, TP, 5, 1>(a, stream);
+        return fast ? launch_one<T, WC, WP, TC, TP, 1, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, 1, 0>(a, stream);
+    } else {
+        return fast ? launch_one<T, WC, WP, TC, TP, STG, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, STG, 0>(a, stream);
+    }
 }
 
 template <typename T>
@@ -564,6 +629,11 @@ int launch_typed(const ConvArgs& a, void* stream) {
         case 48 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 3>(a, stream);
         case 48 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 3>(a, stream);
         case 48 + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 3>(a, stream);
+        case 80 + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 5>(a, stream);       // weights in registers
+        case 80 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 5>(a, stream);
+        case 80 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 5>(a, stream);
+        case 80 + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 5>(a, stream);
+        case 80 + SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2, 5>(a, stream);
         case SY_TILE_RS + SY_TILE_256x256: return launch_cfg<T, 2, 4, 4, 2, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_128x256: return launch_cfg<T, 1, 8, 4, 1, 1>(a, stream);
         case SY_TILE_RS + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 1>(a, stream);

@@ -22,7 +22,7 @@ import torch
 
 from . import ops
 from .ops import View, EPI_SILU, EPI_LINEAR, EPI_SIGMOID, EPI_DECODE, CONV_DGRAD
-from .model.packing import pack_conv_weight, fold_bn
+from .model.packing import pack_conv_weight, pack_conv_weight_frag, fold_bn
 
 
 # ------------------------------------------------------------------------------------------------
@@ -228,6 +228,16 @@ class ParamCache:
             self.entries[key] = e
         return e[1]
 
+    def conv_weight_frag(self, mod, transpose=False):
+        """Fragment-ordered copy of the packed weights for the SY_TILE_WR kernels (None if not applicable)."""
+        key = ("wf", id(mod), transpose)
+        ver = self._ver(mod.conv.weight)
+        e = self.entries.get(key)
+        if e is None or e[0] != ver:
+            e = (ver, pack_conv_weight_frag(self.conv_weight(mod, transpose), mod.ksize))
+            self.entries[key] = e
+        return e[1]
+
     def pred(self, op):
         """Packed (reg|obj) [5 -> rows, Cin] and cls [nc, Cin] weights + fp32 biases."""
         key = ("pred", id(op.cls_mod))
@@ -295,7 +305,9 @@ class InferencePlan:
     def _run_op(self, op):
         if op.kind == "conv":
             w, scale, shift = self.cache.conv_eval(op.mod)
-            ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU, tile=op.tile("fwd"))
+            t = op.tile("fwd")
+            ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU, tile=t,
+                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
         elif op.kind == "resize":
             ops.resize_nearest(op.src, op.dst)
         elif op.kind == "spp":

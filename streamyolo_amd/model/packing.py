@@ -29,3 +29,23 @@ def fold_bn(gamma, beta, mean, var, eps):
     scale = gamma.detach().float() / torch.sqrt(var.detach().float() + eps)
     shift = beta.detach().float() - mean.detach().float() * scale
     return scale.contiguous(), shift.contiguous()
+
+
+def pack_conv_weight_frag(packed, ksize):
+    """[Cout, k*k*Cin] K-contiguous packed weights -> MFMA-fragment order along the FAST kernel's K
+    traversal (channel slab outer, taps inner): [Cout/32][Cin/BK][taps][g][half][32 rows][EPC], i.e. one
+    wave instruction of the SY_TILE_WR kernels reads 1 KiB contiguous.  Returns None when Cin is not a
+    whole number of 64-byte slabs (those layers use the generic loader)."""
+    cout, K = packed.shape
+    taps = ksize * ksize
+    cin = K // taps
+    epc = 16 // packed.element_size()
+    bk = 4 * epc
+    if cin % bk != 0:
+        return None
+    pad = (-cout) % 32
+    if pad:
+        packed = torch.cat([packed, packed.new_zeros(pad, K)], 0)
+    ct = packed.shape[0] // 32
+    v = packed.view(ct, 32, taps, cin // bk, 2, 2, epc)          # [ct, r, t, c, g, half, e]
+    return v.permute(0, 3, 2, 4, 5, 1, 6).contiguous().view(-1)   # [ct, c, t, g, half, r, e]

@@ -103,7 +103,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0):
+           cout=None, tile=0, wfrag=None):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -133,6 +133,8 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.tile = int(tile)
     d.x_bytes = x.bytes_from_ptr()
     d.w_bytes = w.numel() * w.element_size()
+    if wfrag is not None:
+        d.wfrag, d.wfrag_bytes = wfrag.data_ptr(), wfrag.numel() * wfrag.element_size()
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
@@ -286,11 +288,13 @@ def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value,
 # per-shape kernel-variant selection for sy_conv2d (measured once per shape on the device, cached)
 # ---------------------------------------------------------------------------------------------------
 TILE_RS = 16
+TILE_WR = 80           # codes >= 80: fragment-packed weights straight to VGPRs (need the `wfrag` operand)
 _TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging strategy codes, see include/streamyolo_hip.h
     # rs = register-staged, d2/d3 = 2-/3-deep LDS-DMA ring (codes: include/streamyolo_hip.h)
-    "wide": [19, 22, 23, 35, 38, 51, 54],   # rs128x128, rs128x64, rs64x64, d2-128x128, d2-128x64, d3-128x128, d3-128x64
-    "c64": [20, 23, 39, 55, 36],            # rs64x256, rs64x64, d2-64x64, d3-64x64, d2-64x256
-    "c32": [21, 23, 39],                    # rs32x256, rs64x64, d2-64x64
+    # wr = register-staged pixels + fragment-packed weights straight to VGPRs
+    "wide": [19, 22, 23, 35, 38, 51, 54, 83, 86, 87],
+    "c64": [20, 23, 39, 55, 36, 84, 87],
+    "c32": [21, 23, 39, 85, 87],
 }
 _tile_cache = {}
 
@@ -323,15 +327,20 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     scale = torch.ones(Cout, device=device)
     shift = torch.zeros(Cout, device=device)
     stats = (torch.zeros(32 * Cout, device=device), torch.zeros(32 * Cout, device=device)) if with_stats else None
+    from .model.packing import pack_conv_weight_frag
+    wf = pack_conv_weight_frag(w, k)
     cands = _TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide"]
     best, best_t = 0, float("inf")
     for t in cands:
+        if t >= TILE_WR and wf is None:
+            continue
+
         def run():
             if with_stats:
-                conv2d(x, w, y, k, stride, stats=stats, mode=mode, tile=t)
+                conv2d(x, w, y, k, stride, stats=stats, mode=mode, tile=t, wfrag=wf)
             else:
                 conv2d(x, w, y, k, stride, scale, shift, epilogue=EPI_SILU if mode == CONV_FWD else EPI_LINEAR,
-                       mode=mode, tile=t)
+                       mode=mode, tile=t, wfrag=wf)
         try:
             run()
             torch.cuda.synchronize(device)

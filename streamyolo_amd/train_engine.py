@@ -201,7 +201,9 @@ class TrainPlan:
             if k == "conv":
                 bn = op.mod.bn
                 w = self.cache.conv_weight(op.mod)
-                ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=op.tile("fwd_stats"))
+                t = op.tile("fwd_stats")
+                ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
+                           wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
                 scale, shift, mean, invstd = op.aff
                 mom = bn.momentum if bn.momentum is not None else 0.1
                 ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
@@ -348,7 +350,8 @@ class TrainPlan:
                 t = ops.tuned_tile(CONV_DGRAD, dy2.dtype, 2 * N, H, W, C, a.x.C, a.k, a.stride, self.device)
                 a._tiles["dgrad2"] = t
             ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
-                       mode=CONV_DGRAD, accumulate=acca, tile=t)
+                       mode=CONV_DGRAD, accumulate=acca, tile=t,
+                       wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
 
     def _conv_backward(self, op):
         G = self.grads
@@ -358,8 +361,10 @@ class TrainPlan:
         self._wgrad(op, op.x, dyraw)
         if op.need_dx:
             dx, acc = G.target(op.x)
+            t = op.tile("dgrad")
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
-                       mode=CONV_DGRAD, accumulate=acc, tile=op.tile("dgrad"))
+                       mode=CONV_DGRAD, accumulate=acc, tile=t,
+                       wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None)
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, x, targets, iters=2):

@@ -5,7 +5,7 @@ import torch.nn.functional as F
 
 from streamyolo_amd import ops
 from streamyolo_amd.ops import View
-from streamyolo_amd.model.packing import pack_conv_weight
+from streamyolo_amd.model.packing import pack_conv_weight, pack_conv_weight_frag
 
 TOL = {"bf16": 2e-2, "fp16": 3e-3, "fp32": 2e-5}
 
@@ -50,13 +50,13 @@ def test_conv_fwd_silu_residual(backend, dt, cin, cout, k, stride, H, W, N):
     assert float(yb.buf[..., :16].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 17, 18, 19, 20, 21, 22, 23, 35, 36, 38, 39, 51, 52, 54, 55])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 17, 18, 19, 20, 21, 22, 23, 35, 36, 38, 39, 51, 52, 54, 55, 83, 84, 85, 86, 87])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "dgrad")])
 def test_conv_every_tile_configuration(backend, tile, dt, mode):
     """Each workgroup tile (256x256 / 128x256 on 8 waves, 128x128 / 64x256 / 32x256 on 4) on a shape with
     ragged channel and pixel edges, forward (with BN statistics) and data-gradient gathers."""
     g = torch.Generator().manual_seed(tile)
-    N, cin, cout, k, stride, H, W = 1, 24, 264, 3, 2, 21, 27
+    N, cin, cout, k, stride, H, W = 1, (24 if tile < 80 else 32), (264 if tile < 80 else 288), 3, 2, 21, 27
     code = ops.dtype_code(dt)
     x = _q(torch.randn(N, cin, H, W, generator=g), dt).requires_grad_(True)
     w = _q(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, dt)
@@ -66,7 +66,9 @@ def test_conv_every_tile_configuration(backend, tile, dt, mode):
     if mode == "fwd":
         yv = View.alloc(N, Ho, Wo, cout, dt, backend)
         ssum = torch.zeros(2 * cout, device=backend); ssq = torch.zeros(2 * cout, device=backend)
-        ops.conv2d(xv, pack_conv_weight(w, code).to(backend), yv, k, stride, stats=(ssum, ssq), tile=tile)
+        wp = pack_conv_weight(w, code)
+        wf = pack_conv_weight_frag(wp, k)
+        ops.conv2d(xv, wp.to(backend), yv, k, stride, stats=(ssum, ssq), tile=tile, wfrag=None if wf is None else wf.to(backend))
         assert _rel(yv.nchw().cpu(), y.detach()) < TOL[dt]
         assert _rel(ssq.view(2, cout).sum(0).cpu(), (y.detach() ** 2).sum((0, 2, 3))) < 1e-3
     else:
@@ -74,7 +76,9 @@ def test_conv_every_tile_configuration(backend, tile, dt, mode):
         y.backward(dy)
         dyv = View.alloc(N, Ho, Wo, cout, dt, backend); dyv.set_nchw(dy.to(backend))
         dxv = View.alloc(N, H, W, cin, dt, backend, zero=True)
-        ops.conv2d(dyv, pack_conv_weight(w, code, transpose=True).to(backend), dxv, k, stride, mode=ops.CONV_DGRAD, tile=tile)
+        wt = pack_conv_weight(w, code, transpose=True)
+        wf = pack_conv_weight_frag(wt, k)
+        ops.conv2d(dyv, wt.to(backend), dxv, k, stride, mode=ops.CONV_DGRAD, tile=tile, wfrag=None if wf is None else wf.to(backend))
         assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
 
 

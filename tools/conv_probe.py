@@ -33,13 +33,14 @@ SHAPES = [
 NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256", 6: "dma128x64",
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
          22: "rs128x64", 23: "rs64x64", 35: "d2-128x128", 36: "d2-64x256", 38: "d2-128x64", 39: "d2-64x64",
-         51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64"}
+         51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64",
+         83: "wr128x128", 84: "wr64x256", 85: "wr32x256", 86: "wr128x64", 87: "wr64x64"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="")
-    ap.add_argument("--tiles", default="0,19,22,23,35,38,39,51,54,55")
+    ap.add_argument("--tiles", default="0,19,22,23,38,51,83,86,87,84")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
@@ -57,6 +58,8 @@ def main():
         x.buf.copy_(torch.randn(x.buf.shape, generator=g).to(x.buf.dtype))
         w = (torch.randn(cout, k * k * cin, generator=g) / (cin * k * k) ** 0.5).to(x.buf.dtype).to(dev)
         y = View.alloc(N, ops.conv_out_size(H, k, st), ops.conv_out_size(W, k, st), cout, a.dtype, dev)
+        from streamyolo_amd.model.packing import pack_conv_weight_frag
+        wf = pack_conv_weight_frag(w, k)
         scale = torch.ones(cout, device=dev)
         shift = torch.zeros(cout, device=dev)
         flops = 2.0 * cin * cout * k * k * y.pixels
@@ -67,13 +70,13 @@ def main():
                 continue
             try:
                 for _ in range(2):
-                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t)
+                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t, wfrag=wf)
                 torch.cuda.synchronize()
                 ts = []
                 for _ in range(a.reps):
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
-                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t)
+                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t, wfrag=wf)
                     e.record()
                     torch.cuda.synchronize()
                     ts.append(s.elapsed_time(e))
