@@ -39,7 +39,7 @@ enum {
 
 /* workgroup tiles of sy_conv2d (output channels x output pixels) */
 enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x128 = 3, SY_TILE_64x256 = 4, SY_TILE_32x256 = 5,
-       SY_TILE_128x64 = 6, SY_TILE_64x64 = 7,
+       SY_TILE_128x64 = 6, SY_TILE_64x64 = 7, SY_TILE_256x64 = 8, SY_TILE_256x128 = 9,
        SY_TILE_RS = 16,   /* add to a tile code: register-staged variant instead of the 4-deep LDS-DMA ring */
        SY_TILE_DMA2 = 32, /* add: 2-deep LDS-DMA ring */
        SY_TILE_DMA3 = 48, /* add: 3-deep LDS-DMA ring */
@@ -139,6 +139,21 @@ SY_API int sy_bn_finalize(const float* sum, const float* sqsum, int C, int copie
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* scale, float* shift, float* mean, float* invstd,
                    void* stream);
+/* Running-statistics update of MANY BatchNorm modules in one launch, from the same replica arrays sy_bn_finalize
+ * folds (pass running_mean = NULL there).  Entry i describes one nn.BatchNorm2d and the 1 or 2 calls it received
+ * this step IN CALL ORDER (the backbone / neck modules are called once per frame, current frame first —
+ * exps/model/dfp_pafpn.py:120-165): for each call, running = (1 - momentum) * running + momentum * batch_stat
+ * with the unbiased variance, exactly torch.nn.functional.batch_norm(training=True).  `entries` is DEVICE memory. */
+typedef struct sy_bn_running_entry {
+    float* running_mean;
+    float* running_var;
+    const float* sum[2];        /* [copies][C] replica arrays of call 0 / call 1 (call 1 NULL when calls == 1) */
+    const float* sqsum[2];
+    double count[2];            /* elements per channel of each call */
+    int32_t C, copies, calls;
+    float momentum;
+} sy_bn_running_entry;
+SY_API int sy_bn_running_update(const sy_bn_running_entry* entries, int n_entries, int max_C, void* stream);
 /* a = silu(scale*y + shift) [+ res], y raw conv output; views as in sy_conv2d. */
 SY_API int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res,
                      int ldr, void* out, int ldo, int64_t pixels, int C, int dtype, void* stream);

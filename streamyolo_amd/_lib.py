@@ -39,6 +39,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class BnRunningEntry(C.Structure):
+    """sy_bn_running_entry (include/streamyolo_hip.h)."""
+    _fields_ = [("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("sum", C.c_void_p * 2),
+                ("sqsum", C.c_void_p * 2), ("count", C.c_double * 2), ("C", C.c_int32), ("copies", C.c_int32),
+                ("calls", C.c_int32), ("momentum", C.c_float)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
@@ -64,6 +71,7 @@ SIGNATURES = {
     "sy_spp_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "sy_postprocess_workspace_bytes": (_L, [_I, _I]),
     "sy_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
+    "sy_bn_running_update": (_I, [_P, _I, _I, _P]),
     "sy_bn_finalize": (_I, [_P, _P, _I, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sy_bn_silu_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P]),

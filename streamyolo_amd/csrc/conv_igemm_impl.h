@@ -629,6 +629,9 @@ int launch_typed(const ConvArgs& a, void* stream) {
         case 48 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 3>(a, stream);
         case 48 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 3>(a, stream);
         case 48 + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 3>(a, stream);
+        case SY_TILE_RS + SY_TILE_256x64: return launch_cfg<T, 4, 1, 2, 2, 1>(a, stream);
+        case 80 + SY_TILE_256x64: return launch_cfg<T, 4, 1, 2, 2, 5>(a, stream);         // 4 waves x (64 ch x 64 px), shared pixel tile
+        case 80 + SY_TILE_256x128: return launch_cfg<T, 4, 1, 2, 4, 5>(a, stream);        // 4 waves x (64 ch x 128 px)
         case 80 + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 5>(a, stream);       // weights in registers
         case 80 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 5>(a, stream);
         case 80 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 5>(a, stream);

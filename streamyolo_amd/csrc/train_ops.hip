@@ -155,6 +155,39 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, c
     }
 }
 
+// Running statistics of every BatchNorm of the step in one launch (sy_bn_running_update): workgroup = (entry,
+// 32-channel block); the replica fold repeats bn_finalize_kernel's order so both see the same batch statistics.
+__global__ __launch_bounds__(kBlock) void bn_running_update_kernel(const sy_bn_running_entry* entries) {
+    __shared__ float s_s[8][32], s_q[8][32];
+    const sy_bn_running_entry e = entries[blockIdx.x];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.y * 32 + cl;
+    if ((int)blockIdx.y * 32 >= e.C) return;                     // uniform for the workgroup
+    float rm = 0.0f, rv = 0.0f;
+    if (rg == 0 && c < e.C) { rm = e.running_mean[c]; rv = e.running_var[c]; }
+    for (int j = 0; j < e.calls; ++j) {
+        float s = 0.0f, q = 0.0f;
+        if (c < e.C)
+            for (int k = rg; k < e.copies; k += 8) { s += e.sum[j][(long long)k * e.C + c]; q += e.sqsum[j][(long long)k * e.C + c]; }
+        s_s[rg][cl] = s;
+        s_q[rg][cl] = q;
+        __syncthreads();
+        if (rg == 0 && c < e.C) {
+            double ds = 0.0, dq = 0.0;
+            for (int k = 0; k < 8; ++k) { ds += (double)s_s[k][cl]; dq += (double)s_q[k][cl]; }
+            const double count = e.count[j];
+            const double mean = ds / count;
+            double var = dq / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            rm = (1.0f - e.momentum) * rm + e.momentum * (float)mean;
+            rv = (1.0f - e.momentum) * rv + e.momentum * (float)unbiased;
+        }
+        __syncthreads();
+    }
+    if (rg == 0 && c < e.C) { e.running_mean[c] = rm; e.running_var[c] = rv; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T::elem* y, int ldy, const float* scale,
                                                                const float* shift, const typename T::elem* res, int ldr,
@@ -330,6 +363,12 @@ extern "C" int sy_bn_finalize(const float* sum, const float* sqsum, int C, int c
     if ((running_mean == nullptr) != (running_var == nullptr)) return SY_ERR_ARG;
     SY_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, sum, sqsum, C, copies, count,
               gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+extern "C" int sy_bn_running_update(const sy_bn_running_entry* entries, int n_entries, int max_C, void* stream) {
+    if (entries == nullptr || n_entries <= 0 || max_C <= 0) return SY_ERR_ARG;
+    SY_LAUNCH(bn_running_update_kernel, dim3(n_entries, (max_C + 31) / 32), dim3(kBlock), 0, stream, entries);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 

@@ -206,6 +206,36 @@ def bn_finalize(ssum, ssq, count, gamma, beta, eps, momentum, running_mean, runn
           "sy_bn_finalize")
 
 
+class BnRunningTable:
+    """Device table for sy_bn_running_update.  `modules` = [(bn_module, [(sum, sqsum, count), ...calls in order])]."""
+
+    def __init__(self, modules, device):
+        arr = (_lib.BnRunningEntry * len(modules))()
+        self.max_c, self.keep = 0, []
+        for e, (bn, calls) in zip(arr, modules):
+            assert 1 <= len(calls) <= 2
+            e.running_mean, e.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            for j, (ssum, ssq, count) in enumerate(calls):
+                e.sum[j], e.sqsum[j], e.count[j] = ssum.data_ptr(), ssq.data_ptr(), float(count)
+            e.C = bn.num_features
+            e.copies = calls[0][0].numel() // e.C
+            e.calls = len(calls)
+            e.momentum = bn.momentum if bn.momentum is not None else 0.1
+            self.max_c = max(self.max_c, e.C)
+            self.keep.append((bn.running_mean, bn.running_var))
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = raw.to(device)
+        self.n = len(modules)
+        self.sig = tuple(t.data_ptr() for pair in self.keep for t in pair)
+
+    def valid(self):
+        return self.sig == tuple(t.data_ptr() for pair in self.keep for t in pair)
+
+    def run(self):
+        check(_lib.lib().sy_bn_running_update(self.table.data_ptr(), self.n, self.max_c, stream_of(self.table)),
+              "sy_bn_running_update")
+
+
 def bn_silu_apply(y, scale, shift, out, res=None):
     check(_lib.lib().sy_bn_silu_apply(y.ptr(), y.ld, scale.data_ptr(), shift.data_ptr(),
                                       None if res is None else res.ptr(), 0 if res is None else res.ld, out.ptr(),
@@ -292,6 +322,7 @@ TILE_WR = 80           # codes >= 80: fragment-packed weights straight to VGPRs 
 _TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging strategy codes, see include/streamyolo_hip.h
     # rs = register-staged, d2/d3 = 2-/3-deep LDS-DMA ring (codes: include/streamyolo_hip.h)
     # wr = register-staged pixels + fragment-packed weights straight to VGPRs
+    "wide256": [19, 22, 23, 35, 38, 51, 54, 83, 86, 87],        # Cout >= 256 adds the 256-channel weights-in-register tiles
     "wide": [19, 22, 23, 35, 38, 51, 54, 83, 86, 87],
     "c64": [20, 23, 39, 55, 36, 84, 87],
     "c32": [21, 23, 39, 85, 87],
@@ -329,7 +360,7 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     stats = (torch.zeros(32 * Cout, device=device), torch.zeros(32 * Cout, device=device)) if with_stats else None
     from .model.packing import pack_conv_weight_frag
     wf = pack_conv_weight_frag(w, k)
-    cands = _TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide"]
+    cands = _TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide" if Cout < 256 else "wide256"]
     best, best_t = 0, float("inf")
     for t in cands:
         if t >= TILE_WR and wf is None:

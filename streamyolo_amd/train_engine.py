@@ -20,6 +20,8 @@ kernels), a host-synchronising assignment loop, then autograd's generic backward
 dict whose total_loss.backward() fills .grad through one autograd.Function); `TrainStep` is the
 sync-free fast path bench.py and a native trainer use.
 """
+import os
+
 import torch
 
 from . import ops
@@ -116,6 +118,8 @@ class TrainPlan:
     BWD_COPIES = 16              # replicas of each BN-backward reduction (same reason)
     STAT_COPIES = 32             # replicas of each conv's sum / sum^2 arrays (atomic-contention control)
     WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
+    RING = 3                     # raw-gradient scratch slots (wgrad of layer i overlaps BN backward / dgrad of i-1, i-2)
+    STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
 
     def __init__(self, model, B, H, W, dtype, device):
         self.model, self.B, self.H, self.W, self.device = model, B, H, W, device
@@ -132,7 +136,12 @@ class TrainPlan:
         assert len(b.ops) == 2 * self.n_frame_ops and b.replay == len(b.fulls)
         b.paired = False
         fused = build_fuse_net(b, pafpn, cur, sup)                      # (:168-170)
+        self.n_head_start = len(b.ops)
         self.preds, self.A = build_head_net(b, head, fused)
+        lvl = 0
+        for op in b.ops[self.n_head_start:]:                             # per-level towers end with their PredOp
+            op.level = lvl
+            lvl += 1 if op.kind == "pred" else 0
         self.hw = [(f.H, f.W) for f in fused]
         self.ops = b.ops
         self.nc = head.num_classes
@@ -167,12 +176,22 @@ class TrainPlan:
                 op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
             max_raw = max(max_raw, 2 * op.y.pixels * C)
             off += C
-        self.dyraw_scratch = torch.empty(max_raw, dtype=self.tdtype, device=device)
+        # raw-gradient scratch ring: the weight-gradient kernels of layer i run on the side stream while the main
+        # stream is already producing layer i-1's raw gradient, so a slot is reused only after its wgrad retired
+        self.dyraw_ring = [torch.empty(max_raw, dtype=self.tdtype, device=device) for _ in range(self.RING)]
+        self.ring_done = [None] * self.RING
+        self.ring_i = 0
+        self.dyraw_scratch = self.dyraw_ring[0]
+        self.side = torch.cuda.Stream(device=device) if (device.type == "cuda" and self.STREAMS > 1) else None
+        self.tuned = False                    # the first step (autotuning) runs on one stream
+        self.force_serial = False             # profile(): per-kernel durations without overlap
+        self._ev_pool, self._ev_i = [], 0
         self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=device)
         for op in self.ops:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
         self.loss_ws = None
+        self.run_table = None
         self.grads = _GradSpace()
 
         # ---- flat gradient arena in parameter layout ------------------------------------------------
@@ -195,31 +214,42 @@ class TrainPlan:
         self.stat_arena.zero_()
         ops.focus_pack(x, 0, self.f0_cur)
         ops.focus_pack(x, 3, self.f0_sup)
-        nch = 5 + self.nc
-        for op in self.ops:
-            k = op.kind
-            if k == "conv":
-                bn = op.mod.bn
-                w = self.cache.conv_weight(op.mod)
-                t = op.tile("fwd_stats")
-                ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
-                           wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
-                scale, shift, mean, invstd = op.aff
-                mom = bn.momentum if bn.momentum is not None else 0.1
-                ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
-                                bn.running_mean, bn.running_var, scale, shift, mean, invstd)
-                ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
-            elif k == "resize":
-                ops.resize_nearest(op.src, op.dst)
-            elif k == "spp":
-                ops.spp_pool(op.v, op.argmax)
-            else:   # pred: raw logits (tal_head.py:174: cat[reg, obj, cls]), decoded later by the loss
-                w_ro, b_ro, w_c, b_c = self.cache.pred(op)[:4]
-                base = self.raw.data_ptr() + op.a0 * nch * 4
-                ops.conv2d(op.reg_x, w_ro, None, 1, 1, None, b_ro, epilogue=EPI_LINEAR, y_f32=True, y_ptr=base,
-                           y_ld=nch, y_bs=self.A * nch, cout=5)
-                ops.conv2d(op.cls_x, w_c, None, 1, 1, None, b_c, epilogue=EPI_LINEAR, y_f32=True, y_ptr=base + 20,
-                           y_ld=nch, y_bs=self.A * nch, cout=self.nc)
+        nf = self.n_frame_ops
+        side = self.side if (self.tuned and not self.force_serial) else None
+        if side is None:
+            for op in self.ops:
+                self._forward_op(op)
+        else:
+            # the two frames' networks are independent until the DFP fusion (dfp_pafpn.py:120-165): current frame
+            # on the caller's stream, support frame on the side stream; then the three head levels fan out again
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+            CH = 6
+            for i0 in range(0, nf, CH):
+                for op in self.ops[i0:min(nf, i0 + CH)]:
+                    self._forward_op(op)
+                with torch.cuda.stream(side):
+                    for op in self.ops[nf + i0:nf + min(nf, i0 + CH)]:
+                        self._forward_op(op)
+            main.wait_stream(side)
+            for op in self.ops[2 * nf:self.n_head_start]:
+                self._forward_op(op)
+            side.wait_stream(main)
+            for op in self.ops[self.n_head_start:]:
+                if getattr(op, "level", 0) == 0:
+                    self._forward_op(op)
+            with torch.cuda.stream(side):
+                for op in self.ops[self.n_head_start:]:
+                    if getattr(op, "level", 0) != 0:
+                        self._forward_op(op)
+            main.wait_stream(side)
+        if self.run_table is None or not self.run_table.valid():
+            mods = {}
+            for op in self.ops:                                      # plan order == the reference's call order
+                if op.kind == "conv":
+                    mods.setdefault(id(op.mod.bn), (op.mod.bn, []))[1].append((op.stat[0], op.stat[1], op.y.pixels))
+            self.run_table = ops.BnRunningTable(list(mods.values()), self.device)
+        self.run_table.run()
         # num_batches_tracked: +1 per BN call (shared backbone/neck/jian BNs are called twice — trap T2)
         counts = {}
         for bn in self.bn_mods:
@@ -229,6 +259,34 @@ class TrainPlan:
             ts, cs = zip(*counts.values())
             torch._foreach_add_(list(ts), list(cs))
         return self.raw
+
+    def _forward_op(self, op):
+        nch = 5 + self.nc
+        k = op.kind
+        if k == "conv":
+            bn = op.mod.bn
+            w = self.cache.conv_weight(op.mod)
+            t = op.tile("fwd_stats")
+            ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
+                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
+            scale, shift, mean, invstd = op.aff
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
+            # module update them in call order there, whatever stream each frame ran on)
+            ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
+                            None, None, scale, shift, mean, invstd)
+            ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
+        elif k == "resize":
+            ops.resize_nearest(op.src, op.dst)
+        elif k == "spp":
+            ops.spp_pool(op.v, op.argmax)
+        else:   # pred: raw logits (tal_head.py:174: cat[reg, obj, cls]), decoded later by the loss
+            w_ro, b_ro, w_c, b_c = self.cache.pred(op)[:4]
+            base = self.raw.data_ptr() + op.a0 * nch * 4
+            ops.conv2d(op.reg_x, w_ro, None, 1, 1, None, b_ro, epilogue=EPI_LINEAR, y_f32=True, y_ptr=base,
+                       y_ld=nch, y_bs=self.A * nch, cout=5)
+            ops.conv2d(op.cls_x, w_c, None, 1, 1, None, b_c, epilogue=EPI_LINEAR, y_f32=True, y_ptr=base + 20,
+                       y_ld=nch, y_bs=self.A * nch, cout=self.nc)
 
     # ------------------------------------------------------------------------------------------------
     def loss(self, labels, support):
@@ -251,6 +309,9 @@ class TrainPlan:
         G.reset()
         self.arena.zero_()
         self.bwd_arena.zero_()
+        self._ev_i = 0
+        self._side = self.side if (self.tuned and not self.force_serial) else None
+        self._main = torch.cuda.current_stream(self.device) if self._side is not None else None
         nc, A = self.nc, self.A
         # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels
         self.dpad[..., 0:5] = d_raw[..., 0:5]
@@ -272,7 +333,49 @@ class TrainPlan:
                         ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
                     elif op.kind == "spp":
                         ops.spp_pool_bwd(G.view(op.v), op.argmax)
+        if self._side is not None:
+            self._main.wait_stream(self._side)
+        self.tuned = True                                            # kernels are tuned after the first full step
         return self.arena
+
+    # ---- weight gradients off the critical path -------------------------------------------------------------
+    # Nothing downstream in the backward pass reads a weight gradient, so every wgrad (+ its fold) runs on the side
+    # stream, ordered after the main-stream kernels that produced its raw gradient, and the main stream goes
+    # straight on to the data gradient of the same layer.
+    def _event(self):
+        if self._ev_i == len(self._ev_pool):
+            self._ev_pool.append(torch.cuda.Event())
+        e = self._ev_pool[self._ev_i]
+        self._ev_i += 1
+        return e
+
+    def _scratch(self, numel):
+        """Next raw-gradient slot of the ring (the main stream first waits for the wgrad that last read it)."""
+        if self._side is None:
+            self._slot = 0
+            return self.dyraw_ring[0][:numel]
+        self.ring_i = (self.ring_i + 1) % self.RING
+        self._slot = self.ring_i
+        done = self.ring_done[self._slot]
+        if done is not None:
+            self._main.wait_event(done)
+            self.ring_done[self._slot] = None
+        return self.dyraw_ring[self._slot][:numel]
+
+    def _on_side(self, fn, slot=None):
+        """Run fn's launches on the side stream after everything issued so far on the main stream."""
+        if self._side is None:
+            fn()
+            return
+        ready = self._event()
+        ready.record(self._main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            fn()
+            if slot is not None:
+                done = self._event()
+                done.record(self._side)
+                self.ring_done[slot] = done
 
     def _pred_backward(self, op, d_raw):
         G = self.grads
@@ -285,14 +388,17 @@ class TrainPlan:
         ops.conv2d(d_ro, w_ro_t, g_r, 1, 1, mode=CONV_DGRAD, accumulate=acc_r)
         g_c, acc_c = G.target(op.cls_x)
         ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c)
-        sc = self.pred_scratch
-        sc.zero_()
-        ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1, workspace=self.wgrad_ws)
-        ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1, workspace=self.wgrad_ws)
         cin = op.reg_x.C
-        self.gview[id(op.reg_mod.weight)].view(4, cin).add_(sc[0, 0:4, :cin])
-        self.gview[id(op.obj_mod.weight)].view(1, cin).add_(sc[0, 4:5, :cin])
-        self.gview[id(op.cls_mod.weight)].view(nc, cin).add_(sc[1, 0:nc, :cin])
+
+        def wg():
+            sc = self.pred_scratch
+            sc.zero_()
+            ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1, workspace=self.wgrad_ws)
+            ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1, workspace=self.wgrad_ws)
+            self.gview[id(op.reg_mod.weight)].view(4, cin).add_(sc[0, 0:4, :cin])
+            self.gview[id(op.obj_mod.weight)].view(1, cin).add_(sc[0, 4:5, :cin])
+            self.gview[id(op.cls_mod.weight)].view(nc, cin).add_(sc[1, 0:nc, :cin])
+        self._on_side(wg)
         db = d_raw[:, op.a0:op.a0 + hwk].sum((0, 1))
         self.gview[id(op.reg_mod.bias)].add_(db[0:4])
         self.gview[id(op.obj_mod.bias)].add_(db[4:5])
@@ -336,11 +442,12 @@ class TrainPlan:
         statistics), then ONE wgrad and ONE dgrad launch over the 2B images (the weights are shared)."""
         G = self.grads
         N, H, W, C = a.y.N, a.y.H, a.y.W, a.y.C
-        full = self.dyraw_scratch[:2 * N * H * W * C].view(2 * N, H, W, C)
+        full = self._scratch(2 * N * H * W * C).view(2 * N, H, W, C)
+        slot = self._slot
         self._bn_backward(b2, View(full[N:], N, H, W, C))
         self._bn_backward(a, View(full[:N], N, H, W, C))
         dy2 = View(full, 2 * N, H, W, C)
-        self._wgrad(a, a.x.pair(), dy2)
+        self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot)
         if a.need_dx:
             dxa, acca = G.target(a.x)
             dxb, accb = G.target(b2.x)
@@ -356,9 +463,10 @@ class TrainPlan:
     def _conv_backward(self, op):
         G = self.grads
         C = op.y.C
-        dyraw = View(self.dyraw_scratch[:op.y.pixels * C].view(op.y.N, op.y.H, op.y.W, C), op.y.N, op.y.H, op.y.W, C)
+        dyraw = View(self._scratch(op.y.pixels * C).view(op.y.N, op.y.H, op.y.W, C), op.y.N, op.y.H, op.y.W, C)
+        slot = self._slot
         self._bn_backward(op, dyraw)
-        self._wgrad(op, op.x, dyraw)
+        self._on_side(lambda: self._wgrad(op, op.x, dyraw), slot)
         if op.need_dx:
             dx, acc = G.target(op.x)
             t = op.tile("dgrad")
@@ -367,8 +475,9 @@ class TrainPlan:
                        wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None)
 
     # ------------------------------------------------------------------------------------------------
-    def profile(self, x, targets, iters=2):
-        """Per-op-kind kernel time (ms / step) with HIP events on the launch stream (bench.py roofline)."""
+    def profile(self, x, targets, iters=2, detail=False):
+        """Per-op-kind kernel time (ms / step) with HIP events on the launch stream (bench.py roofline).
+        detail=True: per (kind, shape) rows [(kind, shape, launches / step, ms / step, flops / step)] instead."""
         import types
         evs = []
         real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply",
@@ -382,13 +491,27 @@ class TrainPlan:
                     kind = "dgrad" if k.get("mode", 0) == CONV_DGRAD else "conv"
                 elif name == "conv2d_wgrad":
                     kind = "wgrad"
+                desc, fl = "", 0.0
+                if detail and name in ("conv2d", "conv2d_wgrad"):
+                    xi, yo = a[0], (a[2] if name == "conv2d" else a[1])
+                    if xi is None or yo is None:            # prediction convs write / read a raw fp32 pointer
+                        xi = yo = (xi or yo)
+                        desc, kind = "pred N%d %dx%d c%d" % (xi.N, xi.H, xi.W, xi.C), kind + "(pred)"
+                    if kind == "dgrad":
+                        xi, yo = yo, xi
+                    if not desc:
+                        desc = "N%d %dx%d %d->%d k%d s%d" % (xi.N, yo.H, yo.W, xi.C, yo.C, a[3], a[4])
+                        fl = 2.0 * xi.C * yo.C * a[3] * a[3] * yo.N * yo.H * yo.W
+                elif detail and isinstance(a[0], View):
+                    desc = "N%d %dx%d c%d" % (a[0].N, a[0].H, a[0].W, a[0].C)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 r = fn(*a, **k)
                 e.record()
-                evs.append((kind, s, e))
+                evs.append((kind, s, e, desc, fl))
                 return r
             return inner
+        self.force_serial = True                                 # per-kernel durations: one stream, no overlap
         try:
             for n, fn in real.items():
                 setattr(ops, n, wrap(n, fn))
@@ -399,10 +522,16 @@ class TrainPlan:
         finally:
             for n, fn in real.items():
                 setattr(ops, n, fn)
+            self.force_serial = False
         torch.cuda.synchronize()
-        tot = {}
-        for kind, s, e in evs:
-            tot[kind] = tot.get(kind, 0.0) + s.elapsed_time(e)
+        tot, rows = {}, {}
+        for kind, s, e, desc, fl in evs:
+            ms = s.elapsed_time(e)
+            tot[kind] = tot.get(kind, 0.0) + ms
+            r = rows.setdefault((kind, desc), [0, 0.0, 0.0])
+            r[0] += 1; r[1] += ms; r[2] += fl
+        if detail:
+            return [(k[0], k[1], r[0] / iters, r[1] / iters, r[2] / iters) for k, r in rows.items()]
         return {k: v / iters for k, v in tot.items()}
 
 

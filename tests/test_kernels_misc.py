@@ -104,6 +104,36 @@ def test_bn_train_silu_fwd_bwd(backend, dt):
     assert _rel(dyv.nchw().cpu(), y.grad) < (3e-2 if dt == "bf16" else 1e-4)
 
 
+def test_bn_running_update_batched(backend):
+    """sy_bn_running_update: several modules in one launch; a module called twice applies both momentum updates in
+    call order (dfp_pafpn.py:120-165 calls the shared backbone per frame, current frame first)."""
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(5)
+    mods, calls, ref = [], [], []
+    for C, ncalls, copies in ((40, 2, 3), (8, 1, 1), (72, 2, 8)):
+        bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.03)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        rbn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).train()
+        rbn.load_state_dict(bn.state_dict())
+        bn = bn.to(backend)
+        cl = []
+        for j in range(ncalls):
+            y = torch.randn(2 + j, C, 5, 7, generator=g) * (1.0 + j) + 0.3 * j
+            rbn(y)
+            parts = y.permute(1, 0, 2, 3).reshape(C, -1).chunk(copies, dim=1)      # replicas hold disjoint partial sums
+            parts = list(parts) + [torch.zeros(C, 0)] * (copies - len(parts))
+            ssum = torch.stack([p.sum(1) for p in parts]).contiguous().to(backend)
+            ssq = torch.stack([(p ** 2).sum(1) for p in parts]).contiguous().to(backend)
+            cl.append((ssum, ssq, y.numel() // C))
+        mods.append((bn, cl)); ref.append(rbn)
+    tab = ops.BnRunningTable(mods, torch.device(backend) if not isinstance(backend, torch.device) else backend)
+    assert tab.valid()
+    tab.run()
+    for (bn, _), rbn in zip(mods, ref):
+        assert _rel(bn.running_mean.cpu(), rbn.running_mean) < 1e-5
+        assert _rel(bn.running_var.cpu(), rbn.running_var) < 1e-5
+
+
 def _random_preds(B, A, nc, seed, img=(600.0, 960.0), tie_free=True):
     g = torch.Generator().manual_seed(seed)
     p = torch.zeros(B, A, 5 + nc)

@@ -93,3 +93,40 @@ def test_train_step_s_160x256(golden_dir, dt, ltol):
         nerr = np.abs(norms - z["grad_norms"]).max() / np.abs(z["grad_norms"]).max()
         print("s train fp32: worst small-grad rel err %.3e, grad-norm rel err %.3e" % (worst, nerr))
         assert worst < 5e-3 and nerr < 2e-3
+
+
+@pytest.mark.gpu
+def test_overlapped_step_matches_single_stream(golden_dir):
+    """Step 1 runs on one stream (kernel tuning); later steps put the support frame, two head levels and every
+    weight gradient on a side stream.  Same inputs, same weights: losses, gradients and BatchNorm running
+    statistics must match the single-stream pass (fp32; BN partial sums are atomically folded, hence 1e-4)."""
+    from streamyolo_amd import _lib
+    from streamyolo_amd.train_engine import TrainStep
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda:0")
+    z, model, x, targets = _setup("s", "s_train_2x160x256", golden_dir, dev, "fp32")
+    st = TrainStep(model)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    res = []
+    for mode in ("tune", "serial", "overlap", "overlap"):
+        model.load_state_dict(state0)
+        if mode != "tune":
+            assert st.plan.side is not None and st.plan.tuned
+            st.plan.force_serial = (mode == "serial")
+        out = st.step(x, targets)
+        torch.cuda.synchronize()
+        res.append((mode, float(out["total_loss"]), st.plan.arena.clone(),
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    st.plan.force_serial = False
+    assert st.plan.tuned
+    _, l_ref, g_ref, r_ref = res[1]
+    for mode, l, g, r in res[2:]:
+        assert abs(l - l_ref) / abs(l_ref) < 1e-5
+        assert _rel(g, g_ref) < 1e-4
+        for k in r_ref:
+            assert _rel(r[k], r_ref[k]) < 1e-5, k
+    # and the running statistics are the reference's (two momentum updates for the shared backbone modules)
+    sd = model.state_dict()
+    for k in z.files:
+        if k.startswith("stat:") and "running" in k:
+            assert _rel(sd[k[5:]].cpu(), z[k]) < 2e-3, k
