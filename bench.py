@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph when possible")
+    ap.add_argument("--graph", type=int, default=1, help="infer / stream: replay the step from a hipGraph")
+    ap.add_argument("--train-graph", type=int, default=0, help="train: hipGraph replay instead of launch tapes (slower on ROCm 7)")
     return ap.parse_args()
 
 
@@ -142,7 +143,7 @@ def main():
     if workload == "train":
         from streamyolo_amd.train_engine import TrainStep
         lab, sup = synth_labels(B, args.height, args.width, cfg.num_classes, seed=3 + rank)
-        stepper = TrainStep(model, world_size=world, process_group=dist)
+        stepper = TrainStep(model, world_size=world, process_group=dist, graph=bool(args.train_graph))
         lab, sup = lab.to(dev), sup.to(dev)
 
         def step():
@@ -210,6 +211,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # launch-side time (the GPU runs behind it)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -251,7 +253,8 @@ def main():
                                             else "eval forward off_pipe + decode"), B,
                                       "random-init synthetic weights (utils/synth.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "hipgraph": bool(args.graph)},
+                       "hipgraph": bool(args.train_graph if workload == "train" else args.graph),
+                       "host_launch_ms_per_step": round(host_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

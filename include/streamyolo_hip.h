@@ -133,6 +133,25 @@ SY_API int sy_postprocess(const float* pred, int B, int A, int num_classes, floa
                    int max_det, float* out_det, int32_t* out_index, int32_t* out_count,
                    void* workspace, void* stream);
 
+/* Per-step weight staging: the nn.Parameters stay OIHW fp32 (the optimizer's master copy,
+ * exps/train_utils/double_trainer.py:114-119); ONE launch re-derives, for every convolution of the step, the
+ * layouts the MFMA kernels read.  Entry: a source block w[co_n][ci_n][taps] fp32 written as rows r0..r0+co_n of
+ *   packed   [R][taps][CI]       forward / weight-gradient operand (K-contiguous), CI >= ci_n (zero padded once)
+ *   packed_t [CI][taps][R_t]     data-gradient operand, element [ci][tap][r0 + co]
+ *   frag / frag_t                the same two matrices in SY_TILE_WR fragment order
+ *                                [rows/32][channels/BK][taps][2][2][32][EPC]  (BK = 64 bytes of channels)
+ * Any destination may be NULL.  Several entries may target one destination (reg + obj predictors share a matrix).
+ * Padding rows / channels are never written: allocate destinations zeroed.  `entries` is DEVICE memory. */
+typedef struct sy_pack_entry {
+    const float* w;
+    void* packed;
+    void* packed_t;
+    void* frag;
+    void* frag_t;
+    int32_t co_n, ci_n, taps, r0, R, R_t, CI, dtype;
+} sy_pack_entry;
+SY_API int sy_pack_weights(const sy_pack_entry* entries, int n_entries, void* stream);
+
 /* Training-mode BatchNorm helpers around sy_conv2d(stat_sum/stat_sqsum).
  * Replaces nn.BatchNorm2d in training mode (momentum/eps patched by init_yolo, cfgs/<name>.py:40-44). */
 SY_API int sy_bn_finalize(const float* sum, const float* sqsum, int C, int copies, double count, const float* gamma,

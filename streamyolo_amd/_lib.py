@@ -46,6 +46,13 @@ class BnRunningEntry(C.Structure):
                 ("calls", C.c_int32), ("momentum", C.c_float)]
 
 
+class PackEntry(C.Structure):
+    """sy_pack_entry (include/streamyolo_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("packed_t", C.c_void_p), ("frag", C.c_void_p),
+                ("frag_t", C.c_void_p), ("co_n", C.c_int32), ("ci_n", C.c_int32), ("taps", C.c_int32),
+                ("r0", C.c_int32), ("R", C.c_int32), ("R_t", C.c_int32), ("CI", C.c_int32), ("dtype", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
@@ -71,6 +78,7 @@ SIGNATURES = {
     "sy_spp_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "sy_postprocess_workspace_bytes": (_L, [_I, _I]),
     "sy_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
+    "sy_pack_weights": (_I, [_P, _I, _P]),
     "sy_bn_running_update": (_I, [_P, _I, _I, _P]),
     "sy_bn_finalize": (_I, [_P, _P, _I, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sy_bn_silu_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
@@ -111,7 +119,54 @@ def lib():
     if _lib is None:
         _lib = _bind(DEFAULT_PATH)
         _lib_path = DEFAULT_PATH
-    return _lib
+    return _lib if _tape is None else _TapeProxy(_lib, _tape)
+
+
+# ---- launch tapes --------------------------------------------------------------------------------------
+# A plan's launch list is static: the same C-ABI calls with the same descriptors every step.  `record()` executes
+# the ordinary Python wrappers once while noting every library call (function + marshalled arguments, minus the
+# trailing stream); `replay()` re-issues them on an explicitly given hipStream_t — a few ctypes calls per
+# layer instead of re-deriving views, strides and descriptors in Python.
+_tape = None
+
+
+class _TapeProxy:
+    __slots__ = ("real", "tape")
+
+    def __init__(self, real, tape):
+        self.real, self.tape = real, tape
+
+    def __getattr__(self, name):
+        fn = getattr(self.real, name)
+        tape = self.tape
+
+        def call(*args):
+            tape.append((fn, args[:-1], name))                  # every entry point ends with `void* stream`
+            return fn(*args)
+        return call
+
+
+class record:
+    """with record() as tape: ...wrappers...   -> tape = [(cfunc, args_without_stream, name)]"""
+
+    def __enter__(self):
+        global _tape
+        assert _tape is None, "launch tapes do not nest"
+        lib()
+        _tape = []
+        return _tape
+
+    def __exit__(self, *exc):
+        global _tape
+        _tape = None
+        return False
+
+
+def replay(tape, stream):
+    for fn, args, name in tape:
+        rc = fn(*args, stream)
+        if rc != 0:
+            check(rc, name)
 
 
 def use_library(path):

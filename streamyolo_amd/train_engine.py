@@ -20,6 +20,7 @@ kernels), a host-synchronising assignment loop, then autograd's generic backward
 dict whose total_loss.backward() fills .grad through one autograd.Function); `TrainStep` is the
 sync-free fast path bench.py and a native trainer use.
 """
+import ctypes as C
 import os
 
 import torch
@@ -38,6 +39,7 @@ class _GradSpace:
     def __init__(self):
         self.mirror = {}          # id(buf tensor) -> grad tensor
         self.written = {}         # id(buf tensor) -> list of (c0, c1)
+        self.py = lambda fn: fn() # torch-op hook (TrainPlan records these snippets on its launch tape)
 
     def reset(self):
         self.written = {}
@@ -78,7 +80,7 @@ class _GradSpace:
             accumulate = True                                    # (partly) written: zero the holes, then +=
             flat = g.buf.view(-1, v.ld)
             for a, b in gaps:
-                flat[:, a:b].zero_()
+                self.py(lambda t=flat[:, a:b]: t.zero_())
         if gaps:
             merged = []
             for a, b in sorted(iv + [(c0, c1)]):
@@ -114,12 +116,88 @@ class _PairBuilder(_Builder):
         return View(full[half * N:(half + 1) * N], N, H, W, C, root=(full, half * N))
 
 
+class StagedWeights:
+    """Compute-dtype operand layouts of every convolution of the training plan, re-derived from the fp32 OIHW
+    nn.Parameters by ONE sy_pack_weights launch per step (the optimizer rewrites the parameters every iteration —
+    exps/train_utils/double_trainer.py:114-119 — so nothing here is cached across steps).  Same lookup surface as
+    engine.ParamCache: conv_weight / conv_weight_frag / pred."""
+
+    def __init__(self, plan_ops, dtype, device):
+        from . import _lib
+        self.dtype, self.device = dtype, device
+        tdt = ops.TORCH_DTYPE[dtype]
+        epc = 16 // torch.empty(0, dtype=tdt).element_size()
+        bk = 4 * epc
+        self.conv, self.preds, self.sources = {}, {}, []
+        rows = []
+
+        def z(n, dt=tdt):
+            return torch.zeros(n, dtype=dt, device=device)
+
+        def entry(w, packed, packed_t, frag, frag_t, co_n, ci_n, taps, r0, R, R_t, CI, dt=dtype):
+            e = _lib.PackEntry()
+            e.w = w.data_ptr()
+            e.packed, e.packed_t = _ptr(packed), _ptr(packed_t)
+            e.frag, e.frag_t = _ptr(frag), _ptr(frag_t)
+            e.co_n, e.ci_n, e.taps, e.r0, e.R, e.R_t, e.CI, e.dtype = co_n, ci_n, taps, r0, R, R_t, CI, dt
+            rows.append(e)
+            self.sources.append(w)
+
+        def _ptr(t):
+            return None if t is None else t.data_ptr()
+
+        for op in plan_ops:
+            if op.kind == "conv" and id(op.mod) not in self.conv:
+                w = op.mod.conv.weight
+                assert w.dtype == torch.float32 and w.is_contiguous()
+                co, ci, kh, kw = w.shape
+                taps, CI = kh * kw, (16 if ci == 12 else ci)           # Focus stem: 12 -> 16 channels (zero weights)
+                packed, packed_t = z(co * taps * CI).view(co, taps * CI), z(CI * taps * co).view(CI, taps * co)
+                frag = z(-(-co // 32) * 32 * taps * CI) if CI % bk == 0 else None
+                frag_t = z(-(-CI // 32) * 32 * taps * co) if co % bk == 0 else None
+                entry(w, packed, packed_t, frag, frag_t, co, ci, taps, 0, co, co, CI)
+                self.conv[id(op.mod)] = (packed, packed_t, frag, frag_t)
+            elif op.kind == "pred":
+                cin, nc = op.reg_mod.weight.shape[1], op.cls_mod.weight.shape[0]
+                w_ro, w_ro_t = z(5 * cin).view(5, cin), z(cin * 8).view(cin, 8)
+                w_c, w_c_t = z(nc * cin).view(nc, cin), z(cin * nc).view(cin, nc)
+                b_ro = z(5, torch.float32)
+                entry(op.reg_mod.weight, w_ro, w_ro_t, None, None, 4, cin, 1, 0, 5, 8, cin)
+                entry(op.obj_mod.weight, w_ro, w_ro_t, None, None, 1, cin, 1, 4, 5, 8, cin)
+                entry(op.cls_mod.weight, w_c, w_c_t, None, None, nc, cin, 1, 0, nc, nc, cin)
+                entry(op.reg_mod.bias, b_ro, None, None, None, 4, 1, 1, 0, 5, 5, 1, ops.DTYPE_NAME["fp32"])
+                entry(op.obj_mod.bias, b_ro, None, None, None, 1, 1, 1, 4, 5, 5, 1, ops.DTYPE_NAME["fp32"])
+                self.preds[id(op)] = (w_ro, b_ro, w_c, op.cls_mod.bias, w_ro_t, w_c_t)
+        arr = (_lib.PackEntry * len(rows))(*rows)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self.n = len(rows)
+        self.sig = tuple(t.data_ptr() for t in self.sources)
+
+    def valid(self):
+        return self.sig == tuple(t.data_ptr() for t in self.sources)
+
+    def refresh(self):
+        ops.check(ops._lib.lib().sy_pack_weights(self.table.data_ptr(), self.n, ops.stream_of(self.table)),
+                  "sy_pack_weights")
+
+    def conv_weight(self, mod, transpose=False):
+        return self.conv[id(mod)][1 if transpose else 0]
+
+    def conv_weight_frag(self, mod, transpose=False):
+        return self.conv[id(mod)][3 if transpose else 2]
+
+    def pred(self, op):
+        w_ro, b_ro, w_c, b_c, w_ro_t, w_c_t = self.preds[id(op)]
+        return w_ro, b_ro, w_c, b_c.detach(), w_ro_t, w_c_t
+
+
 class TrainPlan:
     BWD_COPIES = 16              # replicas of each BN-backward reduction (same reason)
     STAT_COPIES = 32             # replicas of each conv's sum / sum^2 arrays (atomic-contention control)
     WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
     RING = 3                     # raw-gradient scratch slots (wgrad of layer i overlaps BN backward / dgrad of i-1, i-2)
     STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
+    TAPE_ON_CPU = True           # the SIMT-emulator test runs replay launch tapes too (same code path as the GPU)
 
     def __init__(self, model, B, H, W, dtype, device):
         self.model, self.B, self.H, self.W, self.device = model, B, H, W, device
@@ -127,7 +205,7 @@ class TrainPlan:
         self.tdtype = ops.TORCH_DTYPE[self.dtype]
         pafpn, head = model.backbone, model.head
         self.head = head
-        self.cache = ParamCache(self.dtype, device)
+        self.cache = None                    # StagedWeights, built below once the plan's ops exist
         b = _PairBuilder(self.dtype, device)
         self.f0_cur, cur = build_frame_net(b, pafpn, B, H, W)          # current frame  (dfp_pafpn.py:120-140)
         self.n_frame_ops = len(b.ops)
@@ -179,7 +257,6 @@ class TrainPlan:
         # raw-gradient scratch ring: the weight-gradient kernels of layer i run on the side stream while the main
         # stream is already producing layer i-1's raw gradient, so a slot is reused only after its wgrad retired
         self.dyraw_ring = [torch.empty(max_raw, dtype=self.tdtype, device=device) for _ in range(self.RING)]
-        self.ring_done = [None] * self.RING
         self.ring_i = 0
         self.dyraw_scratch = self.dyraw_ring[0]
         self.side = torch.cuda.Stream(device=device) if (device.type == "cuda" and self.STREAMS > 1) else None
@@ -190,9 +267,12 @@ class TrainPlan:
         for op in self.ops:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
+        self.cache = StagedWeights(self.ops, self.dtype, device)
         self.loss_ws = None
         self.run_table = None
         self.grads = _GradSpace()
+        self.grads.py = self._py
+        self.programs, self._rec, self._param_sig = {}, None, None
 
         # ---- flat gradient arena in parameter layout ------------------------------------------------
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -211,38 +291,17 @@ class TrainPlan:
     def forward(self, x):
         """x [B,6,H,W] float on device -> raw [B, A, 5+nc] fp32 (plan-owned)."""
         x = x.float().contiguous()
+        sig = tuple(p.data_ptr() for p in self.params)
+        if sig != self._param_sig or not self.cache.valid():     # a parameter was re-allocated (.to(), load with assign)
+            self._param_sig = sig
+            self.programs.clear()                                # the tapes hold raw pointers
+            if not self.cache.valid():
+                self.cache = StagedWeights(self.ops, self.dtype, self.device)
+        self.cache.refresh()                                     # this step's weights -> MFMA operand layouts
         self.stat_arena.zero_()
         ops.focus_pack(x, 0, self.f0_cur)
         ops.focus_pack(x, 3, self.f0_sup)
-        nf = self.n_frame_ops
-        side = self.side if (self.tuned and not self.force_serial) else None
-        if side is None:
-            for op in self.ops:
-                self._forward_op(op)
-        else:
-            # the two frames' networks are independent until the DFP fusion (dfp_pafpn.py:120-165): current frame
-            # on the caller's stream, support frame on the side stream; then the three head levels fan out again
-            main = torch.cuda.current_stream(self.device)
-            side.wait_stream(main)
-            CH = 6
-            for i0 in range(0, nf, CH):
-                for op in self.ops[i0:min(nf, i0 + CH)]:
-                    self._forward_op(op)
-                with torch.cuda.stream(side):
-                    for op in self.ops[nf + i0:nf + min(nf, i0 + CH)]:
-                        self._forward_op(op)
-            main.wait_stream(side)
-            for op in self.ops[2 * nf:self.n_head_start]:
-                self._forward_op(op)
-            side.wait_stream(main)
-            for op in self.ops[self.n_head_start:]:
-                if getattr(op, "level", 0) == 0:
-                    self._forward_op(op)
-            with torch.cuda.stream(side):
-                for op in self.ops[self.n_head_start:]:
-                    if getattr(op, "level", 0) != 0:
-                        self._forward_op(op)
-            main.wait_stream(side)
+        self._run("fwd", self._forward_ops)
         if self.run_table is None or not self.run_table.valid():
             mods = {}
             for op in self.ops:                                      # plan order == the reference's call order
@@ -259,6 +318,120 @@ class TrainPlan:
             ts, cs = zip(*counts.values())
             torch._foreach_add_(list(ts), list(cs))
         return self.raw
+
+    def _forward_ops(self):
+        """The op loop in launch order.  The two frames' networks are independent until the DFP fusion
+        (dfp_pafpn.py:120-165): current frame on the caller's stream, support frame on the side stream (chunks of a
+        few layers so both queues stay fed); after the fusion the three head levels fan out again."""
+        nf, CH = self.n_frame_ops, 6
+        self._mark("fork")
+        for i0 in range(0, nf, CH):
+            for op in self.ops[i0:min(nf, i0 + CH)]:
+                self._forward_op(op)
+            self._mark("side_nw")
+            for op in self.ops[nf + i0:nf + min(nf, i0 + CH)]:
+                self._forward_op(op)
+            self._mark("main", None)
+        self._mark("join")
+        for op in self.ops[2 * nf:self.n_head_start]:
+            self._forward_op(op)
+        self._mark("fork")
+        for op in self.ops[self.n_head_start:]:
+            if op.level == 0:
+                self._forward_op(op)
+        self._mark("side_nw")
+        for op in self.ops[self.n_head_start:]:
+            if op.level != 0:
+                self._forward_op(op)
+        self._mark("main", None)
+        self._mark("join")
+
+    # ---- launch programs ------------------------------------------------------------------------------------
+    # Step 1 runs the Python wrappers directly (kernel variants get tuned).  Step 2 runs them again under
+    # _lib.record(): every C-ABI call lands on a tape together with the torch ops in between ("py" entries) and
+    # the stream marks emitted above.  From step 3 on the tape IS the step: the interpreter below re-issues the
+    # recorded calls on explicit hipStream_t handles — main stream / side stream as the marks say — so the
+    # per-launch host cost is one ctypes call, and no Python-side view / descriptor / bookkeeping code runs.
+    def _mark(self, kind, arg=None):
+        if self._rec is not None:
+            self._rec.append((None, arg, kind))
+
+    def _py(self, fn):
+        """A torch-op snippet inside a pass: runs now, and is replayed from the tape later."""
+        fn()
+        if self._rec is not None:
+            self._rec.append((None, fn, "py"))
+
+    def _run(self, name, body, key=None):
+        from . import _lib
+        if self.force_serial or not self.tuned or self.device.type != "cuda" and not self.TAPE_ON_CPU:
+            self._rec = None
+            body()                                               # direct (tuning step, profile(), CPU test runs)
+            return
+        prog = self.programs.get(name)
+        if prog is None or prog[0] != key:
+            with _lib.record() as tape:
+                self._rec = tape
+                try:
+                    body()
+                finally:
+                    self._rec = None
+            self.programs[name] = (key, tape)
+            return
+        self._interpret(prog[1])
+
+    def _interpret(self, tape):
+        from . import _lib
+        dev_cuda = self.device.type == "cuda"
+        side = self.side
+        if dev_cuda:
+            main = torch.cuda.current_stream(self.device)
+            main_h = C.c_void_p(main.cuda_stream)
+            side_h = C.c_void_p(side.cuda_stream) if side is not None else main_h
+        else:
+            main = None
+            main_h = side_h = C.c_void_p(0)
+        cur, on_side = main_h, False
+        ring_done = [None] * self.RING
+        pool, ei = self._ev_pool, 0
+        for fn, args, name in tape:
+            if fn is not None:
+                rc = fn(*args, cur)
+                if rc != 0:
+                    _lib.check(rc, name)
+            elif name == "py":
+                if on_side:
+                    with torch.cuda.stream(side):
+                        args()
+                else:
+                    args()
+            elif side is None:
+                continue
+            elif name == "side" or name == "fork":
+                if ei == len(pool):
+                    pool.append(torch.cuda.Event())
+                ev = pool[ei]; ei += 1
+                ev.record(main)
+                side.wait_event(ev)
+                if name == "side":
+                    cur, on_side = side_h, True
+            elif name == "side_nw":
+                cur, on_side = side_h, True
+            elif name == "main":
+                if args is not None:                              # a raw-gradient ring slot is busy until here
+                    if ei == len(pool):
+                        pool.append(torch.cuda.Event())
+                    ev = pool[ei]; ei += 1
+                    ev.record(side)
+                    ring_done[args] = ev
+                cur, on_side = main_h, False
+            elif name == "acquire":
+                ev = ring_done[args]
+                if ev is not None:
+                    main.wait_event(ev)
+                    ring_done[args] = None
+            elif name == "join":
+                main.wait_stream(side)
 
     def _forward_op(self, op):
         nch = 5 + self.nc
@@ -305,17 +478,20 @@ class TrainPlan:
     # ------------------------------------------------------------------------------------------------
     def backward(self, d_raw):
         """d_raw [B, A, 5+nc] fp32 -> parameter gradients accumulated into self.arena (zeroed here)."""
-        G = self.grads
-        G.reset()
         self.arena.zero_()
         self.bwd_arena.zero_()
-        self._ev_i = 0
-        self._side = self.side if (self.tuned and not self.force_serial) else None
-        self._main = torch.cuda.current_stream(self.device) if self._side is not None else None
-        nc, A = self.nc, self.A
+        nc = self.nc
         # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels
         self.dpad[..., 0:5] = d_raw[..., 0:5]
         self.dpad[..., 8:8 + nc] = d_raw[..., 5:]
+        self._run("bwd", lambda: self._backward_ops(d_raw), key=d_raw.data_ptr())
+        self.tuned = True                                            # kernels are tuned after the first full step
+        return self.arena
+
+    def _backward_ops(self, d_raw):
+        G = self.grads
+        G.reset()
+        self.ring_i = 0
         nf = self.n_frame_ops
         for op in reversed(self.ops[2 * nf:]):                   # head, then DFP fusion
             if op.kind == "pred":
@@ -333,49 +509,24 @@ class TrainPlan:
                         ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
                     elif op.kind == "spp":
                         ops.spp_pool_bwd(G.view(op.v), op.argmax)
-        if self._side is not None:
-            self._main.wait_stream(self._side)
-        self.tuned = True                                            # kernels are tuned after the first full step
-        return self.arena
+        self._mark("join")
 
     # ---- weight gradients off the critical path -------------------------------------------------------------
     # Nothing downstream in the backward pass reads a weight gradient, so every wgrad (+ its fold) runs on the side
     # stream, ordered after the main-stream kernels that produced its raw gradient, and the main stream goes
     # straight on to the data gradient of the same layer.
-    def _event(self):
-        if self._ev_i == len(self._ev_pool):
-            self._ev_pool.append(torch.cuda.Event())
-        e = self._ev_pool[self._ev_i]
-        self._ev_i += 1
-        return e
-
     def _scratch(self, numel):
         """Next raw-gradient slot of the ring (the main stream first waits for the wgrad that last read it)."""
-        if self._side is None:
-            self._slot = 0
-            return self.dyraw_ring[0][:numel]
         self.ring_i = (self.ring_i + 1) % self.RING
         self._slot = self.ring_i
-        done = self.ring_done[self._slot]
-        if done is not None:
-            self._main.wait_event(done)
-            self.ring_done[self._slot] = None
+        self._mark("acquire", self._slot)
         return self.dyraw_ring[self._slot][:numel]
 
     def _on_side(self, fn, slot=None):
-        """Run fn's launches on the side stream after everything issued so far on the main stream."""
-        if self._side is None:
-            fn()
-            return
-        ready = self._event()
-        ready.record(self._main)
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(ready)
-            fn()
-            if slot is not None:
-                done = self._event()
-                done.record(self._side)
-                self.ring_done[slot] = done
+        """fn's launches go to the side stream, after everything issued so far on the main stream."""
+        self._mark("side")
+        fn()
+        self._mark("main", slot)
 
     def _pred_backward(self, op, d_raw):
         G = self.grads
@@ -390,19 +541,27 @@ class TrainPlan:
         ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c)
         cin = op.reg_x.C
 
+        sc = self.pred_scratch
+        g_reg = self.gview[id(op.reg_mod.weight)].view(4, cin)
+        g_obj = self.gview[id(op.obj_mod.weight)].view(1, cin)
+        g_cls = self.gview[id(op.cls_mod.weight)].view(nc, cin)
+
+        def fold():
+            g_reg.add_(sc[0, 0:4, :cin]); g_obj.add_(sc[0, 4:5, :cin]); g_cls.add_(sc[1, 0:nc, :cin])
+
         def wg():
-            sc = self.pred_scratch
-            sc.zero_()
+            self._py(lambda: sc.zero_())
             ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1, workspace=self.wgrad_ws)
             ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1, workspace=self.wgrad_ws)
-            self.gview[id(op.reg_mod.weight)].view(4, cin).add_(sc[0, 0:4, :cin])
-            self.gview[id(op.obj_mod.weight)].view(1, cin).add_(sc[0, 4:5, :cin])
-            self.gview[id(op.cls_mod.weight)].view(nc, cin).add_(sc[1, 0:nc, :cin])
+            self._py(fold)
         self._on_side(wg)
-        db = d_raw[:, op.a0:op.a0 + hwk].sum((0, 1))
-        self.gview[id(op.reg_mod.bias)].add_(db[0:4])
-        self.gview[id(op.obj_mod.bias)].add_(db[4:5])
-        self.gview[id(op.cls_mod.bias)].add_(db[5:])
+        gb_r, gb_o, gb_c = (self.gview[id(m.bias)] for m in (op.reg_mod, op.obj_mod, op.cls_mod))
+        d_lvl = d_raw[:, op.a0:op.a0 + hwk]
+
+        def bias():
+            db = d_lvl.sum((0, 1))
+            gb_r.add_(db[0:4]); gb_o.add_(db[4:5]); gb_c.add_(db[5:])
+        self._py(bias)
 
     def _bn_backward(self, op, dyraw):
         """Residual fan-in + BatchNorm/SiLU backward of one BaseConv call: fills `dyraw` (grad of the raw conv
@@ -432,10 +591,11 @@ class TrainPlan:
         else:                                                        # Focus stem: 12 real + 4 zero-padded channels
             if self.stem_scratch is None:
                 self.stem_scratch = torch.zeros((w.shape[0], x.C, op.k, op.k), dtype=torch.float32, device=self.device)
-            self.stem_scratch.zero_()
-            ops.conv2d_wgrad(x, dyraw, self.stem_scratch, op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
+            sc, gw = self.stem_scratch, self.gview[id(w)]
+            self._py(lambda: sc.zero_())
+            ops.conv2d_wgrad(x, dyraw, sc, op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
                              tile=wt[0], target_blocks=wt[1])
-            self.gview[id(w)].add_(self.stem_scratch[:, :w.shape[1]])
+            self._py(lambda: gw.add_(sc[:, :w.shape[1]]))
 
     def _conv_pair_backward(self, a, b2):
         """Layer i of the current-frame and support-frame networks together: per-frame BN backward (separate
@@ -589,9 +749,14 @@ class TrainStep:
     """Sync-free training step for bench.py / a native trainer: forward + loss + backward (+ one RCCL
     all-reduce of the flat gradient arena when world_size > 1); parameters' .grad are arena views."""
 
-    def __init__(self, model, world_size=1, process_group=None):
+    def __init__(self, model, world_size=1, process_group=None, graph=None):
         self.model, self.world, self.dist = model, world_size, process_group
         self.plan = None
+        # optional hipGraph replay of forward + loss + backward (STREAMYOLO_GRAPH=1 / graph=True).  Off by default:
+        # on ROCm 7 replaying this ~1500-node graph costs MORE host time than the launch tapes (measured, DESIGN.md)
+        self.use_graph = (os.environ.get("STREAMYOLO_GRAPH", "0") != "0") if graph is None else bool(graph)
+        self.graph = None
+        self.eager_steps = 0
         model.train()
         model.head.use_l1 = True                    # double_trainer.py:209-216 (no_aug_epochs == max_epoch)
 
@@ -602,12 +767,40 @@ class TrainStep:
                 p.grad = self.plan.gview[id(p)]
         return self.plan
 
+    def _eager(self, x, lab, sup):
+        plan = self.plan
+        plan.forward(x)
+        out, d_raw = plan.loss(lab, sup)
+        plan.backward(d_raw)
+        return out
+
+    def _capture(self, x, lab, sup):
+        """Record the step into a hipGraph over static copies of the inputs.  The side-stream forks join back inside
+        forward() / backward(), so the capture is one connected graph whose independent branches may run concurrently."""
+        self.gx, self.glab, self.gsup = x.float().contiguous().clone(), lab.clone(), sup.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.gout = self._eager(self.gx, self.glab, self.gsup)
+        self.graph = g
+
     def step(self, x, targets):
         plan = self._ensure(x)
         self._last = (x, targets)
-        plan.forward(x)
-        out, d_raw = plan.loss(targets[0], targets[1])
-        plan.backward(d_raw)
+        lab, sup = targets
+        graphable = self.use_graph and x.is_cuda and plan.run_table is not None and plan.tuned
+        if self.graph is not None and not (plan.cache.valid() and plan.run_table.valid()):
+            self.graph = None                                   # a parameter / buffer moved: the recording is stale
+        if graphable and self.eager_steps >= 2 and (self.graph is None or self.glab.shape != lab.shape):
+            self._capture(x, lab, sup)
+        if graphable and self.graph is not None:
+            self.gx.copy_(x)
+            self.glab.copy_(lab)
+            self.gsup.copy_(sup)
+            self.graph.replay()
+            out = self.gout
+        else:
+            out = self._eager(x, lab, sup)
+            self.eager_steps += 1
         if self.world > 1:
             self.dist.all_reduce(plan.arena)        # RCCL over xGMI: one collective over the whole arena
             plan.arena.div_(self.world)

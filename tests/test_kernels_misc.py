@@ -177,3 +177,35 @@ def test_postprocess_empty_and_ties(backend):
     rdet, ridx = O.postprocess(pred, nc, 0.01, 0.65)[0]
     n = int(cnt[0])
     assert n == ridx.numel() and np.array_equal(idx[0, :n].cpu().numpy(), ridx.numpy().astype(np.int32))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_pack_weights_matches_host_packing(backend, dt):
+    """sy_pack_weights (one launch, all layers) against the host-side packers used by the inference cache."""
+    from streamyolo_amd import _lib
+    from streamyolo_amd.model.packing import pack_conv_weight, pack_conv_weight_frag
+    code = ops.dtype_code(dt)
+    tdt = ops.TORCH_DTYPE[code]
+    g = torch.Generator().manual_seed(11)
+    shapes = [(40, 32, 3), (64, 64, 1), (24, 12, 3), (5, 48, 1)]
+    rows, keep, want = [], [], []
+    for co, ci, k in shapes:
+        w = torch.randn(co, ci, k, k, generator=g)
+        CI = 16 if ci == 12 else ci
+        p = pack_conv_weight(w, code, pad_cin_to=CI)
+        pt = pack_conv_weight(w, code, transpose=True, pad_cin_to=CI)
+        f, ft = pack_conv_weight_frag(p, k), pack_conv_weight_frag(pt, k)
+        wd = w.to(backend)
+        bufs = [torch.zeros(t.numel(), dtype=tdt, device=backend) if t is not None else None for t in (p, pt, f, ft)]
+        e = _lib.PackEntry()
+        e.w = wd.data_ptr()
+        e.packed, e.packed_t, e.frag, e.frag_t = [None if b is None else b.data_ptr() for b in bufs]
+        e.co_n, e.ci_n, e.taps, e.r0, e.R, e.R_t, e.CI, e.dtype = co, ci, k * k, 0, co, co, CI, code
+        rows.append(e); keep.append((wd, bufs)); want.append((p, pt, f, ft))
+    arr = (_lib.PackEntry * len(rows))(*rows)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(backend)
+    ops.check(_lib.lib().sy_pack_weights(table.data_ptr(), len(rows), ops.stream_of(table)), "sy_pack_weights")
+    for (_, bufs), exp in zip(keep, want):
+        for b, t in zip(bufs, exp):
+            if t is not None:
+                assert torch.equal(b.cpu().view(-1), t.reshape(-1))

@@ -70,6 +70,33 @@ def test_train_step_fast_path_matches_dropin(backend, golden_dir):
     assert _rel(g.cpu(), z["grad:backbone.backbone.dark3.1.m.0.conv2.conv.weight"]) < 2e-3
 
 
+def test_launch_tape_replay_matches_direct_step(backend, golden_dir):
+    """Step 1 = Python wrappers, step 2 = the same under the tape recorder, step 3+ = tape replay: identical state
+    and inputs must give the same loss, gradients and running statistics (and follow changed weights)."""
+    from streamyolo_amd.train_engine import TrainStep
+    z, model, x, targets = _setup("nano", "nano_train_2x64x96", golden_dir, backend, "fp32")
+    st = TrainStep(model, graph=False)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    res = []
+    for i in range(3):
+        model.load_state_dict(state0)
+        out = st.step(x, targets)
+        res.append((float(out["total_loss"]), st.plan.arena.clone(),
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    assert set(st.plan.programs) == {"fwd", "bwd"}
+    for l, g, r in res[1:]:
+        assert abs(l - res[0][0]) / abs(res[0][0]) < 1e-6
+        assert _rel(g, res[0][1]) < 1e-5
+        for k in r:
+            assert _rel(r[k], res[0][2][k]) < 1e-6
+    # the tape re-reads the parameters every step: scaled weights change the loss
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(0.5)
+    out = st.step(x, targets)
+    assert abs(float(out["total_loss"]) - res[0][0]) / abs(res[0][0]) > 1e-3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt,ltol", [("fp32", 1e-3), ("bf16", 5e-2)])
 def test_train_step_s_160x256(golden_dir, dt, ltol):
@@ -98,7 +125,7 @@ def test_train_step_s_160x256(golden_dir, dt, ltol):
 @pytest.mark.gpu
 def test_overlapped_step_matches_single_stream(golden_dir):
     """Step 1 runs on one stream (kernel tuning); later steps put the support frame, two head levels and every
-    weight gradient on a side stream.  Same inputs, same weights: losses, gradients and BatchNorm running
+    weight gradient on a side stream, and TrainStep finally replays the whole step from a hipGraph.  Same inputs, same weights: losses, gradients and BatchNorm running
     statistics must match the single-stream pass (fp32; BN partial sums are atomically folded, hence 1e-4)."""
     from streamyolo_amd import _lib
     from streamyolo_amd.train_engine import TrainStep
@@ -108,12 +135,14 @@ def test_overlapped_step_matches_single_stream(golden_dir):
     st = TrainStep(model)
     state0 = {k: v.clone() for k, v in model.state_dict().items()}
     res = []
-    for mode in ("tune", "serial", "overlap", "overlap"):
+    for mode in ("tune", "serial", "overlap", "overlap", "graph", "graph", "graph"):
         model.load_state_dict(state0)
+        st.use_graph = (mode == "graph")
         if mode != "tune":
             assert st.plan.side is not None and st.plan.tuned
             st.plan.force_serial = (mode == "serial")
         out = st.step(x, targets)
+        assert (st.graph is not None) == (mode == "graph")
         torch.cuda.synchronize()
         res.append((mode, float(out["total_loss"]), st.plan.arena.clone(),
                     {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
