@@ -4,7 +4,10 @@
 // exps/train_utils/double_trainer.py:114).
 //
 // GEMM view:  dW[co][k] += sum_p  dY[p][co] * X[gather(p, tap)][ci],    k = (tap, ci)
-// The contraction index is the PIXEL, which is the slow axis of both NHWC operands, so both tiles
+// The contraction index is the PIXEL, which is the slow axis of both NHWC operands.  Two staging schemes:
+//  * 16-bit types (the production path, conv_wgrad_tr_kernel below): tiles land in LDS untransposed by LDS-DMA
+//    and the K-major fragments are gathered with ds_read_b64_tr_b16 — 1.6-2x the scatter kernel on MI355X;
+//  * fp32 (parity runs) and shapes the first scheme does not cover (conv_wgrad_kernel): both tiles
 // are transposed on their way into LDS: a lane loads 16 bytes (8 / 4 consecutive channels of one
 // pixel) and scatters them as 32-bit words into channel-major rows [channel][pixel] (two adjacent
 // pixels are packed per word for 16-bit types).  Row pitch 72 B: the scatter is at most 2-way bank
@@ -57,6 +60,45 @@ struct PixelCursor {            // (n, ho, wo) of one output pixel, advanced sla
         }
     }
 };
+
+// ---- epilogue: D[row = k][col = co].  One split: every dW element belongs to exactly one workgroup, so a
+//      plain += into dW is race free.  Several splits: each writes its tile to a private slab (16-byte
+//      stores, no atomics) and wgrad_fold_kernel sums the slabs into dW.
+template <int TR, int TC>
+__device__ __forceinline__ void wgrad_epilogue(const WgradArgs& p, f32x16 (&acc)[TR][TC], int r0, int c0, int wr, int wcn,
+                                               int lane) {
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const int taps = p.KH * p.KW;
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+        for (int u = 0; u < TC; ++u) {
+            const int co = c0 + (wcn * TC + u) * 32 + l31;
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kb = r0 + (wr * TR + t) * 32 + q * 8 + half * 4;
+                if (kb >= p.K) continue;                       // Cin % 4 == 0: the quad shares one tap and K % 4 == 0
+                const float v0 = acc[t][u][q * 4 + 0], v1 = acc[t][u][q * 4 + 1], v2 = acc[t][u][q * 4 + 2],
+                            v3 = acc[t][u][q * 4 + 3];
+                if (p.splits > 1) {
+                    float* dst = p.part + ((long long)blockIdx.z * p.Cout + co) * p.K + kb;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+                } else if (p.oihw) {
+                    const int tap = kb / p.Cin;
+                    const int ci = kb - tap * p.Cin;
+                    float* row = p.dw + (long long)co * p.K + (long long)ci * taps + tap;
+                    row[0] += v0; row[taps] += v1; row[2 * taps] += v2; row[3 * taps] += v3;
+                } else {
+                    float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co * p.K + kb);
+                    float4 o = *dst;
+                    o.x += v0; o.y += v1; o.z += v2; o.w += v3;
+                    *dst = o;
+                }
+            }
+        }
+}
 
 template <typename T, int WR, int WC, int TR, int TC>
 __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
@@ -248,39 +290,143 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
         }
     }
 
-    // ---- epilogue: D[row = k][col = co].  One split: every dW element belongs to exactly one workgroup, so a
-    //      plain += into dW is race free.  Several splits: each writes its tile to a private slab (16-byte
-    //      stores, no atomics) and wgrad_fold_kernel sums the slabs into dW.
-    const int half = lane >> 5;
-    const int taps = p.KH * p.KW;
+    wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane);
+}
+
+// ---- transpose-read variant (16-bit types) ------------------------------------------------------------------
+// Both operand tiles land in LDS exactly as they lie in HBM — row-major [pixel][channel] — by LDS-DMA, and the
+// K-major MFMA fragments are gathered with ds_read_b64_tr_b16 (sy_lds_read_tr16): no register round trip, no
+// scatter, and the loads of the next slabs stay in flight behind the MFMAs (ring of STG slabs).
+// LDS image of one slab: (RT + CT) / 16 subtiles of [32 pixels][16 channels] (1 KiB, one DMA wave instruction:
+// lane = (pixel, 16-byte half)), 128 B of padding between subtiles so that the two subtiles a half-wave reads
+// (MFMA rows 0-15 / 16-31) fall on disjoint banks.  Requires Cin % 16 == 0 and Cout % 16 == 0 (a subtile never
+// straddles a tap) and buffer-addressable operands.
+constexpr int kSubPitch = 1024 + 128;
+
+template <typename T, int WR, int WC, int TR, int TC, int STG>
+__global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
+    constexpr int RT = WR * TR * 32, CT = WC * TC * 32;
+    constexpr int SA = RT / 16, SB = CT / 16, NS = SA + SB;
+    constexpr int STAGE = NS * kSubPitch;
+    constexpr int SLAB = 32;
+    static_assert(WR * WC == 4 && NS % 4 == 0 && T::kEPC == 8, "4 waves, whole DMA rounds, 16-bit elements");
+    SY_DYN_SMEM(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WC;
+    const int wcn = wave % WC;
+    const int r0 = blockIdx.x * RT;
+    const int c0 = blockIdx.y * CT;
+    const int slab0 = blockIdx.z * p.slabs_per_split;
+    int nslab = p.slabs_per_split;
+    const int slabs_total = (p.M + SLAB - 1) / SLAB;
+    if (slab0 + nslab > slabs_total) nslab = slabs_total - slab0;
+    if (nslab <= 0) return;
+
+    // ---- DMA assignment: wave w fills X subtiles w + 4 j (j < LA) and dY subtiles w + 4 j (j < LB).
+    //      Lane -> (pixel lane>>1, 16-byte channel half lane&1).
+    constexpr int LA = SA / 4, LB = SB / 4;
+    static_assert(SA % 4 == 0 && SB % 4 == 0, "every wave stages the same number of subtiles of each operand");
+    const int wv = sy_uniform(wave);
+    const int half8 = (lane & 1) * 8;
+    bool a_ok[LA], b_ok[LB];
+    int a_dh[LA], a_dw[LA], a_rel[LA], b_rel[LB];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int k = r0 + (wv + 4 * j) * 16;
+        a_ok[j] = k < p.K;
+        const int kk = a_ok[j] ? k : 0;
+        const int tap = kk / p.Cin;
+        const int ci = kk - tap * p.Cin;
+        a_dh[j] = tap / p.KW;
+        a_dw[j] = tap - a_dh[j] * p.KW;
+        a_rel[j] = (a_dh[j] * p.W + a_dw[j]) * p.ldx + ci + half8;
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int co = c0 + (wv + 4 * j) * 16;
+        b_ok[j] = co < p.Cout;
+        b_rel[j] = co + half8;
+    }
+    const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
+    const sy_buffer bufdy = sy_make_buffer(p.dy, p.dy_extent);
+    const sy_lds_base_t lds0 = sy_lds_base(smem);
+    PixelCursor cur;
+    cur.init(slab0 * SLAB + (lane >> 1), p.Ho, p.Wo);
+
+    int issued = 0, stage_w = 0;
+    auto issue_slab = [&]() {
+        const unsigned stage = (unsigned)(stage_w * STAGE + wv * kSubPitch);
+        const bool m_ok = cur.m < p.M;
+        const int hb = cur.ho * p.stride - p.pad, wb = cur.wo * p.stride - p.pad;
+        const int xo = cur.n * (int)p.xbs + (hb * p.W + wb) * p.ldx;
+        const int yo = cur.n * (int)p.dybs + (cur.ho * p.Wo + cur.wo) * p.lddy;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int hi = hb + a_dh[j], wi = wb + a_dw[j];
+            const bool ok = m_ok && a_ok[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            sy_glds16_buf_at(bufx, ok ? (unsigned)((xo + a_rel[j]) * 2) : 0xFFFFFFFFu, lds0, stage + 4 * j * kSubPitch);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j)
+            sy_glds16_buf_at(bufdy, (m_ok && b_ok[j]) ? (unsigned)((yo + b_rel[j]) * 2) : 0xFFFFFFFFu, lds0,
+                             stage + (SA + 4 * j) * kSubPitch);
+        cur.advance(SLAB, p.Ho, p.Wo);
+        ++issued;
+        stage_w = (stage_w + 1 == STG) ? 0 : stage_w + 1;
+    };
+    auto wait_slab = [&](int ahead) {             // at most `ahead` later slabs of this wave's loads still in flight
+        constexpr int LJ2 = LA + LB;
+        if (ahead >= 3) sy_wait_vmcnt<3 * LJ2>();
+        else if (ahead == 2) sy_wait_vmcnt<2 * LJ2>();
+        else if (ahead == 1) sy_wait_vmcnt<LJ2>();
+        else sy_wait_vmcnt<0>();
+    };
+
+    f32x16 acc[TR][TC];
 #pragma unroll
     for (int t = 0; t < TR; ++t)
 #pragma unroll
-        for (int u = 0; u < TC; ++u) {
-            const int co = c0 + (wcn * TC + u) * 32 + l31;
-            if (co >= p.Cout) continue;
+        for (int u = 0; u < TC; ++u)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int kb = r0 + (wr * TR + t) * 32 + q * 8 + half * 4;
-                if (kb >= p.K) continue;                       // Cin % 4 == 0: the quad shares one tap and K % 4 == 0
-                const float v0 = acc[t][u][q * 4 + 0], v1 = acc[t][u][q * 4 + 1], v2 = acc[t][u][q * 4 + 2],
-                            v3 = acc[t][u][q * 4 + 3];
-                if (p.splits > 1) {
-                    float* dst = p.part + ((long long)blockIdx.z * p.Cout + co) * p.K + kb;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
-                } else if (p.oihw) {
-                    const int tap = kb / p.Cin;
-                    const int ci = kb - tap * p.Cin;
-                    float* row = p.dw + (long long)co * p.K + (long long)ci * taps + tap;
-                    row[0] += v0; row[taps] += v1; row[2 * taps] += v2; row[3 * taps] += v3;
-                } else {
-                    float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co * p.K + kb);
-                    float4 o = *dst;
-                    o.x += v0; o.y += v1; o.z += v2; o.w += v3;
-                    *dst = o;
-                }
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    // fragment gather: lane (g = lane>>5, parity = (lane>>4)&1, i = lane&15) addresses pixel row 8g + (i>>2)
+    // [+4 for the second half of its 8 k-values], column quad i&3 of subtile 2*tile + parity
+    const int lane_off = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+
+    for (int j = 0; j < STG - 1 && j < nslab; ++j) issue_slab();
+    int stage_r = 0;
+    for (int s = 0; s < nslab; ++s) {
+        wait_slab(issued - s - 1);
+        sy_barrier();                             // slab s complete for every wave; everyone is past slab s-1
+        if (issued < nslab) issue_slab();
+        const unsigned char* const base = smem + stage_r * STAGE + lane_off;
+        stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 a[TR], b[TC];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                const unsigned char* ptr = base + ((wr * TR + t) * 2) * kSubPitch + ks * 512;
+                const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
+                a[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
+#pragma unroll
+            for (int u = 0; u < TC; ++u) {
+                const unsigned char* ptr = base + (SA + (wcn * TC + u) * 2) * kSubPitch + ks * 512;
+                const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
+                b[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int t = 0; t < TR; ++t)
+#pragma unroll
+                for (int u = 0; u < TC; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
         }
+    }
+    wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane);
 }
 
 // dW (+)= sum over splits of the partial slabs; also applies the packed -> OIHW layout change.
@@ -319,7 +465,27 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
     }
 }
 
-template <typename T, int WR, int WC, int TR, int TC>
+template <typename T, int WR, int WC, int TR, int TC, int STG>
+int launch_tr_kernel(const WgradArgs& a, dim3 grid, void* stream) {
+    if constexpr (T::kEPC == 8 && ((WR * TR + WC * TC) * 2) % 4 == 0) {
+        constexpr size_t smem = (size_t)STG * ((WR * TR + WC * TC) * 2) * kSubPitch;
+#ifndef SY_EMU
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<T, WR, WC, TR, TC, STG>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                return SY_ERR_LAUNCH;
+            attr_done = true;
+        }
+#endif
+        SY_LAUNCH((conv_wgrad_tr_kernel<T, WR, WC, TR, TC, STG>), grid, dim3(kThreadsW), smem, stream, a);
+        return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+    } else {
+        return SY_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T, int WR, int WC, int TR, int TC, int TRV = 0>
 int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     constexpr int RT = WR * TR * 32, CT = WC * TC * 32, SLAB = 4 * T::kEPC;
     const int gx = (a.K + RT - 1) / RT, gy = (a.Cout + CT - 1) / CT;
@@ -336,7 +502,18 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     a.slabs_per_split = (slabs_total + splits - 1) / splits;
     splits = (slabs_total + a.slabs_per_split - 1) / a.slabs_per_split;
     a.splits = splits;
-    SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
+    if constexpr (TRV != 0) {
+        // transpose-read variant preconditions; otherwise the scatter kernel of the same tile runs
+        const bool tr_ok = T::kEPC == 8 && a.Cin % 16 == 0 && a.Cout % 16 == 0 && a.x_extent != 0 && a.dy_extent != 0;
+        if (tr_ok) {
+            const int rc = launch_tr_kernel<T, WR, WC, TR, TC, TRV>(a, dim3(gx, gy, splits), stream);
+            if (rc != SY_OK) return rc;
+        } else {
+            SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
+        }
+    } else {
+        SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
+    }
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
     if (splits > 1) {
         const long long work = (long long)a.Cout * a.K;
@@ -363,10 +540,19 @@ int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
         case 4: return launch_wgrad_cfg<T, 2, 2, 1, 1>(a, ws_bytes, stream);   //  64 x  64
         case 5: return launch_wgrad_cfg<T, 1, 4, 2, 1>(a, ws_bytes, stream);   //  64 x 128
         case 6: return launch_wgrad_cfg<T, 2, 2, 1, 2>(a, ws_bytes, stream);   //  64 x 128 (2x2 waves)
+        // + 16: transpose-read variants (LDS-DMA ring of 3 slabs + ds_read_b64_tr_b16), + 32: ring of 4
+        case 17: return launch_wgrad_cfg<T, 2, 2, 2, 2, 3>(a, ws_bytes, stream);
+        case 18: return launch_wgrad_cfg<T, 4, 1, 1, 2, 3>(a, ws_bytes, stream);
+        case 20: return launch_wgrad_cfg<T, 2, 2, 1, 1, 3>(a, ws_bytes, stream);
+        case 21: return launch_wgrad_cfg<T, 1, 4, 2, 1, 3>(a, ws_bytes, stream);
+        case 22: return launch_wgrad_cfg<T, 2, 2, 1, 2, 3>(a, ws_bytes, stream);
+        case 33: return launch_wgrad_cfg<T, 2, 2, 2, 2, 4>(a, ws_bytes, stream);
+        case 34: return launch_wgrad_cfg<T, 4, 1, 1, 2, 4>(a, ws_bytes, stream);
         default: break;
     }
-    if (a.Cout > 64) return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);     // 128 k x 128 co
-    if (a.Cout > 32) return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);     // 128 k x  64 co
+    // defaults: transpose-read variants (they fall back to the scatter kernel of the same tile when not applicable)
+    if (a.Cout > 64) return launch_wgrad_cfg<T, 2, 2, 2, 2, 3>(a, ws_bytes, stream);  // 128 k x 128 co
+    if (a.Cout > 32) return launch_wgrad_cfg<T, 4, 1, 1, 2, 3>(a, ws_bytes, stream);  // 128 k x  64 co
     return launch_wgrad_cfg<T, 4, 1, 1, 1>(a, ws_bytes, stream);                      // 128 k x  32 co
 }
 

@@ -117,6 +117,32 @@ template <int N> __device__ __forceinline__ void sy_wait_vmcnt() { asm volatile(
 __device__ __forceinline__ void sy_barrier() { __builtin_amdgcn_s_barrier(); }
 #endif
 
+// ---- LDS transpose read (ds_read_b64_tr_b16) ---------------------------------------------------------
+// Per 16-lane group: lane i supplies the 8-byte-aligned address of 4 consecutive 16-bit elements (row i>>2,
+// column quad i&3 of a [4 rows][16 cols] block whose row pitch the addresses imply) and receives COLUMN i:
+// element j of the result = block[row j][col i].  A K-major MFMA fragment straight out of a row-major
+// [pixel][channel] LDS image — the transpose the weight-gradient GEMM needs (its contraction index is the pixel).
+#ifdef SY_EMU
+static inline uint2 sy_lds_read_tr16(const unsigned char* p) {
+    unsigned long long mine;
+    __builtin_memcpy(&mine, p, 8);
+    uint2 out = make_uint2(0u, 0u);
+    const int lane = emu::lane_id(), G = lane >> 4, i = lane & 15;
+    emu::wave_exchange(&mine, 8, [&](unsigned char (*s)[64]) {
+        unsigned short e[4];
+        for (int j = 0; j < 4; ++j) __builtin_memcpy(&e[j], s[G * 16 + j * 4 + (i >> 2)] + (i & 3) * 2, 2);
+        __builtin_memcpy(&out, e, 8);
+    });
+    return out;
+}
+#else
+__device__ __forceinline__ uint2 sy_lds_read_tr16(const unsigned char* p) {
+    typedef short sy_v4s __attribute__((ext_vector_type(4)));
+    const sy_v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sy_v4s*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+#endif
+
 // ---- bounds-checked 16-byte buffer loads -------------------------------------------------------------
 // A buffer descriptor (base, extent) + a 32-bit byte offset per lane: the address math of a gather is one
 // integer add, and an offset >= extent (we use 0xFFFFFFFF) returns zeros — convolution padding for free.
@@ -153,6 +179,37 @@ __device__ __forceinline__ void sy_glds16_buf(const sy_buffer& b, unsigned voff,
                  : "v"(voff), "s"(b), "s"(dst)
                  : "memory");
 }
+#endif
+
+// LDS-DMA with the destination given as (wave-uniform LDS base, byte offset): the base is resolved to an LDS address
+// once per kernel (sy_lds_base), so the per-load destination math is scalar adds — no generic->LDS pointer cast
+// (and its null check) in the loop.
+#ifdef SY_EMU
+typedef unsigned char* sy_lds_base_t;
+static inline sy_lds_base_t sy_lds_base(unsigned char* p) { return p; }
+static inline void sy_glds16_buf_at(const sy_buffer& b, unsigned voff, sy_lds_base_t base, unsigned off) {
+    sy_glds16_buf(b, voff, base + off);
+}
+#else
+typedef unsigned sy_lds_base_t;
+__device__ __forceinline__ sy_lds_base_t sy_lds_base(unsigned char* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)p);
+}
+__device__ __forceinline__ void sy_glds16_buf_at(const sy_buffer& b, unsigned voff, sy_lds_base_t base, unsigned off) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(base + off);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(b), "s"(dst)
+                 : "memory");
+}
+#endif
+
+// wave-uniform value hint (lets hipcc keep per-wave constants in SGPRs and branch on them with SALU)
+#ifdef SY_EMU
+static inline int sy_uniform(int v) { return v; }
+#else
+__device__ __forceinline__ int sy_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
 // ---- small math ---------------------------------------------------------------------------------

@@ -390,7 +390,9 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     return best
 
 
-_WGRAD_CANDIDATES = [(0, 0), (1, 1024), (1, 2048), (2, 512), (2, 1024), (4, 1024), (6, 1024)]
+# tile codes 1-6: scatter-transposed staging; +16 / +32: LDS-DMA ring (3 / 4 slabs) + ds_read_b64_tr_b16 fragments
+_WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 1024), (33, 1024), (18, 512), (18, 1024),
+                     (20, 1024), (22, 1024), (21, 1024)]
 _wgrad_cache = {}
 
 
@@ -408,9 +410,9 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
     dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
     best, best_t = (0, 0), float("inf")
     for (t, tb) in _WGRAD_CANDIDATES:
-        if t in (1, 6) and Cout < 128:
+        if (t & 15) in (1, 5, 6) and Cout < 128:
             continue
-        if t == 2 and Cout < 64:
+        if (t & 15) == 2 and Cout < 64:
             continue
         try:
             conv2d_wgrad(x, dy, dw, k, stride, oihw=True, workspace=workspace, tile=t, target_blocks=tb)

@@ -122,7 +122,7 @@ def test_conv_stats_dgrad_wgrad(backend, dt, cin, cout, k, stride, H, W, N):
     ops.conv2d_wgrad(xv, dyv, dw2, k, stride, oihw=True, workspace=ws)
     assert _rel(dw2.cpu(), 2 * w.grad) < TOL[dt]
     # every wgrad workgroup tile
-    for t in (1, 2, 3, 4, 5, 6):
+    for t in (1, 2, 3, 4, 5, 6, 17, 18, 20, 21, 22, 33, 34):   # +16 / +32: transpose-read variants
         dw3 = torch.zeros(cout, k * k * cin, device=backend)
         ops.conv2d_wgrad(xv, dyv, dw3, k, stride, workspace=ws, tile=t, target_blocks=8)
         assert _rel(dw3.cpu(), ref_dw) < TOL[dt], "wgrad tile %d" % t

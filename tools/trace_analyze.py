@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Timeline summary of a rocprofv3 --kernel-trace CSV: for the last full training step (delimited by
+pack_weights_kernel launches) report wall time, union-busy time, per-queue busy time, idle gaps and the
+per-kernel-family totals.  Usage: python tools/trace_analyze.py <kernel_trace.csv>"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
+rows.sort()
+marks = [i for i, r in enumerate(rows) if "pack_weights_kernel" in r[2]]
+if len(marks) < 2:
+    print("no step delimiters found"); sys.exit(0)
+a, b = marks[-2], marks[-1]
+step = rows[a:b]
+t0, t1 = step[0][0], max(r[1] for r in step)
+print("kernels in step: %d   wall %.3f ms" % (len(step), (t1 - t0) / 1e6))
+# union busy
+ev = sorted((s, e) for s, e, _, _ in step)
+busy, cur_s, cur_e = 0, ev[0][0], ev[0][1]
+gaps = []
+for s, e in ev[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s
+        gaps.append(s - cur_e)
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+print("union busy %.3f ms, idle %.3f ms in %d gaps (median gap %.1f us)" % (busy / 1e6, sum(gaps) / 1e6, len(gaps),
+                                                                        sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0))
+print("sum of kernel durations %.3f ms" % (sum(e - s for s, e, _, _ in step) / 1e6))
+perq = defaultdict(lambda: [0, 0])
+for s, e, n, q in step:
+    perq[q][0] += 1; perq[q][1] += e - s
+for q, (n, d) in perq.items():
+    print("queue %s: %d kernels, %.3f ms busy" % (q, n, d / 1e6))
+fam = defaultdict(lambda: [0, 0])
+for s, e, n, q in step:
+    m = re.search(r"(\w+_kernel|\w+)(<[^>]*>)?\(", n)
+    key = re.sub(r"^void ", "", n.split("(")[0])[:70]
+    fam[key][0] += 1; fam[key][1] += e - s
+for k, (n, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:28]:
+    print("%9.3f ms %5d  %s" % (d / 1e6, n, k))

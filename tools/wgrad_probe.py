@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    variants = [(0, 0), (1, 256), (1, 512), (1, 1024), (2, 512), (4, 512), (4, 1024), (6, 512), (5, 512)]
+    variants = [(1, 1024), (2, 512), (4, 1024), (17, 512), (17, 1024), (33, 1024), (18, 512), (18, 1024), (34, 1024), (20, 1024), (22, 1024), (21, 1024)]
     sel = [int(i) for i in a.shapes.split(",")] if a.shapes else range(len(SHAPES))
     ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     print("%-10s %-28s " % ("layer", "shape") + " ".join("%9s" % ("t%d/%d" % v) for v in variants) + "   (TFLOP/s)")
@@ -31,7 +31,7 @@ def main():
         flops = 2.0 * cin * cout * k * k * dy.pixels
         res = []
         for (t, tb) in variants:
-            if t in (1, 5, 6) and cout < 128 and t != 0:
+            if (t & 15) in (1, 5, 6) and cout < 128 and t != 0:
                 res.append(float("nan")); continue
             try:
                 ops.conv2d_wgrad(x, dy, dw, k, st, oihw=True, workspace=ws, tile=t, target_blocks=tb)
