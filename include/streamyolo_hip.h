@@ -75,6 +75,8 @@ typedef struct sy_conv_desc {
     int32_t accumulate;                 /* 1: y += result (gradient fan-in)                      */
     float dec_stride;                   /* SY_EPI_DECODE: the level's stride (8/16/32)           */
     int32_t stat_copies;                /* stat arrays hold this many replicas [copies][Cout] (>=1) */
+    int32_t stat_segments;              /* 0/1: one set of statistics; S > 1: the N images form S equal groups with
+                                           separate statistics, arrays [S][copies][Cout] (N % S == 0) */
     int32_t tile;                       /* SY_TILE_AUTO or a forced workgroup tile (channels x pixels) */
     int64_t x_bytes, w_bytes;           /* bytes addressable from x / w (buffer bounds of the fast gather; 0 = unknown) */
     const void* wfrag;                  /* optional: weights re-packed in MFMA-fragment order (SY_TILE_WR variants) */
@@ -152,12 +154,19 @@ typedef struct sy_pack_entry {
 } sy_pack_entry;
 SY_API int sy_pack_weights(const sy_pack_entry* entries, int n_entries, void* stream);
 
-/* Training-mode BatchNorm helpers around sy_conv2d(stat_sum/stat_sqsum).
+/* SEGMENTS (nseg >= 1): the two frames of a pair pass through the shared backbone separately in the reference, so each
+ * BatchNorm normalises them with separate batch statistics (dfp_pafpn.py:120-165).  Here both frames run in ONE launch
+ * per layer: segment s owns rows [s*pixels, (s+1)*pixels) of every activation view (`pixels` = rows PER segment,
+ * `count` likewise), its own statistics [s][copies][C] / sums [s][copies][2][C] and its own affine / mean / invstd
+ * [s][C]; gamma, beta, dgamma, dbeta are shared.  sy_conv2d's stat_segments splits its pixel range the same way.
+ * nseg = 1 is an ordinary single-call BatchNorm.
+ *
+ * Training-mode BatchNorm helpers around sy_conv2d(stat_sum/stat_sqsum).
  * Replaces nn.BatchNorm2d in training mode (momentum/eps patched by init_yolo, cfgs/<name>.py:40-44). */
 SY_API int sy_bn_finalize(const float* sum, const float* sqsum, int C, int copies, double count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* scale, float* shift, float* mean, float* invstd,
-                   void* stream);
+                   int nseg, void* stream);
 /* Running-statistics update of MANY BatchNorm modules in one launch, from the same replica arrays sy_bn_finalize
  * folds (pass running_mean = NULL there).  Entry i describes one nn.BatchNorm2d and the 1 or 2 calls it received
  * this step IN CALL ORDER (the backbone / neck modules are called once per frame, current frame first —
@@ -175,19 +184,19 @@ typedef struct sy_bn_running_entry {
 SY_API int sy_bn_running_update(const sy_bn_running_entry* entries, int n_entries, int max_C, void* stream);
 /* a = silu(scale*y + shift) [+ res], y raw conv output; views as in sy_conv2d. */
 SY_API int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res,
-                     int ldr, void* out, int ldo, int64_t pixels, int C, int dtype, void* stream);
+                     int ldr, void* out, int ldo, int64_t pixels, int C, int dtype, int nseg, void* stream);
 /* Backward of (BN-train + SiLU): reduce pass then apply pass.
  * reduce: sums[r][0][c] += sum dz, sums[r][1][c] += sum dz*xhat over replica r = workgroup % copies,
  * with dz = da * silu'(scale*y+shift). */
 SY_API int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                  const float* shift, const float* mean, const float* invstd, float* sums,
-                                 int copies, int64_t pixels, int C, int dtype, void* stream);
+                                 int copies, int64_t pixels, int C, int dtype, int nseg, void* stream);
 /* apply: dy = gamma*invstd*(dz - S0/M - xhat*S1/M) with S = sums folded over its `copies` replicas
  * ([copies][2][C]); optionally dgamma += S1, dbeta += S0. */
 SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                 const float* shift, const float* mean, const float* invstd,
                                 const float* gamma, const float* sums, int copies, void* dy, int lddy,
-                                int64_t pixels, int C, float* dgamma, float* dbeta, int dtype, void* stream);
+                                int64_t pixels, int C, float* dgamma, float* dbeta, int dtype, int nseg, void* stream);
 
 /* SimOTA assignment + Trend-Aware loss, forward and gradient, for a whole batch, no host sync.
  * raw [B, A, 5+nc] fp32 raw head logits (reg4, obj, cls); labels/support [B, max_labels, 5] fp32 rows

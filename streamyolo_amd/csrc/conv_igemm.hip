@@ -29,12 +29,18 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.y_f32 = d->y_f32; a.mode = d->mode; a.epilogue = d->epilogue; a.accumulate = d->accumulate;
     a.dec_stride = d->dec_stride;
     a.stat_copies = d->stat_copies > 0 ? d->stat_copies : 1;
+    a.seg_M = 0;
+    a.s2_classes = 0;
+    if (d->stat_segments > 1) {
+        if (d->stat_sum == nullptr || d->N % d->stat_segments != 0 || d->mode != SY_CONV_FWD) return SY_ERR_ARG;
+        a.seg_M = (d->N / d->stat_segments) * d->Ho * d->Wo;
+    }
     a.x_extent = (d->x_bytes > 0 && d->x_bytes < 0xFFFFFFF0LL) ? (unsigned)d->x_bytes : 0u;
     a.w_extent = (d->w_bytes > 0 && d->w_bytes < 0xFFFFFFF0LL) ? (unsigned)d->w_bytes : 0u;
     a.wfrag = (const unsigned char*)d->wfrag;
     a.wfrag_extent = (d->wfrag != nullptr && d->wfrag_bytes > 0 && d->wfrag_bytes < 0xFFFFFFF0LL) ? (unsigned)d->wfrag_bytes : 0u;
     a.tile = d->tile & 0xff;
-    a.ablate = (d->tile >> 8) & 3;
+    a.ablate = (d->tile >> 8) & 7;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return sy_conv_launch_bf16(a, stream);

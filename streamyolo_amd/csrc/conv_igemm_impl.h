@@ -53,6 +53,8 @@ struct ConvArgs {
     float dec_stride;
     int M, K, HoWo;
     int stat_copies;            // replicas of the statistics arrays (atomic-contention control)
+    int seg_M;                  // > 0: pixels per statistics segment (gridDim.z segments, tiles never straddle one)
+    int s2_classes;             // stride-2 data gradient split into 4 output-parity classes (gridDim.z), see the kernel
     int tile;                   // 0 = heuristic, else a forced tile configuration (tests / tuning)
     unsigned x_extent, w_extent; // bytes addressable from x / w (FAST loader's buffer bounds)
     const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
@@ -96,7 +98,20 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     const int wc = wave / WP;
     const int wp = wave % WP;
     const int c0 = blockIdx.x * CT;
-    const int m0 = blockIdx.y * PT;
+    // statistics segments (training forward of a frame pair): segment z owns pixels [z * seg_M, (z + 1) * seg_M)
+    // Stride-2 data gradient: an output pixel (ho, wo) only receives the taps with kh = ho + pad, kw = wo + pad (mod 2)
+    // — a 3x3 kernel has 1, 2, 2 or 4 of them, never 9.  gridDim.z enumerates the four parity classes; a workgroup
+    // tiles the half-resolution grid of ITS class and walks only that class's taps, so no MFMA multiplies padding.
+    int cls_ph = 0, cls_pw = 0, Hc = p.Ho, Wc = p.Wo, cls_M = p.M;
+    if (p.s2_classes) {
+        cls_ph = (int)blockIdx.z >> 1; cls_pw = (int)blockIdx.z & 1;
+        Hc = (p.Ho - cls_ph + 1) >> 1; Wc = (p.Wo - cls_pw + 1) >> 1;
+        cls_M = p.N * Hc * Wc;
+        if ((int)blockIdx.y * PT >= cls_M) return;              // uniform: the smaller classes need fewer tiles
+    }
+    const int cls_hw = Hc * Wc;
+    const int m_end = p.seg_M > 0 ? ((int)blockIdx.z + 1) * p.seg_M : cls_M;
+    const int m0 = (p.s2_classes ? 0 : (int)blockIdx.z * p.seg_M) + blockIdx.y * PT;
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
@@ -112,12 +127,13 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     // output pixel of staged row i -> image index and gather origin
     auto row_geom = [&](int i, bool& ok, long long& base, int& h0, int& w0) {
         const int m = m0 + row0 + i * RPI;
-        ok = (m < p.M);
+        ok = (m < m_end);
         const int mm = ok ? m : 0;
-        const int n = mm / p.HoWo;
-        const int rem = mm - n * p.HoWo;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
+        const int n = mm / cls_hw;
+        const int rem = mm - n * cls_hw;
+        int ho = rem / Wc;
+        int wo = rem - ho * Wc;
+        if (p.s2_classes) { ho = 2 * ho + cls_ph; wo = 2 * wo + cls_pw; }
         base = (long long)n * p.xbs;
         if (p.mode == SY_CONV_FWD) { h0 = ho * p.stride - p.pad; w0 = wo * p.stride - p.pad; }
         else { h0 = ho + p.pad; w0 = wo + p.pad; }
@@ -140,7 +156,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
-    const int nslab = (p.K + BK - 1) / BK;
+    const int nslab_all = (p.K + BK - 1) / BK;                 // K slabs of the whole filter (fragment-packed weight pitch)
+    const int kh0 = p.s2_classes ? ((cls_ph + p.pad) & 1) : 0, kw0 = p.s2_classes ? ((cls_pw + p.pad) & 1) : 0;
+    const int kstep = p.s2_classes ? 2 : 1;
+    // slabs this workgroup walks: all of them, or (class taps) x (channel slabs)
+    const int nslab = p.s2_classes ? ((p.KH - kh0 + 1) / 2) * ((p.KW - kw0 + 1) / 2) * (p.Cin / BK) : nslab_all;
 
     // one slab of MFMAs from LDS rows `bw`/`bx` with row pitch PITCH and per-lane 16-byte slot selector
     auto compute_slab = [&](const unsigned char* bw, const unsigned char* bx, int pitch, int swz) {
@@ -185,8 +205,8 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
             const int co = c0 + r;
             woff[i] = (r < CT && co < p.Cout && !(p.ablate & 2)) ? (unsigned)(((long long)co * p.K + kc * EPC) * ESZ) : 0xFFFFFFFFu;
         }
-        int f_kh = 0, f_kw = 0, f_c = 0, f_t = 0;          // wave-uniform K position of the next slab to fetch
-        unsigned s_x = 0, s_w = 0;
+        int f_kh = kh0, f_kw = kw0, f_c = 0, f_t = kh0 * p.KW + kw0, f_cs = 0;   // wave-uniform K position of the next slab to fetch
+        unsigned s_x = 0, s_w = 0, s_f = 0;
         auto slab_offsets = [&]() {                          // uniform offsets of slab (f_t, f_c); then advance
             int dpix;
             if (p.mode == SY_CONV_FWD) dpix = f_kh * p.W + f_kw;
@@ -194,10 +214,16 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
             else dpix = -(f_kh * p.W + f_kw);
             s_x = (unsigned)((dpix * p.ldx + f_c) * ESZ);
             s_w = (unsigned)((f_t * p.Cin + f_c) * ESZ);
+            s_f = (unsigned)((f_cs * ntaps + f_t) * 2048);   // fragment-packed weights: [cslab][tap] blocks of 2 KiB
         };
         auto advance = [&]() {
-            ++f_t;
-            if (++f_kw == p.KW) { f_kw = 0; if (++f_kh == p.KH) { f_kh = 0; f_t = 0; f_c += BK; } }
+            f_kw += kstep;
+            if (f_kw >= p.KW) {
+                f_kw = kw0;
+                f_kh += kstep;
+                if (f_kh >= p.KH) { f_kh = kh0; f_c += BK; ++f_cs; }
+            }
+            f_t = f_kh * p.KW + f_kw;
         };
         if constexpr (WR) {
             // ---- weights straight to VGPRs.  The host packs them in MFMA-fragment order along the kernel's own
@@ -209,21 +235,19 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
 #pragma unroll
             for (int t = 0; t < TC; ++t) {
                 const int ct = (int)blockIdx.x * (CT / 32) + wc * TC + t;
-                foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * nslab) * 128 + lane) * 16) : 0xFFFFFFFFu;
+                foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * nslab_all) * 128 + lane) * 16) : 0xFFFFFFFFu;
             }
             uint4 fa[TC][2], fn[TC][2], rx[XCH];
-            int seq = 0;
             auto load_slab = [&]() {
                 slab_offsets();
 #pragma unroll
                 for (int t = 0; t < TC; ++t)
 #pragma unroll
                     for (int g = 0; g < 2; ++g)
-                        fn[t][g] = sy_buffer_load16(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + (unsigned)((seq * 2 + g) * 1024));
+                        fn[t][g] = sy_buffer_load16(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + s_f + (unsigned)(g * 1024));
 #pragma unroll
                 for (int i = 0; i < XCH; ++i) rx[i] = sy_buffer_load16(bufx, ((xmask[i] >> f_t) & 1u) ? xoff[i] + s_x : 0xFFFFFFFFu);
                 advance();
-                ++seq;
             };
             auto store_slab = [&]() {
 #pragma unroll
@@ -448,10 +472,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
 #pragma unroll
         for (int u = 0; u < TP; ++u) {
             const int m = m0 + (wp * TP + u) * 32 + l31;
-            const bool m_ok = m < p.M;
+            const bool m_ok = m < m_end;
             const int mm = m_ok ? m : 0;
-            const int n = mm / p.HoWo;
-            const int rem = mm - n * p.HoWo;
+            const int n = mm / cls_hw;
+            int rem = mm - n * cls_hw;
+            if (p.s2_classes) { const int i2 = rem / Wc; rem = (2 * i2 + cls_ph) * p.Wo + 2 * (rem - i2 * Wc) + cls_pw; }
             const long long yoff = (long long)n * p.ybs + (long long)rem * p.ldy;
             const long long roff = (long long)n * p.rbs + (long long)rem * p.ldr;
             int gy = 0, gx = 0;
@@ -559,7 +584,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     if (want_stats) {
         __syncthreads();
         const float* red = reinterpret_cast<const float*>(sW);
-        const int copy = (int)(blockIdx.y % (unsigned)p.stat_copies);
+        const int copy = (int)blockIdx.z * p.stat_copies + (int)(blockIdx.y % (unsigned)p.stat_copies);
         for (int cl = tid; cl < CT; cl += kThreads) {
             const int co = c0 + cl;
             if (co >= p.Cout) continue;
@@ -577,7 +602,9 @@ int launch_one(const ConvArgs& a, void* stream) {
     constexpr int RS = (STG == 1 || STG == 5) ? 1 : 0;
     constexpr int kStages = RS ? 1 : (STG == 0 ? 4 : STG);
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
-    dim3 grid((a.Cout + CT - 1) / CT, (a.M + PT - 1) / PT, 1);
+    const int nseg = a.seg_M > 0 ? a.M / a.seg_M : 1;
+    dim3 grid((a.Cout + CT - 1) / CT, ((a.seg_M > 0 ? a.seg_M : a.M) + PT - 1) / PT, nseg);
+    if (a.s2_classes) grid = dim3(grid.x, (a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2) + PT - 1) / PT, 4);
     // STG 5 keeps only the pixel tile in LDS (the BN-statistics scratch [WP][CT][2] floats aliases it after the K loop)
     constexpr size_t smem = (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
                                        : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
@@ -595,9 +622,11 @@ int launch_one(const ConvArgs& a, void* stream) {
 }
 
 template <typename T, int WC, int WP, int TC, int TP, int STG = 0>
-int launch_cfg(const ConvArgs& a, void* stream) {
+int launch_cfg(const ConvArgs& a_in, void* stream) {
     // FAST loader preconditions: whole slabs per tap, 32-bit addressable operands, taps fit the validity mask
+    ConvArgs a = a_in;
     const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32;
+    a.s2_classes = (fast && a.mode != SY_CONV_FWD && a.stride == 2 && a.KH >= 2 && a.KW >= 2 && !(a_in.ablate & 4)) ? 1 : 0;
     if constexpr (STG == 5) {       // fragment-packed weights exist only for the FAST traversal; else plain register staging
         if (fast && a.wfrag != nullptr && a.wfrag_extent != 0) return launch_one<T, WC, WP, TC, TP, 5, 1>(a, stream);
         return fast ? launch_one<T, WC, WP, TC, TP, 1, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, 1, 0>(a, stream);

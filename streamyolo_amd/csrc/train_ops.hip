@@ -130,6 +130,12 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, c
     __shared__ float s_s[8][32], s_q[8][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    {   // segment blockIdx.y: statistics [seg][copies][C], outputs [seg][C] (gamma / beta are shared)
+        const long long so = (long long)blockIdx.y * copies * C, ao = (long long)blockIdx.y * C;
+        sum += so; sqsum += so; scale += ao; shift += ao;
+        if (mean_out != nullptr) mean_out += ao;
+        if (invstd_out != nullptr) invstd_out += ao;
+    }
     float s = 0.0f, q = 0.0f;
     if (c < C)
         for (int k = rg; k < copies; k += 8) { s += sum[(long long)k * C + c]; q += sqsum[(long long)k * C + c]; }
@@ -197,6 +203,11 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
     const int c0 = cc * T::kEPC;
     const int rows = kBlock / cpp;
     if ((int)threadIdx.x >= rows * cpp) return;        // idle tail when cpp does not divide the workgroup
+    {   // segment blockIdx.y: rows [seg * pixels, (seg + 1) * pixels), affine [seg][C]
+        const long long ro = (long long)blockIdx.y * pixels;
+        y += ro * ldy; out += ro * ldo; scale += blockIdx.y * C; shift += blockIdx.y * C;
+        if (res != nullptr) res += ro * ldr;
+    }
     float sc[T::kEPC], sh[T::kEPC];
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
@@ -231,6 +242,12 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
     const int cc = threadIdx.x % cpp;
     const int pr = threadIdx.x / cpp;
     const int c0 = cc * T::kEPC;
+    {   // segment blockIdx.y
+        const long long ro = (long long)blockIdx.y * pixels;
+        const int ao = blockIdx.y * C;
+        y += ro * ldy; da += ro * ldda; scale += ao; shift += ao; mean += ao; invstd += ao;
+        sums += (long long)blockIdx.y * copies * 2 * C;
+    }
     float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], s0[T::kEPC], s1[T::kEPC];
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) {
@@ -271,9 +288,16 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
                                                                    const float* mean, const float* invstd,
                                                                    const float* gamma, const float* sums,
                                                                    typename T::elem* dy, int lddy, long long pixels,
-                                                                   int C, int copies, float* dgamma, float* dbeta) {
+                                                                   int C, int copies, float* dgamma, float* dbeta,
+                                                                   long long seg_sum_stride) {
     // fold the replicas of the two reduction sums once per workgroup, cooperatively, through LDS
     __shared__ float s_fold[2 * 1024];
+    {   // segment blockIdx.y
+        const long long ro = (long long)blockIdx.y * pixels;
+        const int ao = blockIdx.y * C;
+        y += ro * ldy; da += ro * ldda; dy += ro * lddy; scale += ao; shift += ao; mean += ao; invstd += ao;
+        sums += blockIdx.y * seg_sum_stride;
+    }
     const int cpp = C / T::kEPC;
     const int rows = kBlock / cpp;
     const int cc = threadIdx.x % cpp;
@@ -285,8 +309,12 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         s_fold[i] = a;
     }
     __syncthreads();
-    if (blockIdx.x == 0 && dgamma != nullptr) {        // launches on one stream are ordered: plain += is race free
-        for (int c = threadIdx.x; c < C; c += kBlock) { dbeta[c] += s_fold[c]; dgamma[c] += s_fold[C + c]; }
+    if (blockIdx.x == 0 && dgamma != nullptr) {
+        if (gridDim.y == 1) {                           // launches on one stream are ordered: plain += is race free
+            for (int c = threadIdx.x; c < C; c += kBlock) { dbeta[c] += s_fold[c]; dgamma[c] += s_fold[C + c]; }
+        } else {                                        // the segments (frames) share gamma / beta
+            for (int c = threadIdx.x; c < C; c += kBlock) { atomicAdd(dbeta + c, s_fold[c]); atomicAdd(dgamma + c, s_fold[C + c]); }
+        }
     }
     if ((int)threadIdx.x >= rows * cpp) return;
     float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], gi[T::kEPC], m0[T::kEPC], m1[T::kEPC];
@@ -316,6 +344,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
 __global__ __launch_bounds__(kBlock) void fold_replicas_kernel(float* sums, int n, int copies) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    sums += (long long)blockIdx.y * copies * n;
     float a = 0.0f;
     for (int k = 0; k < copies; ++k) a += sums[(long long)k * n + i];
     sums[i] = a;
@@ -356,12 +385,13 @@ extern "C" int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int
 
 extern "C" int sy_bn_finalize(const float* sum, const float* sqsum, int C, int copies, double count, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                              float* scale, float* shift, float* mean, float* invstd, void* stream) {
+                              float* scale, float* shift, float* mean, float* invstd, int nseg, void* stream) {
     if (sum == nullptr || sqsum == nullptr || gamma == nullptr || beta == nullptr || scale == nullptr ||
         shift == nullptr || C <= 0 || copies <= 0 || count <= 0.0)
         return SY_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SY_ERR_ARG;
-    SY_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, sum, sqsum, C, copies, count,
+    if (nseg < 1 || (nseg > 1 && running_mean != nullptr)) return SY_ERR_ARG;   // running stats of several calls: sy_bn_running_update
+    SY_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32, nseg), dim3(kBlock), 0, stream, sum, sqsum, C, copies, count,
               gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
@@ -373,24 +403,24 @@ extern "C" int sy_bn_running_update(const sy_bn_running_entry* entries, int n_en
 }
 
 extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr,
-                                void* out, int ldo, int64_t pixels, int C, int dtype, void* stream) {
-    if (y == nullptr || out == nullptr || scale == nullptr || shift == nullptr || pixels <= 0 || C <= 0) return SY_ERR_ARG;
+                                void* out, int ldo, int64_t pixels, int C, int dtype, int nseg, void* stream) {
+    if (y == nullptr || out == nullptr || scale == nullptr || shift == nullptr || pixels <= 0 || C <= 0 || nseg < 1) return SY_ERR_ARG;
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
 }
 
 extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                      const float* shift, const float* mean, const float* invstd, float* sums,
-                                     int copies, int64_t pixels, int C, int dtype, void* stream) {
-    if (y == nullptr || da == nullptr || sums == nullptr || pixels <= 0 || C <= 0 || copies <= 0) return SY_ERR_ARG;
+                                     int copies, int64_t pixels, int C, int dtype, int nseg, void* stream) {
+    if (y == nullptr || da == nullptr || sums == nullptr || pixels <= 0 || C <= 0 || copies <= 0 || nseg < 1) return SY_ERR_ARG;
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, 2048), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, sums, (long long)pixels, C, copies));
 }
@@ -398,20 +428,21 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
 extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                     const float* shift, const float* mean, const float* invstd, const float* gamma,
                                     const float* sums, int copies, void* dy, int lddy, int64_t pixels, int C,
-                                    float* dgamma, float* dbeta, int dtype, void* stream) {
-    if (y == nullptr || da == nullptr || sums == nullptr || dy == nullptr || pixels <= 0 || C <= 0 || copies <= 0)
+                                    float* dgamma, float* dbeta, int dtype, int nseg, void* stream) {
+    if (y == nullptr || da == nullptr || sums == nullptr || dy == nullptr || pixels <= 0 || C <= 0 || copies <= 0 || nseg < 1)
         return SY_ERR_ARG;
+    const long long seg_sum_stride = (long long)copies * 2 * C;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e || lddy % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e) || C > 1024) return SY_ERR_UNSUPPORTED;
     if (copies > 1) {       // fold once here instead of in every workgroup of the apply pass (sums is consumed by it)
-        SY_LAUNCH(fold_replicas_kernel, dim3((2 * C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, const_cast<float*>(sums),
-                  2 * C, copies);
+        SY_LAUNCH(fold_replicas_kernel, dim3((2 * C + kBlock - 1) / kBlock, nseg), dim3(kBlock), 0, stream,
+                  const_cast<float*>(sums), 2 * C, copies);
         copies = 1;
     }
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048)), dim3(kBlock), 0, stream,
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
-                                       dgamma, dbeta));
+                                       dgamma, dbeta, seg_sum_stride));
 }

@@ -103,7 +103,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None):
+           cout=None, tile=0, wfrag=None, segments=1):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -111,7 +111,8 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.scale, d.shift = _p(scale), _p(shift)
     d.res = None if res is None else res.ptr()
     d.stat_sum, d.stat_sqsum = (None, None) if stats is None else (stats[0].data_ptr(), stats[1].data_ptr())
-    d.stat_copies = 1 if stats is None else max(1, stats[0].numel() // (y.C if cout is None else cout))
+    d.stat_copies = 1 if stats is None else max(1, stats[0].numel() // (segments * (y.C if cout is None else cout)))
+    d.stat_segments = segments          # statistics arrays [segments][copies][Cout] (frame pairs: one segment per frame)
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     if y is not None:
         d.y, d.Ho, d.Wo, d.Cout = y.ptr(), y.H, y.W, y.C
@@ -198,12 +199,14 @@ def view_copy(src, dst, accumulate=False):
                                   1 if accumulate else 0, stream_of(src.buf)), "sy_view_copy")
 
 
-def bn_finalize(ssum, ssq, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd):
+def bn_finalize(ssum, ssq, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd,
+                nseg=1):
+    """count = elements per channel PER SEGMENT; statistics [nseg][copies][C], outputs [nseg][C] (see the header)."""
     C_ = gamma.numel()
-    check(_lib.lib().sy_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), C_, ssum.numel() // C_, float(count), gamma.data_ptr(),
-                                    beta.data_ptr(), float(eps), float(momentum), _p(running_mean), _p(running_var),
-                                    scale.data_ptr(), shift.data_ptr(), _p(mean), _p(invstd), stream_of(ssum)),
-          "sy_bn_finalize")
+    check(_lib.lib().sy_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), C_, ssum.numel() // (nseg * C_), float(count),
+                                    gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum), _p(running_mean),
+                                    _p(running_var), scale.data_ptr(), shift.data_ptr(), _p(mean), _p(invstd), nseg,
+                                    stream_of(ssum)), "sy_bn_finalize")
 
 
 class BnRunningTable:
@@ -236,24 +239,24 @@ class BnRunningTable:
               "sy_bn_running_update")
 
 
-def bn_silu_apply(y, scale, shift, out, res=None):
+def bn_silu_apply(y, scale, shift, out, res=None, nseg=1):
     check(_lib.lib().sy_bn_silu_apply(y.ptr(), y.ld, scale.data_ptr(), shift.data_ptr(),
                                       None if res is None else res.ptr(), 0 if res is None else res.ld, out.ptr(),
-                                      out.ld, y.pixels, y.C, y.dtype, stream_of(y.buf)), "sy_bn_silu_apply")
+                                      out.ld, y.pixels // nseg, y.C, y.dtype, nseg, stream_of(y.buf)), "sy_bn_silu_apply")
 
 
-def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums):
+def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums, nseg=1):
     check(_lib.lib().sy_bn_silu_bwd_reduce(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
                                            mean.data_ptr(), invstd.data_ptr(), sums.data_ptr(),
-                                           sums.numel() // (2 * y.C), y.pixels, y.C, y.dtype, stream_of(y.buf)),
-          "sy_bn_silu_bwd_reduce")
+                                           sums.numel() // (2 * y.C * nseg), y.pixels // nseg, y.C, y.dtype, nseg,
+                                           stream_of(y.buf)), "sy_bn_silu_bwd_reduce")
 
 
-def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None):
+def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None, nseg=1):
     check(_lib.lib().sy_bn_silu_bwd_apply(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
-                                          sums.numel() // (2 * y.C), dy.ptr(), dy.ld, y.pixels, y.C, _p(dgamma),
-                                          _p(dbeta), y.dtype,
+                                          sums.numel() // (2 * y.C * nseg), dy.ptr(), dy.ld, y.pixels // nseg, y.C,
+                                          _p(dgamma), _p(dbeta), y.dtype, nseg,
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 

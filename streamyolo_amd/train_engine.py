@@ -244,16 +244,27 @@ class TrainPlan:
                 full = torch.empty((2 * a.y.N, a.y.H, a.y.W, a.y.C), dtype=self.tdtype, device=device)
                 a.yraw = View(full[:a.y.N], a.y.N, a.y.H, a.y.W, a.y.C, root=(full, 0))
                 b2.yraw = View(full[a.y.N:], a.y.N, a.y.H, a.y.W, a.y.C, root=(full, a.y.N))
-        for op in convs:
-            C = op.y.C
-            op.stat = (self.stat_arena[SC * off:SC * (off + C)],
-                       self.stat_arena[SC * (tot_c + off):SC * (tot_c + off + C)])
-            op.bsum = self.bwd_arena[2 * BC * off:2 * BC * (off + C)]
-            op.aff = tuple(self.aff_arena[k * tot_c + off:k * tot_c + off + C] for k in range(4))
-            if op.yraw is None:
-                op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
-            max_raw = max(max_raw, 2 * op.y.pixels * C)
-            off += C
+        # Units: (current-frame op, support-frame op) of the shared per-frame network, then the single fusion / head
+        # convs.  A unit's state is laid out segment-major — statistics [seg][copies][C], backward sums
+        # [seg][copies][2][C], affine [seg][C] — so ONE launch per layer serves both frames (nseg = 2) while each
+        # frame keeps its own batch statistics, like the reference's two backbone passes (dfp_pafpn.py:120-165).
+        units = [(self.ops[i], self.ops[nf + i]) for i in range(nf) if self.ops[i].kind == "conv"]
+        units += [(op,) for op in self.ops[2 * nf:] if op.kind == "conv"]
+        for unit in units:
+            C, S = unit[0].y.C, len(unit)
+            u_sum = self.stat_arena[SC * off:SC * (off + S * C)]
+            u_sq = self.stat_arena[SC * (tot_c + off):SC * (tot_c + off + S * C)]
+            u_bsum = self.bwd_arena[2 * BC * off:2 * BC * (off + S * C)]
+            u_aff = tuple(self.aff_arena[k * tot_c + off:k * tot_c + off + S * C] for k in range(4))
+            for s_, op in enumerate(unit):
+                op.stat = (u_sum[s_ * SC * C:(s_ + 1) * SC * C], u_sq[s_ * SC * C:(s_ + 1) * SC * C])
+                op.bsum = u_bsum[s_ * 2 * BC * C:(s_ + 1) * 2 * BC * C]
+                op.aff = tuple(t[s_ * C:(s_ + 1) * C] for t in u_aff)
+                if op.yraw is None:
+                    op.yraw = View.alloc(op.y.N, op.y.H, op.y.W, C, self.dtype, device)
+                max_raw = max(max_raw, 2 * op.y.pixels * C)
+            unit[0].unit = (u_sum, u_sq, u_bsum, u_aff)             # the whole unit's arrays (paired launches)
+            off += S * C
         # raw-gradient scratch ring: the weight-gradient kernels of layer i run on the side stream while the main
         # stream is already producing layer i-1's raw gradient, so a slot is reused only after its wgrad retired
         self.dyraw_ring = [torch.empty(max_raw, dtype=self.tdtype, device=device) for _ in range(self.RING)]
@@ -320,19 +331,17 @@ class TrainPlan:
         return self.raw
 
     def _forward_ops(self):
-        """The op loop in launch order.  The two frames' networks are independent until the DFP fusion
-        (dfp_pafpn.py:120-165): current frame on the caller's stream, support frame on the side stream (chunks of a
-        few layers so both queues stay fed); after the fusion the three head levels fan out again."""
-        nf, CH = self.n_frame_ops, 6
-        self._mark("fork")
-        for i0 in range(0, nf, CH):
-            for op in self.ops[i0:min(nf, i0 + CH)]:
-                self._forward_op(op)
-            self._mark("side_nw")
-            for op in self.ops[nf + i0:nf + min(nf, i0 + CH)]:
-                self._forward_op(op)
-            self._mark("main", None)
-        self._mark("join")
+        """The op loop in launch order.  The per-frame network runs ONCE over both frames (2B images per launch, one
+        statistics segment per frame — the reference's two backbone passes, dfp_pafpn.py:120-165); after the DFP
+        fusion the three head levels fan out over the two streams."""
+        nf = self.n_frame_ops
+        for i in range(nf):
+            a, b2 = self.ops[i], self.ops[nf + i]
+            if a.kind == "conv":
+                self._forward_pair(a)
+            else:
+                self._forward_op(a)
+                self._forward_op(b2)
         for op in self.ops[2 * nf:self.n_head_start]:
             self._forward_op(op)
         self._mark("fork")
@@ -345,6 +354,23 @@ class TrainPlan:
                 self._forward_op(op)
         self._mark("main", None)
         self._mark("join")
+
+    def _forward_pair(self, a):
+        """BaseConv of the shared per-frame network on both frames: conv (+ per-frame statistics), finalize, BN+SiLU."""
+        bn = a.mod.bn
+        x2, raw2, y2 = a.x.pair(), a.yraw.pair(), a.y.pair()
+        t = a._tiles.get("fwd_stats2")
+        if t is None:
+            t = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride, self.device,
+                               with_stats=True)
+            a._tiles["fwd_stats2"] = t
+        u_sum, u_sq, _, (scale, shift, mean, invstd) = a.unit
+        ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
+                   wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        ops.bn_finalize(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, mom, None, None, scale, shift, mean, invstd,
+                        nseg=2)
+        ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
 
     # ---- launch programs ------------------------------------------------------------------------------------
     # Step 1 runs the Python wrappers directly (kernel variants get tuned).  Step 2 runs them again under
@@ -604,9 +630,21 @@ class TrainPlan:
         N, H, W, C = a.y.N, a.y.H, a.y.W, a.y.C
         full = self._scratch(2 * N * H * W * C).view(2 * N, H, W, C)
         slot = self._slot
-        self._bn_backward(b2, View(full[N:], N, H, W, C))
-        self._bn_backward(a, View(full[:N], N, H, W, C))
         dy2 = View(full, 2 * N, H, W, C)
+        bn = a.mod.bn
+        dYa, dYb = G.view(a.y), G.view(b2.y)
+        assert dYa.root[0] is dYb.root[0]
+        dY2 = dYa.pair()
+        if a.res is not None:                                        # y = silu(bn(conv)) + res, both frames at once
+            dra, acca = G.target(a.res)
+            drb, accb = G.target(b2.res)
+            assert acca == accb and dra.root[0] is drb.root[0]
+            ops.view_copy(dY2, dra.pair(), accumulate=acca)
+        _, _, u_bsum, (scale, shift, mean, invstd) = a.unit
+        raw2 = a.yraw.pair()
+        ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
+        ops.bn_silu_bwd_apply(raw2, dY2, scale, shift, mean, invstd, bn.weight, u_bsum, dy2,
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2)
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot)
         if a.need_dx:
             dxa, acca = G.target(a.x)

@@ -209,3 +209,48 @@ def test_pack_weights_matches_host_packing(backend, dt):
         for b, t in zip(bufs, exp):
             if t is not None:
                 assert torch.equal(b.cpu().view(-1), t.reshape(-1))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_segmented_conv_stats_and_batchnorm(backend, dt):
+    """stat_segments / nseg = 2: one launch per kernel over a 2-frame batch must equal two independent single-frame
+    BatchNorm passes (separate batch statistics per frame, shared gamma / beta whose gradients add up)."""
+    from streamyolo_amd.model.packing import pack_conv_weight
+    g = torch.Generator().manual_seed(21)
+    code = ops.dtype_code(dt)
+    tdt = ops.TORCH_DTYPE[code]
+    N, cin, C, H, W, copies = 2, 16, 24, 7, 9, 3            # 2 segments of N images each; 63 pixels per image (ragged tiles)
+    x = (torch.randn(2 * N, cin, H, W, generator=g) * torch.tensor([1.0, 1.0, 3.0, 3.0]).view(4, 1, 1, 1)).to(tdt).float()
+    w = (torch.randn(C, cin, 3, 3, generator=g) / 12.0).to(tdt).float()
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    da = torch.randn(2 * N, C, H, W, generator=g).to(tdt).float()
+    yref = F.conv2d(x, w, None, 1, 1)
+    yq = yref.to(tdt).float().requires_grad_(True)
+    a_ref = torch.cat([F.silu(F.batch_norm(yq[s * N:(s + 1) * N], None, None, gamma, beta, True, 0.03, 1e-3)) for s in range(2)])
+    a_ref.backward(da)
+    dev = backend
+    xv = View.alloc(2 * N, H, W, cin, dt, dev); xv.set_nchw(x.to(dev))
+    yv = View.alloc(2 * N, H, W, C, dt, dev)
+    ssum = torch.zeros(2 * copies * C, device=dev); ssq = torch.zeros(2 * copies * C, device=dev)
+    ops.conv2d(xv, pack_conv_weight(w, code).to(dev), yv, 3, 1, stats=(ssum, ssq), segments=2)
+    for s in range(2):
+        got = ssum.view(2, copies, C)[s].sum(0).cpu()
+        assert _rel(got, yref[s * N:(s + 1) * N].sum((0, 2, 3))) < (2e-2 if dt == "bf16" else 1e-4)
+    yv.set_nchw(yq.detach().to(dev))                       # continue from the exactly representable activations
+    ssum.copy_(torch.stack([torch.cat([yq[s * N:(s + 1) * N].detach().sum((0, 2, 3)), torch.zeros((copies - 1) * C)]) for s in range(2)]).view(-1))
+    ssq.copy_(torch.stack([torch.cat([(yq[s * N:(s + 1) * N].detach() ** 2).sum((0, 2, 3)), torch.zeros((copies - 1) * C)]) for s in range(2)]).view(-1))
+    scale, shift, mean, invstd = [torch.empty(2 * C, device=dev) for _ in range(4)]
+    gd, bd = gamma.detach().to(dev), beta.detach().to(dev)
+    ops.bn_finalize(ssum, ssq, N * H * W, gd, bd, 1e-3, 0.03, None, None, scale, shift, mean, invstd, nseg=2)
+    av = View.alloc(2 * N, H, W, C, dt, dev)
+    ops.bn_silu_apply(yv, scale, shift, av, nseg=2)
+    assert _rel(av.nchw().cpu(), a_ref.detach()) < (2e-2 if dt == "bf16" else 1e-5)
+    dav = View.alloc(2 * N, H, W, C, dt, dev); dav.set_nchw(da.to(dev))
+    sums = torch.zeros(2 * copies * 2 * C, device=dev)
+    ops.bn_silu_bwd_reduce(yv, dav, scale, shift, mean, invstd, sums, nseg=2)
+    dyv = View.alloc(2 * N, H, W, C, dt, dev)
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_silu_bwd_apply(yv, dav, scale, shift, mean, invstd, gd, sums, dyv, dgam, dbet, nseg=2)
+    assert _rel(dbet.cpu(), beta.grad) < 1e-4 and _rel(dgam.cpu(), gamma.grad) < 1e-4
+    assert _rel(dyv.nchw().cpu(), yq.grad) < (3e-2 if dt == "bf16" else 1e-4)
