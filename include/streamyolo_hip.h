@@ -151,8 +151,11 @@ typedef struct sy_pack_entry {
     void* frag;
     void* frag_t;
     int32_t co_n, ci_n, taps, r0, R, R_t, CI, dtype;
+    int32_t tile0;              /* prefix sum over the preceding entries of ceil(co_n/32) * ceil(ci_n/32) */
+    int32_t reserved;
 } sy_pack_entry;
-SY_API int sy_pack_weights(const sy_pack_entry* entries, int n_entries, void* stream);
+/* total_tiles = the prefix sum over ALL entries (one workgroup per 32x32 tile); taps <= 9. */
+SY_API int sy_pack_weights(const sy_pack_entry* entries, int n_entries, int total_tiles, void* stream);
 
 /* SEGMENTS (nseg >= 1): the two frames of a pair pass through the shared backbone separately in the reference, so each
  * BatchNorm normalises them with separate batch statistics (dfp_pafpn.py:120-165).  Here both frames run in ONE launch

@@ -50,7 +50,17 @@ class PackEntry(C.Structure):
     """sy_pack_entry (include/streamyolo_hip.h)."""
     _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("packed_t", C.c_void_p), ("frag", C.c_void_p),
                 ("frag_t", C.c_void_p), ("co_n", C.c_int32), ("ci_n", C.c_int32), ("taps", C.c_int32),
-                ("r0", C.c_int32), ("R", C.c_int32), ("R_t", C.c_int32), ("CI", C.c_int32), ("dtype", C.c_int32)]
+                ("r0", C.c_int32), ("R", C.c_int32), ("R_t", C.c_int32), ("CI", C.c_int32), ("dtype", C.c_int32),
+                ("tile0", C.c_int32), ("reserved", C.c_int32)]
+
+
+def pack_table(rows):
+    """ctypes array of PackEntry with the tile0 prefix filled in -> (array, total_tiles)."""
+    t = 0
+    for e in rows:
+        e.tile0 = t
+        t += -(-e.co_n // 32) * -(-e.ci_n // 32)
+    return (PackEntry * len(rows))(*rows), t
 
 
 class WgradDesc(C.Structure):
@@ -78,7 +88,7 @@ SIGNATURES = {
     "sy_spp_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "sy_postprocess_workspace_bytes": (_L, [_I, _I]),
     "sy_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
-    "sy_pack_weights": (_I, [_P, _I, _P]),
+    "sy_pack_weights": (_I, [_P, _I, _I, _P]),
     "sy_bn_running_update": (_I, [_P, _I, _I, _P]),
     "sy_bn_finalize": (_I, [_P, _P, _I, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
     "sy_bn_silu_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),

@@ -26,46 +26,66 @@ template <typename T> __device__ __forceinline__ long long frag_index(int row, i
     return ((((((long long)ct * nslab + cslab) * taps + tap) * 2 + g) * 2 + half) * 32 + r) * EPC + e;
 }
 
-// grid (x, entry, pass).  pass 0: threads over (co, ci) ci-fastest -> packed / frag (coalesced writes);
-// pass 1: threads over (ci, co) co-fastest -> packed_t / frag_t.  A thread owns all taps of its (co, ci).
-template <typename T> __device__ void pack_entry(const sy_pack_entry& e, int pass) {
-    const long long n = (long long)e.co_n * e.ci_n;
+// One workgroup = one 32 (co) x 32 (ci) tile of one entry (found by bisection over the entries' tile0 prefix).
+// Phase A: threads (co, ci) ci-fastest read their taps straight from the OIHW parameter (a wave reads 32 x taps
+// consecutive floats) and write packed / frag, whose fast index is ci; the fp32 tile is parked in LDS.  Phase B:
+// threads (ci, co) co-fastest write packed_t / frag_t, whose fast index is co.  Every global access is coalesced.
+constexpr int kPackTile = 32, kPackTaps = 9;
+
+template <typename T> __device__ void pack_tile(const sy_pack_entry& e, int tile, float (*lds)[kPackTile][kPackTile + 1]) {
+    const int tiles_ci = (e.ci_n + kPackTile - 1) / kPackTile;
+    const int co0 = (tile / tiles_ci) * kPackTile, ci0 = (tile % tiles_ci) * kPackTile;
     const int taps = e.taps;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        int co, ci;
-        if (pass == 0) { co = (int)(i / e.ci_n); ci = (int)(i - (long long)co * e.ci_n); }
-        else { ci = (int)(i / e.co_n); co = (int)(i - (long long)ci * e.co_n); }
+    const int a_l = threadIdx.x >> 5, b_l = threadIdx.x & 31;
+    for (int pass = 0; pass < kPackTile / 8; ++pass) {
+        const int col = a_l + 8 * pass, co = co0 + col, ci = ci0 + b_l;
+        const bool ok = co < e.co_n && ci < e.ci_n;
         const float* src = e.w + ((long long)co * e.ci_n + ci) * taps;
         const int row = e.r0 + co;
         for (int t = 0; t < taps; ++t) {
-            const float v = src[t];
-            if (pass == 0) {
-                if (e.packed != nullptr) put<T>(e.packed, ((long long)row * taps + t) * e.CI + ci, v);
-                if (e.frag != nullptr) put<T>(e.frag, frag_index<T>(row, t, ci, taps, e.CI), v);
-            } else {
-                if (e.packed_t != nullptr) put<T>(e.packed_t, ((long long)ci * taps + t) * e.R_t + row, v);
-                if (e.frag_t != nullptr) put<T>(e.frag_t, frag_index<T>(ci, t, row, taps, e.R_t), v);
-            }
+            const float v = ok ? src[t] : 0.0f;
+            lds[t][col][b_l] = v;
+            if (!ok) continue;
+            if (e.packed != nullptr) put<T>(e.packed, ((long long)row * taps + t) * e.CI + ci, v);
+            if (e.frag != nullptr) put<T>(e.frag, frag_index<T>(row, t, ci, taps, e.CI), v);
+        }
+    }
+    __syncthreads();
+    if (e.packed_t == nullptr && e.frag_t == nullptr) return;
+    for (int pass = 0; pass < kPackTile / 8; ++pass) {
+        const int cil = a_l + 8 * pass, ci = ci0 + cil, co = co0 + b_l;
+        if (co >= e.co_n || ci >= e.ci_n) continue;
+        const int row = e.r0 + co;
+        for (int t = 0; t < taps; ++t) {
+            const float v = lds[t][b_l][cil];
+            if (e.packed_t != nullptr) put<T>(e.packed_t, ((long long)ci * taps + t) * e.R_t + row, v);
+            if (e.frag_t != nullptr) put<T>(e.frag_t, frag_index<T>(ci, t, row, taps, e.R_t), v);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void pack_weights_kernel(const sy_pack_entry* entries) {
-    const sy_pack_entry e = entries[blockIdx.y];
-    const int pass = blockIdx.z;
-    if (pass == 0 ? (e.packed == nullptr && e.frag == nullptr) : (e.packed_t == nullptr && e.frag_t == nullptr)) return;
-    if ((long long)blockIdx.x * blockDim.x >= (long long)e.co_n * e.ci_n) return;
+__global__ __launch_bounds__(256) void pack_weights_kernel(const sy_pack_entry* entries, int n_entries) {
+    __shared__ float lds[kPackTaps][kPackTile][kPackTile + 1];
+    int lo = 0, hi = n_entries - 1;                           // last entry with tile0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (entries[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const sy_pack_entry e = entries[lo];
+    const int tile = (int)blockIdx.x - e.tile0;
+    const int tiles = ((e.co_n + kPackTile - 1) / kPackTile) * ((e.ci_n + kPackTile - 1) / kPackTile);
+    if (tile >= tiles || e.taps > kPackTaps) return;
     switch (e.dtype) {
-        case SY_DT_BF16: pack_entry<BF16>(e, pass); break;
-        case SY_DT_F16: pack_entry<F16>(e, pass); break;
-        default: pack_entry<F32>(e, pass); break;
+        case SY_DT_BF16: pack_tile<BF16>(e, tile, lds); break;
+        case SY_DT_F16: pack_tile<F16>(e, tile, lds); break;
+        default: pack_tile<F32>(e, tile, lds); break;
     }
 }
 
 }  // namespace
 
-extern "C" int sy_pack_weights(const sy_pack_entry* entries, int n_entries, void* stream) {
-    if (entries == nullptr || n_entries <= 0) return SY_ERR_ARG;
-    SY_LAUNCH(pack_weights_kernel, dim3(64, n_entries, 2), dim3(256), 0, stream, entries);
+extern "C" int sy_pack_weights(const sy_pack_entry* entries, int n_entries, int total_tiles, void* stream) {
+    if (entries == nullptr || n_entries <= 0 || total_tiles <= 0) return SY_ERR_ARG;
+    SY_LAUNCH(pack_weights_kernel, dim3(total_tiles), dim3(256), 0, stream, entries, n_entries);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }

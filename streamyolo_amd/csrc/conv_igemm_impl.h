@@ -97,21 +97,22 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     const int wave = tid >> 6;
     const int wc = wave / WP;
     const int wp = wave % WP;
-    const int c0 = blockIdx.x * CT;
+    const sy_block_id bid = sy_xcd_block_id();   // logical tile of this workgroup (XCD-contiguous order)
+    const int c0 = bid.x * CT;
     // statistics segments (training forward of a frame pair): segment z owns pixels [z * seg_M, (z + 1) * seg_M)
     // Stride-2 data gradient: an output pixel (ho, wo) only receives the taps with kh = ho + pad, kw = wo + pad (mod 2)
     // — a 3x3 kernel has 1, 2, 2 or 4 of them, never 9.  gridDim.z enumerates the four parity classes; a workgroup
     // tiles the half-resolution grid of ITS class and walks only that class's taps, so no MFMA multiplies padding.
     int cls_ph = 0, cls_pw = 0, Hc = p.Ho, Wc = p.Wo, cls_M = p.M;
     if (p.s2_classes) {
-        cls_ph = (int)blockIdx.z >> 1; cls_pw = (int)blockIdx.z & 1;
+        cls_ph = bid.z >> 1; cls_pw = bid.z & 1;
         Hc = (p.Ho - cls_ph + 1) >> 1; Wc = (p.Wo - cls_pw + 1) >> 1;
         cls_M = p.N * Hc * Wc;
-        if ((int)blockIdx.y * PT >= cls_M) return;              // uniform: the smaller classes need fewer tiles
+        if (bid.y * PT >= cls_M) return;              // uniform: the smaller classes need fewer tiles
     }
     const int cls_hw = Hc * Wc;
-    const int m_end = p.seg_M > 0 ? ((int)blockIdx.z + 1) * p.seg_M : cls_M;
-    const int m0 = (p.s2_classes ? 0 : (int)blockIdx.z * p.seg_M) + blockIdx.y * PT;
+    const int m_end = p.seg_M > 0 ? (bid.z + 1) * p.seg_M : cls_M;
+    const int m0 = (p.s2_classes ? 0 : bid.z * p.seg_M) + bid.y * PT;
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
             unsigned foff[TC];
 #pragma unroll
             for (int t = 0; t < TC; ++t) {
-                const int ct = (int)blockIdx.x * (CT / 32) + wc * TC + t;
+                const int ct = bid.x * (CT / 32) + wc * TC + t;
                 foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * nslab_all) * 128 + lane) * 16) : 0xFFFFFFFFu;
             }
             uint4 fa[TC][2], fn[TC][2], rx[XCH];
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     if (want_stats) {
         __syncthreads();
         const float* red = reinterpret_cast<const float*>(sW);
-        const int copy = (int)blockIdx.z * p.stat_copies + (int)(blockIdx.y % (unsigned)p.stat_copies);
+        const int copy = bid.z * p.stat_copies + (int)((unsigned)bid.y % (unsigned)p.stat_copies);
         for (int cl = tid; cl < CT; cl += kThreads) {
             const int co = c0 + cl;
             if (co >= p.Cout) continue;

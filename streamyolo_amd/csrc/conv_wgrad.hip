@@ -66,7 +66,7 @@ struct PixelCursor {            // (n, ho, wo) of one output pixel, advanced sla
 //      stores, no atomics) and wgrad_fold_kernel sums the slabs into dW.
 template <int TR, int TC>
 __device__ __forceinline__ void wgrad_epilogue(const WgradArgs& p, f32x16 (&acc)[TR][TC], int r0, int c0, int wr, int wcn,
-                                               int lane) {
+                                               int lane, int split) {
     const int l31 = lane & 31;
     const int half = lane >> 5;
     const int taps = p.KH * p.KW;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void wgrad_epilogue(const WgradArgs& p, f32x16 (&acc)
                 const float v0 = acc[t][u][q * 4 + 0], v1 = acc[t][u][q * 4 + 1], v2 = acc[t][u][q * 4 + 2],
                             v3 = acc[t][u][q * 4 + 3];
                 if (p.splits > 1) {
-                    float* dst = p.part + ((long long)blockIdx.z * p.Cout + co) * p.K + kb;
+                    float* dst = p.part + ((long long)split * p.Cout + co) * p.K + kb;
                     *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
                 } else if (p.oihw) {
                     const int tap = kb / p.Cin;
@@ -123,9 +123,10 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
     const int wave = tid >> 6;
     const int wr = wave / WC;
     const int wcn = wave % WC;
-    const int r0 = blockIdx.x * RT;
-    const int c0 = blockIdx.y * CT;
-    const int slab0 = blockIdx.z * p.slabs_per_split;
+    const sy_block_id bid = sy_xcd_block_id();   // the row / column tiles of one pixel range share an XCD's L2
+    const int r0 = bid.x * RT;
+    const int c0 = bid.y * CT;
+    const int slab0 = bid.z * p.slabs_per_split;
     int nslab = p.slabs_per_split;
     const int slabs_total = (p.M + SLAB - 1) / SLAB;
     if (slab0 + nslab > slabs_total) nslab = slabs_total - slab0;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
         }
     }
 
-    wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane);
+    wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
 }
 
 // ---- transpose-read variant (16-bit types) ------------------------------------------------------------------
@@ -317,9 +318,10 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
     const int wave = tid >> 6;
     const int wr = wave / WC;
     const int wcn = wave % WC;
-    const int r0 = blockIdx.x * RT;
-    const int c0 = blockIdx.y * CT;
-    const int slab0 = blockIdx.z * p.slabs_per_split;
+    const sy_block_id bid = sy_xcd_block_id();   // the row / column tiles of one pixel range share an XCD's L2
+    const int r0 = bid.x * RT;
+    const int c0 = bid.y * CT;
+    const int slab0 = bid.z * p.slabs_per_split;
     int nslab = p.slabs_per_split;
     const int slabs_total = (p.M + SLAB - 1) / SLAB;
     if (slab0 + nslab > slabs_total) nslab = slabs_total - slab0;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
                 for (int u = 0; u < TC; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
         }
     }
-    wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane);
+    wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
 }
 
 // dW (+)= sum over splits of the partial slabs; also applies the packed -> OIHW layout change.

@@ -212,6 +212,28 @@ static inline int sy_uniform(int v) { return v; }
 __device__ __forceinline__ int sy_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// ---- XCD-aware workgroup order ------------------------------------------------------------------------------
+// MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs, each with a private L2.  Tiles that
+// share operand rows (the channel tiles of one pixel tile, neighbouring pixel tiles with their halo rows, the
+// K-splits' row / column tiles of one pixel range) have CONSECUTIVE logical ids in our grids, so left alone
+// they would land on 8 different L2s and every XCD would fetch the same rows.  The remap hands XCD k one
+// contiguous range of logical ids instead: hardware id w (XCD w % 8, its (w / 8)-th workgroup) -> logical id
+// start(k) + w / 8.  A bijection for any grid size (the first nwg % 8 XCDs take one extra workgroup).
+struct sy_block_id { int x, y, z; };
+__device__ __forceinline__ sy_block_id sy_xcd_block_id() {
+    constexpr unsigned kXcd = 8;
+    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const unsigned nwg = gx * gy * gz;
+    const unsigned w = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned k = w % kXcd, q = nwg / kXcd, r = nwg % kXcd;
+    const unsigned L = k * q + (k < r ? k : r) + w / kXcd;
+    sy_block_id b;
+    b.x = (int)(L % gx);
+    b.y = (int)((L / gx) % gy);
+    b.z = (int)(L / (gx * gy));
+    return b;
+}
+
 // ---- small math ---------------------------------------------------------------------------------
 #ifdef SY_EMU
 static inline float sy_exp(float x) { return expf(x); }

@@ -168,7 +168,7 @@ class StagedWeights:
                 entry(op.reg_mod.bias, b_ro, None, None, None, 4, 1, 1, 0, 5, 5, 1, ops.DTYPE_NAME["fp32"])
                 entry(op.obj_mod.bias, b_ro, None, None, None, 1, 1, 1, 4, 5, 5, 1, ops.DTYPE_NAME["fp32"])
                 self.preds[id(op)] = (w_ro, b_ro, w_c, op.cls_mod.bias, w_ro_t, w_c_t)
-        arr = (_lib.PackEntry * len(rows))(*rows)
+        arr, self.total_tiles = _lib.pack_table(rows)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.n = len(rows)
         self.sig = tuple(t.data_ptr() for t in self.sources)
@@ -177,7 +177,7 @@ class StagedWeights:
         return self.sig == tuple(t.data_ptr() for t in self.sources)
 
     def refresh(self):
-        ops.check(ops._lib.lib().sy_pack_weights(self.table.data_ptr(), self.n, ops.stream_of(self.table)),
+        ops.check(ops._lib.lib().sy_pack_weights(self.table.data_ptr(), self.n, self.total_tiles, ops.stream_of(self.table)),
                   "sy_pack_weights")
 
     def conv_weight(self, mod, transpose=False):

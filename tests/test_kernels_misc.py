@@ -187,7 +187,7 @@ def test_pack_weights_matches_host_packing(backend, dt):
     code = ops.dtype_code(dt)
     tdt = ops.TORCH_DTYPE[code]
     g = torch.Generator().manual_seed(11)
-    shapes = [(40, 32, 3), (64, 64, 1), (24, 12, 3), (5, 48, 1)]
+    shapes = [(40, 32, 3), (64, 64, 1), (24, 12, 3), (5, 48, 1), (96, 80, 3)]
     rows, keep, want = [], [], []
     for co, ci, k in shapes:
         w = torch.randn(co, ci, k, k, generator=g)
@@ -202,9 +202,9 @@ def test_pack_weights_matches_host_packing(backend, dt):
         e.packed, e.packed_t, e.frag, e.frag_t = [None if b is None else b.data_ptr() for b in bufs]
         e.co_n, e.ci_n, e.taps, e.r0, e.R, e.R_t, e.CI, e.dtype = co, ci, k * k, 0, co, co, CI, code
         rows.append(e); keep.append((wd, bufs)); want.append((p, pt, f, ft))
-    arr = (_lib.PackEntry * len(rows))(*rows)
+    arr, total = _lib.pack_table(rows)
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(backend)
-    ops.check(_lib.lib().sy_pack_weights(table.data_ptr(), len(rows), ops.stream_of(table)), "sy_pack_weights")
+    ops.check(_lib.lib().sy_pack_weights(table.data_ptr(), len(rows), total, ops.stream_of(table)), "sy_pack_weights")
     for (_, bufs), exp in zip(keep, want):
         for b, t in zip(bufs, exp):
             if t is not None:
