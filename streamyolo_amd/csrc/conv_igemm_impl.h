@@ -461,6 +461,99 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
                         (p.res == nullptr || (p.ldr & 3) == 0);
     const bool want_stats = (p.stat_sum != nullptr);
+    // Output staging (16-bit outputs without residual / accumulate): the MFMA accumulator layout gives a lane 4
+    // channels of one pixel, i.e. 8-byte stores 2*ldy bytes apart — 64 partial cache lines per store instruction,
+    // and the 1x1 layers were bound by exactly that.  Instead the wave parks its converted tile in LDS as
+    // [pixel][channel] and the workgroup writes whole pixel rows, 16 bytes per lane, consecutive lanes consecutive
+    // addresses (the K loop is over, its LDS is free).
+    constexpr int kStagePitch = CT * 2 + 16;                    // bytes per staged pixel row (+16: bank spread)
+    constexpr int kStatBytes = WP * CT * 8;                     // BN-statistics scratch [WP][CT][2] floats (aliases too)
+    constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 8 + kStatBytes <= 48 * 1024);
+    const bool stage_out = kCanStage && vec_ok && !p.y_f32 && !p.accumulate && p.res == nullptr;
+    unsigned char* const stg = smem + kStatBytes;               // [PT][kStagePitch]
+    long long* const stg_off = reinterpret_cast<long long*>(smem + kStatBytes + PT * kStagePitch);   // [PT] element offsets
+    if (want_stats || stage_out) __syncthreads();               // every wave is done with the operand tiles
+    // ---- lean path for staged outputs (every training forward / first-write data gradient / eval conv without a
+    //      residual): the mode, affine and statistics decisions are taken ONCE here, not per element — the general
+    //      loop below re-tests them for each of its 16 x TP values per tile, and at 1x1 layers (4-16 slabs of MFMA
+    //      per tile) those ~2500 scalar-ish instructions per wave were the whole kernel time.
+    const bool lean = kCanStage && stage_out && (p.epilogue == SY_EPI_LINEAR || p.epilogue == SY_EPI_SILU) &&
+                      (!want_stats || (p.epilogue == SY_EPI_LINEAR && p.scale == nullptr && p.shift == nullptr));
+    if (lean) {
+        if constexpr (kCanStage) {
+            auto body = [&](auto silu_, auto aff_, auto stats_) {
+                constexpr bool SILU = decltype(silu_)::value != 0, AFF = decltype(aff_)::value != 0,
+                               STATS = decltype(stats_)::value != 0;
+                if (wc == 0 && half == 0) {                         // output element offset of every tile pixel, once
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        const int m = m0 + (wp * TP + u) * 32 + l31;
+                        long long off = -1;
+                        if (m < m_end) {
+                            const int n = m / cls_hw;
+                            int rem = m - n * cls_hw;
+                            if (p.s2_classes) { const int i2 = rem / Wc; rem = (2 * i2 + cls_ph) * p.Wo + 2 * (rem - i2 * Wc) + cls_pw; }
+                            off = (long long)n * p.ybs + (long long)rem * p.ldy;
+                        }
+                        stg_off[(wp * TP + u) * 32 + l31] = off;
+                    }
+                }
+                sy_static_for<0, TC>([&](auto tc_) {
+                    constexpr int t = decltype(tc_)::value;
+                    float sc[16], sh[16], ssum[16], ssq[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (AFF) {
+                            const int co = sy_min(c0 + (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3), p.Cout - 1);
+                            sc[r] = p.scale[co]; sh[r] = p.shift[co];
+                        }
+                        if (STATS) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        unsigned char* const row = stg + ((wp * TP + u) * 32 + l31) * kStagePitch + ((wc * TC + t) * 32 + half * 4) * 2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float a = acc[t][u][q * 4 + j];
+                                if (STATS) { ssum[q * 4 + j] += a; ssq[q * 4 + j] += a * a; }
+                                float z = AFF ? a * sc[q * 4 + j] + sh[q * 4 + j] : a;
+                                if (SILU) z = sy_silu(z);
+                                v[j] = z;
+                            }
+                            *reinterpret_cast<uint2*>(row + q * 16) = make_uint2(T::pack2(v[0], v[1]), T::pack2(v[2], v[3]));
+                        }
+                    }
+                    if (STATS) {
+                        float* red = reinterpret_cast<float*>(smem);          // [WP][CT][2]
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float a = ssum[r], b = ssq[r];
+#pragma unroll
+                            for (int off = 1; off < 32; off <<= 1) {
+                                a += __shfl_xor(a, off);
+                                b += __shfl_xor(b, off);
+                            }
+                            const int cl = (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
+                            if (l31 == 0) {
+                                red[(wp * CT + cl) * 2 + 0] = a;
+                                red[(wp * CT + cl) * 2 + 1] = b;
+                            }
+                        }
+                    }
+                });
+            };
+            const bool aff = p.scale != nullptr && p.shift != nullptr;
+            const bool silu = p.epilogue == SY_EPI_SILU;
+            if (want_stats) body(sy_int<0>(), sy_int<0>(), sy_int<1>());          // training forward: raw output + statistics
+            else if (silu && aff) body(sy_int<1>(), sy_int<1>(), sy_int<0>());    // eval BaseConv
+            else if (!silu && !aff) body(sy_int<0>(), sy_int<0>(), sy_int<0>());  // data gradient
+            else if (silu) body(sy_int<1>(), sy_int<0>(), sy_int<0>());
+            else body(sy_int<0>(), sy_int<1>(), sy_int<0>());
+        }
+    } else
     // compile-time loop over the wave's channel tiles: accumulator indices must be constants (a runtime
     // index would push the 128-register accumulator file of the 256x256 tile into scratch)
     sy_static_for<0, TC>([&](auto tc_) {
@@ -482,6 +575,8 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
             const long long roff = (long long)n * p.rbs + (long long)rem * p.ldr;
             int gy = 0, gx = 0;
             if (p.epilogue == SY_EPI_DECODE) { gy = rem / p.Wo; gx = rem - gy * p.Wo; }
+            if (kCanStage && stage_out && t == 0 && wc == 0 && half == 0)
+                stg_off[(wp * TP + u) * 32 + l31] = m_ok ? yoff : -1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cb = c0 + (wc * TC + t) * 32 + q * 8 + half * 4;   // first of 4 channels
@@ -503,6 +598,16 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
                         else z = sy_sigmoid(z);
                     }
                     v[j] = z;
+                }
+                if (kCanStage && stage_out) {
+                    elem e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = T::from_f32(v[j]);
+                    uint2 o;
+                    __builtin_memcpy(&o, e, 8);
+                    *reinterpret_cast<uint2*>(stg + ((wp * TP + u) * 32 + l31) * kStagePitch +
+                                              ((wc * TC + t) * 32 + q * 8 + half * 4) * 2) = o;
+                    continue;
                 }
                 if (!m_ok || cb >= p.Cout) continue;   // (inside the q loop)
                 if (vec_ok) {
@@ -564,8 +669,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
         if (want_stats) {
             // reduce over the 32 pixels held by lanes with equal `half`; park the wave's 32 channel sums in LDS
             // (the K loop is over: sW is free after the barrier below), fold the WP waves, one atomic per channel.
-            float* red = reinterpret_cast<float*>(sW);            // [WP][CT][2]
-            if (t == 0) __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);          // [WP][CT][2]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float a = ssum[r], b = ssq[r];
@@ -582,9 +686,20 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
             }
         }
     });
+    if (want_stats || (kCanStage && stage_out)) __syncthreads();
+    if (kCanStage && stage_out) {
+        constexpr int CPR = CT / 8;                             // 16-byte chunks per staged pixel row
+        for (int i = tid; i < PT * CPR; i += kThreads) {
+            const int px = i / CPR, ck = i - px * CPR;
+            const long long off = stg_off[px];
+            const int co = c0 + ck * 8;
+            if (off < 0 || co >= p.Cout) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + px * kStagePitch + ck * 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + off + co) = v;
+        }
+    }
     if (want_stats) {
-        __syncthreads();
-        const float* red = reinterpret_cast<const float*>(sW);
+        const float* red = reinterpret_cast<const float*>(smem);
         const int copy = bid.z * p.stat_copies + (int)((unsigned)bid.y % (unsigned)p.stat_copies);
         for (int cl = tid; cl < CT; cl += kThreads) {
             const int co = c0 + cl;
@@ -607,8 +722,11 @@ int launch_one(const ConvArgs& a, void* stream) {
     dim3 grid((a.Cout + CT - 1) / CT, ((a.seg_M > 0 ? a.seg_M : a.M) + PT - 1) / PT, nseg);
     if (a.s2_classes) grid = dim3(grid.x, (a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2) + PT - 1) / PT, 4);
     // STG 5 keeps only the pixel tile in LDS (the BN-statistics scratch [WP][CT][2] floats aliases it after the K loop)
-    constexpr size_t smem = (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
-                                       : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
+    constexpr size_t smem_k = (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
+                                         : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
+    // epilogue staging of 16-bit outputs (see the kernel): statistics scratch + [PT][CT*2+16] + [PT] offsets
+    constexpr size_t smem_e = (size_t)WP * CT * 8 + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
+    constexpr size_t smem = (T::kEPC == 8 && smem_e <= 48 * 1024 && smem_e > smem_k) ? smem_e : smem_k;
 #ifndef SY_EMU
     static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
     if (!attr_done) {

@@ -39,6 +39,17 @@ struct BF16 {   // bfloat16 storage; arithmetic is always fp32
         u += 0x7fffu + ((u >> 16) & 1u);
         return (elem)(u >> 16);
     }
+    // two fp32 -> packed pair, round-to-nearest-even: v_cvt_pk_bf16_f32 on gfx950 (one VALU op for two elements)
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+#ifdef SY_EMU
+        return (unsigned)from_f32(a) | ((unsigned)from_f32(b) << 16);
+#else
+        typedef __bf16 sy_bf2 __attribute__((ext_vector_type(2)));
+        typedef float sy_f2 __attribute__((ext_vector_type(2)));
+        const sy_f2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sy_bf2));
+#endif
+    }
 };
 struct F16 {
     typedef unsigned short elem;
@@ -46,6 +57,7 @@ struct F16 {
     static constexpr int kEPC = 8;
     static __device__ __forceinline__ float to_f32(elem h) { return (float)__builtin_bit_cast(_Float16, h); }
     static __device__ __forceinline__ elem from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)from_f32(a) | ((unsigned)from_f32(b) << 16); }
 };
 struct F32 {
     typedef float elem;
@@ -53,6 +65,7 @@ struct F32 {
     static constexpr int kEPC = 4;
     static __device__ __forceinline__ float to_f32(elem h) { return h; }
     static __device__ __forceinline__ elem from_f32(float f) { return f; }
+    static __device__ __forceinline__ unsigned pack2(float, float) { return 0u; }   // 16-bit staging only
 };
 
 // ---- MFMA wrappers ------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--tiles", default="0,22,38,83,86,87,88,89,24")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--chain", type=int, default=1, help="launches per timed event pair (amortises the event / launch gap)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     tiles = [int(t) for t in a.tiles.split(",")]
@@ -76,10 +77,11 @@ def main():
                 for _ in range(a.reps):
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
-                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t, wfrag=wf)
+                    for _ in range(a.chain):
+                        ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t, wfrag=wf)
                     e.record()
                     torch.cuda.synchronize()
-                    ts.append(s.elapsed_time(e))
+                    ts.append(s.elapsed_time(e) / a.chain)
                 ts.sort()
                 res.append(flops / (ts[len(ts) // 2] * 1e-3) / 1e12)
             except Exception as ex:                                    # noqa: BLE001
