@@ -6,6 +6,7 @@
 // Replaces nn.BatchNorm2d (training mode, eps/momentum patched by init_yolo — cfgs/<name>.py:40-44 of
 // the reference), nn.SiLU, SPPBottleneck's three nn.MaxPool2d + cat (exps/model/darknet.py:156) and
 // their autograd backward kernels.
+#include <stdlib.h>
 #include "sy_pointwise.h"
 
 namespace {
@@ -352,6 +353,11 @@ __global__ __launch_bounds__(kBlock) void fold_replicas_kernel(float* sums, int 
 
 inline bool chunk_rows_ok(int C, int e) { const int cpp = C / e; return cpp >= 1 && cpp <= kBlock; }
 
+inline int env_cap(const char* name, int dflt) {          // tuning knob (tools/): workgroups per launch of the row kernels
+    const char* v = getenv(name);
+    return (v != nullptr && atoi(v) > 0) ? atoi(v) : dflt;
+}
+
 inline int row_grid(long long pixels, int C, int e, int cap) {
     const int rows = kBlock / (C / e);
     long long b = (pixels + rows - 1) / rows;
@@ -408,7 +414,8 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048), nseg), dim3(kBlock), 0, stream,
+    static const int cap_apply = env_cap("SY_BN_APPLY_BLOCKS", 4096);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
 }
@@ -420,7 +427,8 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, 2048), nseg), dim3(kBlock), 0, stream,
+    static const int cap_reduce = env_cap("SY_BN_REDUCE_BLOCKS", 1024);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, cap_reduce / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, sums, (long long)pixels, C, copies));
 }
@@ -441,7 +449,8 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
                   const_cast<float*>(sums), 2 * C, copies);
         copies = 1;
     }
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, 2048), nseg), dim3(kBlock), 0, stream,
+    static const int cap_bapply = env_cap("SY_BN_BAPPLY_BLOCKS", 2048);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
                                        dgamma, dbeta, seg_sum_stride));
