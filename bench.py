@@ -99,6 +99,23 @@ def cpu_baseline(args, workload, flops_pair):
             "gflops_effective": n * flops_pair / el / 1e9}
 
 
+def pmc_traffic(workload, args, B):
+    """HBM-side bytes per step of the MFMA kernels from the committed PMC passes of this exact configuration
+    (tools/pmc_traffic.py: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE in separate passes).  PMC collection
+    serialises kernels, so it is not re-run inside the timed bench; null when no matching measurement exists."""
+    import glob
+    if (args.height, args.width) != (600, 960) or args.dtype != "bf16" or B != 8:
+        return None, None
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%s_%s.json" % (workload, args.model))))
+    if not hits:
+        return None, None
+    try:
+        with open(hits[-1]) as fh:
+            return float(json.load(fh)["mfma_kernels_bytes"]), os.path.relpath(hits[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -228,9 +245,11 @@ def main():
         prof = profile(3)                                       # {kind: ms per step}
         mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad"))
         ach = flops_pair * B / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel" + ("+conv_wgrad_kernel" if workload == "train" else ""),
+        traffic, traffic_src = pmc_traffic(workload, args, B)
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel" + ("+conv_wgrad_tr_kernel" if workload == "train" else ""),
                     "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": None,
+                    "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_unit": "bytes/step (MFMA kernels)",
+                    "traffic_source": traffic_src,
                     "flops_per_step": flops_pair * B, "kernel_ms_per_step": mfma_ms,
                     "per_kind_ms": {k: round(v, 4) for k, v in prof.items()},
                     "whole_step_frac": flops_pair * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype]}
