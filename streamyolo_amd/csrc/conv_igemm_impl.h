@@ -67,6 +67,10 @@ constexpr int kPitchRS = 80;        // register-staged: 64 B of K + 16 B pad per
 
 static __device__ uint4 g_zero16[4] = {};  // DMA generic loader: source of every predicated-off 16-byte chunk
 
+template <typename T, int WC, int WP, int TC, int TP, typename Args>
+__device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int bz, f32x16 (&acc)[TC][TP],
+                                              unsigned char* smem, int tid);
+
 // STG: staging strategy — 1 = register-staged; 2 / 3 / 4 (0 = 4) = LDS-DMA ring of that depth (depth-1 slabs of
 // loads in flight while one feeds the MFMAs; a shallow ring costs less LDS, so more workgroups share a CU).
 template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
@@ -208,12 +212,12 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
         }
         int f_kh = kh0, f_kw = kw0, f_c = 0, f_t = kh0 * p.KW + kw0, f_cs = 0;   // wave-uniform K position of the next slab to fetch
         unsigned s_x = 0, s_w = 0, s_f = 0;
+        // pixel delta of tap (kh, kw): forward +(kh*W + kw); data gradient -(kh*W + kw), at half resolution for stride 2
+        const int tap_sh = half_res ? 1 : 0;
+        const int tap_ld = (p.mode == SY_CONV_FWD) ? p.ldx : -p.ldx;
         auto slab_offsets = [&]() {                          // uniform offsets of slab (f_t, f_c); then advance
-            int dpix;
-            if (p.mode == SY_CONV_FWD) dpix = f_kh * p.W + f_kw;
-            else if (p.stride == 2) dpix = -((f_kh >> 1) * p.W + (f_kw >> 1));
-            else dpix = -(f_kh * p.W + f_kw);
-            s_x = (unsigned)((dpix * p.ldx + f_c) * ESZ);
+            const int dpix = (f_kh >> tap_sh) * p.W + (f_kw >> tap_sh);
+            s_x = (unsigned)((dpix * tap_ld + f_c) * ESZ);
             s_w = (unsigned)((f_t * p.Cin + f_c) * ESZ);
             s_f = (unsigned)((f_cs * ntaps + f_t) * 2048);   // fragment-packed weights: [cslab][tap] blocks of 2 KiB
         };
@@ -241,11 +245,13 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
             uint4 fa[TC][2], fn[TC][2], rx[XCH];
             auto load_slab = [&]() {
                 slab_offsets();
+                // fragment loads: the per-lane offset is fixed for the whole kernel, the slab position rides in the
+                // scalar offset operand of the buffer load (no VALU address math)
 #pragma unroll
                 for (int t = 0; t < TC; ++t)
 #pragma unroll
                     for (int g = 0; g < 2; ++g)
-                        fn[t][g] = sy_buffer_load16(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + s_f + (unsigned)(g * 1024));
+                        fn[t][g] = sy_buffer_load16_s(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + (unsigned)(g * 1024), s_f);
 #pragma unroll
                 for (int i = 0; i < XCH; ++i) rx[i] = sy_buffer_load16(bufx, ((xmask[i] >> f_t) & 1u) ? xoff[i] + s_x : 0xFFFFFFFFu);
                 advance();
@@ -458,6 +464,42 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
+    // Everything below sees the kernel arguments and the tile geometry through LATE copies (SY_LATE_ARGS): values
+    // used only here are not kept in SGPRs across the K loop.
+    SY_LATE_ARGS(ConvArgs, p);
+    int e_bx = bid.x, e_by = bid.y, e_bz = bid.z;
+    SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_by); SY_LAUNDER_INT(e_bz);
+    conv_epilogue<T, WC, WP, TC, TP>(p_late, e_bx, e_by, e_bz, acc, smem, tid);
+}
+
+// The epilogue as a separate (inlined) function: its only inputs are the late argument view, the logical tile and
+// the accumulators, so none of the prologue's uniforms can be referenced (and kept alive) by accident.
+template <typename T, int WC, int WP, int TC, int TP, typename Args>
+__device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int bz, f32x16 (&acc)[TC][TP],
+                                              unsigned char* smem, int tid) {
+    typedef typename T::elem elem;
+    constexpr int kThreads = WC * WP * 64;
+    constexpr int EPC = T::kEPC;
+    constexpr int ESZ = 16 / EPC;
+    constexpr int CT = WC * TC * 32;
+    constexpr int PT = WP * TP * 32;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave / WP;
+    const int wp = wave % WP;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const int c0 = bx * CT;
+    int cls_ph = 0, cls_pw = 0, Hc = p.Ho, Wc = p.Wo, cls_M = p.M;
+    if (p.s2_classes) {
+        cls_ph = bz >> 1; cls_pw = bz & 1;
+        Hc = (p.Ho - cls_ph + 1) >> 1; Wc = (p.Wo - cls_pw + 1) >> 1;
+        cls_M = p.N * Hc * Wc;
+    }
+    const int cls_hw = Hc * Wc;
+    const int m_end = p.seg_M > 0 ? (bz + 1) * p.seg_M : cls_M;
+    const int m0 = (p.s2_classes ? 0 : bz * p.seg_M) + by * PT;
+    struct { int x, y, z; } bid = {bx, by, bz};
     const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
                         (p.res == nullptr || (p.ldr & 3) == 0);
     const bool want_stats = (p.stat_sum != nullptr);

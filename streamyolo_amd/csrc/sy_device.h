@@ -167,6 +167,12 @@ static inline uint4 sy_buffer_load16(const sy_buffer& b, unsigned voff) {
     if ((unsigned long long)voff + 16ull <= (unsigned long long)b.extent) __builtin_memcpy(&v, b.base + voff, 16);
     return v;
 }
+// voffset per lane + wave-uniform soffset (the hardware adds the scalar for free; range check on the sum)
+static inline uint4 sy_buffer_load16_s(const sy_buffer& b, unsigned voff, unsigned soff) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned long long)voff + soff + 16ull <= (unsigned long long)b.extent) __builtin_memcpy(&v, b.base + voff + soff, 16);
+    return v;
+}
 static inline void sy_glds16_buf(const sy_buffer& b, unsigned voff, unsigned char* lds_wave_base) {
     const uint4 v = sy_buffer_load16(b, voff);
     __builtin_memcpy(lds_wave_base + emu::lane_id() * 16, &v, 16);
@@ -179,6 +185,10 @@ __device__ __forceinline__ sy_buffer sy_make_buffer(const void* p, unsigned exte
 }
 __device__ __forceinline__ uint4 sy_buffer_load16(const sy_buffer& b, unsigned voff) {
     sy_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 sy_buffer_load16_s(const sy_buffer& b, unsigned voff, unsigned soff) {
+    sy_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, voff, soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 // LDS-DMA through a buffer descriptor: out-of-range lanes deposit zeros.  Inline asm for the same reason as
@@ -246,6 +256,23 @@ __device__ __forceinline__ sy_block_id sy_xcd_block_id() {
     b.z = (int)(L / (gx * gy));
     return b;
 }
+
+// ---- late kernel arguments -----------------------------------------------------------------------------------
+// hipcc loads every field of a by-value argument struct into SGPRs at kernel entry and keeps the ones the epilogue
+// needs alive across the main loop, where they crowd out (spill) the loop's own uniforms.  SY_LATE_ARGS re-reads the
+// struct from the kernarg segment through a laundered pointer: fields touched only after the loop are then loaded
+// after the loop (scalar loads, K$-resident).  The struct must be the kernel's first (only) parameter.
+#ifdef SY_EMU
+#define SY_LATE_ARGS(Type, p) const Type& p##_late = (p)
+#define SY_LAUNDER_INT(x) ((void)0)
+#else
+#define SY_LATE_ARGS(Type, p)                                                                                       \
+    const __attribute__((address_space(4))) Type* p##_late_ptr =                                                     \
+        (const __attribute__((address_space(4))) Type*)__builtin_amdgcn_kernarg_segment_ptr();                      \
+    asm volatile("" : "+s"(p##_late_ptr));                                                                          \
+    const __attribute__((address_space(4))) Type& p##_late = *p##_late_ptr
+#define SY_LAUNDER_INT(x) asm volatile("" : "+s"(x))
+#endif
 
 // ---- small math ---------------------------------------------------------------------------------
 #ifdef SY_EMU
