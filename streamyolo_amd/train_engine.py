@@ -294,6 +294,8 @@ class TrainPlan:
         for p in self.params:
             self.gview[id(p)] = self.arena[o:o + p.numel()].view(p.shape)
             o += p.numel()
+        self._build_buckets()
+        self.on_bucket = None                 # TrainStep: callable(k, main_stream, side_stream) -> starts the bucket's all-reduce
         self.bn_mods = [op.mod.bn for op in convs]
         self.stem_scratch = None
         self.pred_scratch = torch.zeros((2, 8, int(256 * head.width)), dtype=torch.float32, device=device)
@@ -431,6 +433,9 @@ class TrainPlan:
                         args()
                 else:
                     args()
+            elif name == "bucket":
+                if self.on_bucket is not None:
+                    self.on_bucket(args, main, side)
             elif side is None:
                 continue
             elif name == "side" or name == "fork":
@@ -514,27 +519,69 @@ class TrainPlan:
         self.tuned = True                                            # kernels are tuned after the first full step
         return self.arena
 
+    # ---- gradient buckets (data-parallel overlap) -----------------------------------------------------------
+    # The arena is in parameter order = forward order, the backward walk runs it back to front, so contiguous
+    # arena ranges complete one after the other.  _build_buckets cuts it into ranges of >= BUCKET_BYTES and notes,
+    # for each, the position of the backward walk after which every gradient in the range is final; the walk emits
+    # a "bucket" mark there and TrainStep starts that range's RCCL all-reduce while the rest of backward still runs.
+    BUCKET_BYTES = 32 << 20
+
+    def _backward_sequence(self):
+        nf = self.n_frame_ops
+        return list(reversed(self.ops[2 * nf:])) + [self.ops[i] for i in reversed(range(nf))]
+
+    def _build_buckets(self):
+        last = {}
+        for pos, op in enumerate(self._backward_sequence()):
+            if op.kind == "conv":
+                prm = (op.mod.conv.weight, op.mod.bn.weight, op.mod.bn.bias)
+            elif op.kind == "pred":
+                prm = tuple(t for m in (op.reg_mod, op.obj_mod, op.cls_mod) for t in (m.weight, m.bias))
+            else:
+                prm = ()
+            for t in prm:
+                last[id(t)] = pos
+        self.buckets, lo, o, ready = [], 0, 0, -1
+        for p in self.params:
+            o += p.numel()
+            ready = max(ready, last.get(id(p), -1))
+            if (o - lo) * 4 >= self.BUCKET_BYTES:
+                self.buckets.append((lo, o, ready))
+                lo, ready = o, -1
+        if o > lo:
+            self.buckets.append((lo, o, ready))
+        self.bucket_at = {}
+        for k, (_, _, r) in enumerate(self.buckets):
+            self.bucket_at.setdefault(r, []).append(k)
+
+    def _bucket_marks(self, pos):
+        for k in self.bucket_at.get(pos, ()):
+            self._mark("bucket", k)
+
     def _backward_ops(self, d_raw):
         G = self.grads
         G.reset()
         self.ring_i = 0
         nf = self.n_frame_ops
-        for op in reversed(self.ops[2 * nf:]):                   # head, then DFP fusion
-            if op.kind == "pred":
-                self._pred_backward(op, d_raw)
-            else:
-                self._conv_backward(op)
-        for i in reversed(range(nf)):                            # the two frames' networks, layer by layer together
-            a, b2 = self.ops[i], self.ops[nf + i]
-            if a.kind == "conv":
-                self._conv_pair_backward(a, b2)
-            else:
-                for op in (b2, a):
-                    if op.kind == "resize":
-                        dsrc, acc = G.target(op.src)
-                        ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
-                    elif op.kind == "spp":
-                        ops.spp_pool_bwd(G.view(op.v), op.argmax)
+        self._bucket_marks(-1)                                   # ranges no kernel writes (unused parameters)
+        for pos, a in enumerate(self._backward_sequence()):      # head, DFP fusion, then the per-frame network
+            if pos < len(self.ops) - 2 * nf:
+                if a.kind == "pred":
+                    self._pred_backward(a, d_raw)
+                else:
+                    self._conv_backward(a)
+            else:                                                # layer i of both frames together
+                b2 = self.ops[nf + (len(self.ops) - 2 * nf) + nf - 1 - pos]
+                if a.kind == "conv":
+                    self._conv_pair_backward(a, b2)
+                else:
+                    for op in (b2, a):
+                        if op.kind == "resize":
+                            dsrc, acc = G.target(op.src)
+                            ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
+                        elif op.kind == "spp":
+                            ops.spp_pool_bwd(G.view(op.v), op.argmax)
+            self._bucket_marks(pos)
         self._mark("join")
 
     # ---- weight gradients off the critical path -------------------------------------------------------------
@@ -795,6 +842,7 @@ class TrainStep:
         self.use_graph = (os.environ.get("STREAMYOLO_GRAPH", "0") != "0") if graph is None else bool(graph)
         self.graph = None
         self.eager_steps = 0
+        self.comm = None                            # stream the bucket all-reduces are issued from
         model.train()
         model.head.use_l1 = True                    # double_trainer.py:209-216 (no_aug_epochs == max_epoch)
 
@@ -825,6 +873,8 @@ class TrainStep:
         plan = self._ensure(x)
         self._last = (x, targets)
         lab, sup = targets
+        self._works, self._reduced = [], set()
+        plan.on_bucket = self._reduce_bucket if (self.world > 1 and not self.use_graph) else None
         graphable = self.use_graph and x.is_cuda and plan.run_table is not None and plan.tuned
         if self.graph is not None and not (plan.cache.valid() and plan.run_table.valid()):
             self.graph = None                                   # a parameter / buffer moved: the recording is stale
@@ -840,9 +890,32 @@ class TrainStep:
             out = self._eager(x, lab, sup)
             self.eager_steps += 1
         if self.world > 1:
-            self.dist.all_reduce(plan.arena)        # RCCL over xGMI: one collective over the whole arena
+            # buckets whose all-reduce was not started during backward (the first two steps run the Python
+            # wrappers / record the tape) go out now; then wait for all of them and average
+            for k, (lo, hi, _) in enumerate(plan.buckets):
+                if k not in self._reduced:
+                    self._works.append(self.dist.all_reduce(plan.arena[lo:hi], async_op=True))
+            for w in self._works:
+                w.wait()
             plan.arena.div_(self.world)
         return out
+
+    def _reduce_bucket(self, k, main, side):
+        """Start the RCCL all-reduce of gradient bucket k (its gradients are final on `main` and `side`); the
+        collective runs beside the rest of the backward pass."""
+        lo, hi, _ = self.plan.buckets[k]
+        view = self.plan.arena[lo:hi]
+        if main is not None:
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=self.plan.device)
+            self.comm.wait_stream(main)
+            if side is not None:
+                self.comm.wait_stream(side)
+            with torch.cuda.stream(self.comm):
+                self._works.append(self.dist.all_reduce(view, async_op=True))
+        else:
+            self._works.append(self.dist.all_reduce(view, async_op=True))
+        self._reduced.add(k)
 
     def profile(self, iters=2):
         x, targets = self._last
