@@ -93,3 +93,57 @@ def test_two_rank_gradient_allreduce_and_ddp(tmp_path):
         assert res["nonzero"]
         assert res["err_fast"] < 1e-5, res
         assert res["err_ddp"] < 1e-5, res
+
+
+@pytest.mark.gpu
+def test_bucketed_allreduce_streams_on_gpu_single_rank_rccl(golden_dir):
+    """The overlapped-bucket machinery on real streams with RCCL: a 1-rank `nccl` group makes every all-reduce the
+    identity, so with world_size=2 declared to TrainStep the taped step must return exactly half of the local
+    gradients — any missing stream dependency (communication stream vs main / weight-gradient stream) or a bucket
+    reduced before its gradients are final shows up as a mismatch."""
+    import numpy as np
+    import streamyolo_amd as sy
+    from streamyolo_amd import _lib, train_engine
+    from streamyolo_amd.train_engine import TrainStep
+    from oracle import streamyolo_oracle as O
+    from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
+    _lib.use_library(_lib.DEFAULT_PATH)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        z = np.load(os.path.join(golden_dir, "s_train_2x160x256.npz"))
+        B, H, W = [int(v) for v in z["shape"]]
+        cfg = O.OracleConfig.named("s")
+        sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+        x = synth_frames(B, H, W, seed=2).to(dev)
+        lab, sup = synth_labels(B, H, W, cfg.num_classes, num_gt=6, seed=3)
+        lab, sup = lab.to(dev), sup.to(dev)
+
+        def fresh():
+            m = sy.build_model("s")
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dev).train().set_compute_dtype("fp32")
+            m.head.use_l1 = True
+            return m
+        old = train_engine.TrainPlan.BUCKET_BYTES
+        train_engine.TrainPlan.BUCKET_BYTES = 4 << 20
+        try:
+            m = fresh()
+            ref = TrainStep(m)
+            ref.step(x, (lab, sup))
+            local = ref.plan.arena.clone()
+            state0 = {k: v.clone() for k, v in m.state_dict().items()}
+            m2 = fresh()
+            st = TrainStep(m2, world_size=2, process_group=dist)
+            for i in range(4):
+                m2.load_state_dict(state0)
+                st.step(x, (lab, sup))
+                torch.cuda.synchronize()
+                err = float((st.plan.arena - 0.5 * local).abs().max() / local.abs().max())
+                assert err < 1e-4, (i, err)
+            assert len(st.plan.buckets) >= 3 and len(st._reduced) == len(st.plan.buckets)
+        finally:
+            train_engine.TrainPlan.BUCKET_BYTES = old
+    finally:
+        dist.destroy_process_group()
