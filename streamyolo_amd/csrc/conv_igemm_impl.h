@@ -74,10 +74,11 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
 // STG: staging strategy — 1 = register-staged; 2 / 3 / 4 (0 = 4) = LDS-DMA ring of that depth (depth-1 slabs of
 // loads in flight while one feeds the MFMAs; a shallow ring costs less LDS, so more workgroups share a CU).
 template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
-__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WC * WP * 64, ((TC * TP <= 4 && !(STG == 6 && TC * TP == 4)) ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
     typedef typename T::elem elem;
-    constexpr int RS = (STG == 1 || STG == 5) ? 1 : 0;
-    constexpr int WR = (STG == 5) ? 1 : 0;          // weights: fragment-packed, global -> VGPR, never in LDS
+    constexpr int RS = (STG == 1 || STG == 5 || STG == 6) ? 1 : 0;
+    constexpr int WR = (STG == 5 || STG == 6) ? 1 : 0;   // weights: fragment-packed, global -> VGPR, never in LDS
+    constexpr int WR3 = (STG == 6) ? 1 : 0;         // ... with three register stages and two LDS pixel buffers
     constexpr int kStages = RS ? 1 : (STG == 0 ? 4 : STG);
     constexpr int kThreads = WC * WP * 64;       // 4 or 8 waves
     constexpr int RPI = kThreads / 4;            // rows staged per sweep of the workgroup (one 16-byte chunk per lane)
@@ -242,6 +243,71 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
                 const int ct = bid.x * (CT / 32) + wc * TC + t;
                 foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * nslab_all) * 128 + lane) * 16) : 0xFFFFFFFFu;
             }
+            if constexpr (WR3) {
+                // ---- three register stages, two LDS pixel buffers.  Iteration s: (1) issue the pixel loads of slab
+                //      s+3, (2) park slab s+1's pixels (landed by now) in the other LDS buffer, (3) multiply slab s,
+                //      (4) issue the weight fragments of slab s+3 into the registers slab s just used, (5) ONE barrier.
+                //      Loads get two full iterations to land (the single-stage loop above waits for them in the
+                //      iteration that issued them) and the second barrier per slab is gone.
+                uint4 fr[3][TC][2], rx3[3][XCH];
+                unsigned h_f[3] = {0u, 0u, 0u};                     // fragment offset of the slab whose pixels sit in set i
+                auto load_x = [&](auto set_) {
+                    constexpr int S = decltype(set_)::value;
+                    slab_offsets();
+                    h_f[S] = s_f;
+#pragma unroll
+                    for (int i = 0; i < XCH; ++i)
+                        rx3[S][i] = sy_buffer_load16(bufx, ((xmask[i] >> f_t) & 1u) ? xoff[i] + s_x : 0xFFFFFFFFu);
+                    advance();
+                };
+                auto load_f = [&](auto set_) {
+                    constexpr int S = decltype(set_)::value;
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+                            fr[S][t][g] = sy_buffer_load16_s(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + (unsigned)(g * 1024), h_f[S]);
+                };
+                auto store_x = [&](auto set_, int buf) {
+                    constexpr int S = decltype(set_)::value;
+#pragma unroll
+                    for (int i = 0; i < XCH; ++i)
+                        *reinterpret_cast<uint4*>(sX + buf * (PT * kPitchRS) + (row0 + i * RPI) * kPitchRS + kc * 16) = rx3[S][i];
+                };
+                auto mma = [&](auto set_, int buf) {
+                    constexpr int S = decltype(set_)::value;
+                    const unsigned char* bx = sX + buf * (PT * kPitchRS);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        uint4 b[TP];
+#pragma unroll
+                        for (int u = 0; u < TP; ++u)
+                            b[u] = *reinterpret_cast<const uint4*>(bx + ((wp * TP + u) * 32 + l31) * kPitchRS + (g * 2 + half) * 16);
+#pragma unroll
+                        for (int t = 0; t < TC; ++t)
+#pragma unroll
+                            for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), fr[S][t][g], b[u], acc[t][u]);
+                    }
+                };
+                load_x(sy_int<0>()); load_f(sy_int<0>());
+                if (nslab > 1) { load_x(sy_int<1>()); load_f(sy_int<1>()); }
+                if (nslab > 2) { load_x(sy_int<2>()); load_f(sy_int<2>()); }
+                store_x(sy_int<0>(), 0);
+                __syncthreads();
+                for (int s0 = 0; s0 < nslab; s0 += 3) {
+                    sy_static_for<0, 3>([&](auto j_) {
+                        constexpr int J = decltype(j_)::value;
+                        const int s = s0 + J;
+                        if (s < nslab) {                                  // uniform
+                            if (s + 3 < nslab) load_x(sy_int<J>());       // pixel registers of set J were parked last iteration
+                            if (s + 1 < nslab) store_x(sy_int<(J + 1) % 3>(), (s + 1) & 1);
+                            mma(sy_int<J>(), s & 1);
+                            if (s + 3 < nslab) load_f(sy_int<J>());
+                            __syncthreads();
+                        }
+                    });
+                }
+            } else {
             uint4 fa[TC][2], fn[TC][2], rx[XCH];
             auto load_slab = [&]() {
                 slab_offsets();
@@ -284,6 +350,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 4 : 2)) void conv_ige
                     store_slab();
                     __syncthreads();
                 }
+            }
             }
         } else if constexpr (RS) {
             uint4 rw[WCH], rx[XCH];
@@ -757,14 +824,15 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
 
 template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
 int launch_one(const ConvArgs& a, void* stream) {
-    constexpr int RS = (STG == 1 || STG == 5) ? 1 : 0;
+    constexpr int RS = (STG == 1 || STG == 5 || STG == 6) ? 1 : 0;
     constexpr int kStages = RS ? 1 : (STG == 0 ? 4 : STG);
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
     const int nseg = a.seg_M > 0 ? a.M / a.seg_M : 1;
     dim3 grid((a.Cout + CT - 1) / CT, ((a.seg_M > 0 ? a.seg_M : a.M) + PT - 1) / PT, nseg);
     if (a.s2_classes) grid = dim3(grid.x, (a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2) + PT - 1) / PT, 4);
     // STG 5 keeps only the pixel tile in LDS (the BN-statistics scratch [WP][CT][2] floats aliases it after the K loop)
-    constexpr size_t smem_k = (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
+    constexpr size_t smem_k = (STG == 6) ? (size_t)(2 * PT * kPitchRS > WP * CT * 8 ? 2 * PT * kPitchRS : WP * CT * 8)
+                              : (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
                                          : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
     // epilogue staging of 16-bit outputs (see the kernel): statistics scratch + [PT][CT*2+16] + [PT] offsets
     constexpr size_t smem_e = (size_t)WP * CT * 8 + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
@@ -788,8 +856,8 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
     ConvArgs a = a_in;
     const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32;
     a.s2_classes = (fast && a.mode != SY_CONV_FWD && a.stride == 2 && a.KH >= 2 && a.KW >= 2 && !(a_in.ablate & 4)) ? 1 : 0;
-    if constexpr (STG == 5) {       // fragment-packed weights exist only for the FAST traversal; else plain register staging
-        if (fast && a.wfrag != nullptr && a.wfrag_extent != 0) return launch_one<T, WC, WP, TC, TP, 5, 1>(a, stream);
+    if constexpr (STG == 5 || STG == 6) {   // fragment-packed weights exist only for the FAST traversal; else plain register staging
+        if (fast && a.wfrag != nullptr && a.wfrag_extent != 0) return launch_one<T, WC, WP, TC, TP, STG, 1>(a, stream);
         return fast ? launch_one<T, WC, WP, TC, TP, 1, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, 1, 0>(a, stream);
     } else {
         return fast ? launch_one<T, WC, WP, TC, TP, STG, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, STG, 0>(a, stream);
@@ -824,6 +892,10 @@ int launch_typed(const ConvArgs& a, void* stream) {
         case 80 + SY_TILE_256x128: return launch_cfg<T, 4, 1, 2, 4, 5>(a, stream);        // 4 waves x (64 ch x 128 px)
         case 80 + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 5>(a, stream);       // weights in registers
         case 80 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 5>(a, stream);
+        // + 96: weights in registers, three register stages + two LDS pixel buffers (one barrier per slab)
+        case 96 + SY_TILE_128x64: return launch_cfg<T, 4, 1, 1, 2, 6>(a, stream);
+        case 96 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 6>(a, stream);
+        case 96 + SY_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, 6>(a, stream);
         case 80 + SY_TILE_64x64: return launch_cfg<T, 2, 2, 1, 1, 5>(a, stream);
         case 80 + SY_TILE_64x256: return launch_cfg<T, 1, 4, 2, 2, 5>(a, stream);
         case 80 + SY_TILE_32x256: return launch_cfg<T, 1, 4, 1, 2, 5>(a, stream);

@@ -325,9 +325,9 @@ TILE_WR = 80           # codes >= 80: fragment-packed weights straight to VGPRs 
 _TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging strategy codes, see include/streamyolo_hip.h
     # rs = register-staged, d2/d3 = 2-/3-deep LDS-DMA ring (codes: include/streamyolo_hip.h)
     # wr = register-staged pixels + fragment-packed weights straight to VGPRs
-    "wide256": [19, 22, 23, 35, 38, 51, 54, 83, 86, 87],        # Cout >= 256 adds the 256-channel weights-in-register tiles
-    "wide": [19, 22, 23, 35, 38, 51, 54, 83, 86, 87],
-    "c64": [20, 23, 39, 55, 36, 84, 87],
+    "wide256": [19, 22, 23, 35, 38, 51, 54, 83, 86, 87, 99, 102, 103],        # Cout >= 256 adds the 256-channel weights-in-register tiles
+    "wide": [19, 22, 23, 35, 38, 51, 54, 83, 86, 87, 99, 102, 103],   # 96+: WR with 3 register stages
+    "c64": [20, 23, 39, 55, 36, 84, 87, 103],
     "c32": [21, 23, 39, 85, 87],
 }
 _tile_cache = {}

@@ -50,7 +50,7 @@ def test_conv_fwd_silu_residual(backend, dt, cin, cout, k, stride, H, W, N):
     assert float(yb.buf[..., :16].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 17, 18, 19, 20, 21, 22, 23, 35, 36, 38, 39, 51, 52, 54, 55, 83, 84, 85, 86, 87, 24, 88, 89])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 17, 18, 19, 20, 21, 22, 23, 35, 36, 38, 39, 51, 52, 54, 55, 83, 84, 85, 86, 87, 24, 88, 89, 99, 102, 103])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "dgrad")])
 def test_conv_every_tile_configuration(backend, tile, dt, mode):
     """Each workgroup tile (256x256 / 128x256 on 8 waves, 128x128 / 64x256 / 32x256 on 4) on a shape with
