@@ -578,7 +578,11 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
     constexpr int kStagePitch = CT * 2 + 16;                    // bytes per staged pixel row (+16: bank spread)
     constexpr int kStatBytes = WP * CT * 8;                     // BN-statistics scratch [WP][CT][2] floats (aliases too)
     constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 8 + kStatBytes <= 48 * 1024);
-    const bool stage_out = kCanStage && vec_ok && !p.y_f32 && !p.accumulate && p.res == nullptr;
+    // (+= outputs — data gradients of activations with several consumers — are staged too: the write-out pass reads
+    //  the old row chunk, adds in fp32 and stores, all coalesced; the staged value was already rounded to 16 bits,
+    //  one extra rounding the gradient path tolerates.  Residual adds keep the direct path: single rounding.)
+    const bool stage_out = kCanStage && vec_ok && !p.y_f32 && p.res == nullptr && ((p.ldy & 7) == 0) &&
+                           ((reinterpret_cast<unsigned long long>(p.y) & 15ull) == 0);
     unsigned char* const stg = smem + kStatBytes;               // [PT][kStagePitch]
     long long* const stg_off = reinterpret_cast<long long*>(smem + kStatBytes + PT * kStagePitch);   // [PT] element offsets
     if (want_stats || stage_out) __syncthreads();               // every wave is done with the operand tiles
@@ -803,8 +807,20 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
             const long long off = stg_off[px];
             const int co = c0 + ck * 8;
             if (off < 0 || co >= p.Cout) continue;
-            const uint4 v = *reinterpret_cast<const uint4*>(stg + px * kStagePitch + ck * 16);
-            *reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + off + co) = v;
+            uint4 v = *reinterpret_cast<const uint4*>(stg + px * kStagePitch + ck * 16);
+            uint4* const dst = reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + off + co);
+            if (p.accumulate) {
+                const uint4 o = *dst;
+                elem ev[8], eo[8];
+                __builtin_memcpy(ev, &v, 16);
+                __builtin_memcpy(eo, &o, 16);
+                unsigned w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] = T::pack2(T::to_f32(ev[2 * j]) + T::to_f32(eo[2 * j]), T::to_f32(ev[2 * j + 1]) + T::to_f32(eo[2 * j + 1]));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *dst = v;
         }
     }
     if (want_stats) {
