@@ -149,6 +149,8 @@ class _TapeProxy:
     def __getattr__(self, name):
         fn = getattr(self.real, name)
         tape = self.tape
+        if name.endswith("_supported") or name.endswith("_bytes") or name.endswith("version"):
+            return fn                                           # queries: no stream argument, nothing to replay
 
         def call(*args):
             tape.append((fn, args[:-1], name))                  # every entry point ends with `void* stream`
