@@ -1,10 +1,11 @@
 #!/bin/bash
-# stage "d" archive: full GPU suite, bench matrix, kernel stats, PMC traffic, probes
-mkdir -p gpurun_out/d
+# stage archive (copy the outputs to profiles/rNN/<stage>_*): full GPU suite, bench matrix, kernel stats, PMC traffic, probes
+mkdir -p gpurun_out/e
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/d
-(timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6) > $O/pytest_gpu_all.log 2>&1
+O=gpurun_out/e
+(timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -vE 'RCCL|HIP version|ROCm version|Hostname|Librccl' | tail -8) > $O/pytest_gpu_all.log 2>&1
+(timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2) > $O/smoke.log 2>&1
 (timeout 600 python bench.py --workload train --model l --steps 20 --warmup 5 --cpu-seconds 15 2>&1 | tail -1) > $O/bench_train_l.json 2>&1
 (timeout 300 python bench.py --workload train --model s --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1) > $O/bench_train_s.json 2>&1
 (timeout 300 python bench.py --workload infer --model l --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1) > $O/bench_infer_l.json 2>&1
@@ -16,8 +17,8 @@ rm -rf $O/prof
 (timeout 900 python tools/pmc_traffic.py --out $O/traffic_train_l.json -- --workload train --model l 2>&1 | tail -14) > $O/traffic_train_l.txt 2>&1
 (timeout 900 python tools/pmc_traffic.py --out $O/traffic_infer_l.json -- --workload infer --model l 2>&1 | tail -8) > $O/traffic_infer_l.txt 2>&1
 (timeout 600 python tools/profile_train.py 2>&1 | tail -75) > $O/train_l_layer_profile.txt 2>&1
-(timeout 600 python tools/conv_probe.py --tiles 0,86,87,83,22,19,38 --reps 5 --chain 10 2>&1 | tail -18) > $O/conv_variants_probe.txt 2>&1
+(timeout 600 python tools/conv_probe.py --tiles 86,102,87,103,83,22,19,38 --reps 5 --chain 10 2>&1 | tail -18) > $O/conv_variants_probe.txt 2>&1
 (timeout 600 python tools/wgrad_probe.py 2>&1 | tail -18) > $O/wgrad_variants_probe.txt 2>&1
 cat $O/pytest_gpu_all.log
 for f in $O/bench_*.json; do echo $f; cut -c1-260 $f; done
-cat $O/traffic_train_l.txt
+cat $O/smoke.log $O/traffic_train_l.txt
