@@ -2,8 +2,8 @@
 """HBM traffic of one training / inference step from rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM section):
 FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (TCC slot budget), both are reported in KiB, and on
 gfx950 FETCH_SIZE counts wide coalesced reads at half their size -> doubled here (WRITE_SIZE is left as reported:
-the guide calls it uncalibrated).  One step = the dispatches between the last two sy_pack_weights launches
-(training) or the whole run divided by the step count (inference).
+the guide calls it uncalibrated).  One step = the dispatches between the last two launches of a
+once-per-step kernel (weight staging in training, Focus packing in inference).
 
 Usage (GPU box):  python tools/pmc_traffic.py --out profiles/r01/traffic_train_l.json -- --workload train --model l
 """
@@ -47,10 +47,14 @@ def one_pass(counter, bench_args, workdir):
 
 
 def step_slice(rows):
-    marks = [i for i, r in enumerate(rows) if "pack_weights_kernel" in r[1]]
-    if len(marks) >= 2:
-        return rows[marks[-2]:marks[-1]], 1
-    return rows, None
+    """One step = the dispatches between the last two launches of a once-per-step kernel: the weight staging kernel
+    (training) or the Focus packing kernel (inference: one launch per forward, also inside hipGraph replays)."""
+    for mark in ("pack_weights_kernel", "focus_pack_kernel"):
+        marks = [i for i, r in enumerate(rows) if mark in r[1]]
+        marks = [m for k, m in enumerate(marks) if k == 0 or m - marks[k - 1] > 1]     # back-to-back launches = one step start
+        if len(marks) >= 2:
+            return rows[marks[-2]:marks[-1]], 1
+    raise SystemExit("pmc_traffic: no per-step delimiter kernel found")
 
 
 def main():
