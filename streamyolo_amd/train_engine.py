@@ -26,9 +26,7 @@ import os
 import torch
 
 from . import ops
-from .engine import (ConvOp, PredOp, ResizeOp, SppOp, ParamCache, _Builder, build_frame_net, build_fuse_net,
-                     build_head_net)
-from .model.packing import pack_conv_weight
+from .engine import _Builder, build_frame_net, build_fuse_net, build_head_net
 from .model.plan_cache import compute_dtype_for
 from .ops import View, EPI_LINEAR, CONV_DGRAD
 
@@ -269,11 +267,10 @@ class TrainPlan:
         # stream is already producing layer i-1's raw gradient, so a slot is reused only after its wgrad retired
         self.dyraw_ring = [torch.empty(max_raw, dtype=self.tdtype, device=device) for _ in range(self.RING)]
         self.ring_i = 0
-        self.dyraw_scratch = self.dyraw_ring[0]
         self.side = torch.cuda.Stream(device=device) if (device.type == "cuda" and self.STREAMS > 1) else None
         self.tuned = False                    # the first step (autotuning) runs on one stream
         self.force_serial = False             # profile(): per-kernel durations without overlap
-        self._ev_pool, self._ev_i = [], 0
+        self._ev_pool = []
         self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=device)
         for op in self.ops:
             if op.kind == "spp":
@@ -723,7 +720,6 @@ class TrainPlan:
     def profile(self, x, targets, iters=2, detail=False):
         """Per-op-kind kernel time (ms / step) with HIP events on the launch stream (bench.py roofline).
         detail=True: per (kind, shape) rows [(kind, shape, launches / step, ms / step, flops / step)] instead."""
-        import types
         evs = []
         real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply",
                                              "bn_silu_bwd_reduce", "bn_silu_bwd_apply", "resize_nearest",
