@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", type=int, default=1, help="infer / stream: replay the step from a hipGraph")
+    ap.add_argument("--with-optimizer", type=int, default=0,
+                    help="train: also run the fused SGD-nesterov + EMA step (sy_sgd_ema_step) inside every timed step "
+                         "(off by default: BASELINE.json's metric is forward + loss + backward)")
     ap.add_argument("--train-graph", type=int, default=0, help="train: hipGraph replay instead of launch tapes (slower on ROCm 7)")
     return ap.parse_args()
 
@@ -163,8 +166,16 @@ def main():
         stepper = TrainStep(model, world_size=world, process_group=dist, graph=bool(args.train_graph))
         lab, sup = lab.to(dev), sup.to(dev)
 
+        opt = [None]
+
         def step():
-            return stepper.step(x, (lab, sup))
+            out = stepper.step(x, (lab, sup))
+            if args.with_optimizer:
+                if opt[0] is None:
+                    from streamyolo_amd.optim import FusedSGDEMA
+                    opt[0] = FusedSGDEMA(model)
+                opt[0].step(1e-5)               # tiny lr: the synthetic batch must not blow the random-init weights up
+            return out
         profile = stepper.profile
     elif workload == "stream":
         # BASELINE.json configs[4]: on_pipe steady state, one 600x960 frame per step, decode + NMS included
@@ -273,6 +284,7 @@ def main():
                                       "random-init synthetic weights (utils/synth.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "hipgraph": bool(args.train_graph if workload == "train" else args.graph),
+                       "optimizer_in_step": bool(args.with_optimizer) if workload == "train" else None,
                        "host_launch_ms_per_step": round(host_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

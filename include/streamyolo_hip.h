@@ -135,6 +135,27 @@ SY_API int sy_postprocess(const float* pred, int B, int A, int num_classes, floa
                    int max_det, float* out_det, int32_t* out_index, int32_t* out_count,
                    void* workspace, void* stream);
 
+/* Optimizer + EMA step of one training iteration in one launch.  Replaces
+ * `scaler.step(optimizer)` + `ema_model.update(model)` (exps/train_utils/double_trainer.py:115-119):
+ * torch.optim.SGD(momentum, nesterov=True) semantics per entry — d = g*grad_scale; d += weight_decay*p;
+ * buf = first_step ? d : momentum*buf + d; d += momentum*buf; p -= lr*lr_mult*d — then yolox ModelEMA:
+ * ema = ema_decay*ema + (1-ema_decay)*p on the UPDATED p.  g == NULL: EMA only (BatchNorm running statistics);
+ * buf == NULL: no momentum; ema == NULL: no EMA.  grad_scale folds GradScaler's 1/scale and the 1/world_size of the
+ * gradient all-reduce.  chunk0 = prefix sum of ceil(n/1024) over the preceding entries; `entries` is DEVICE memory. */
+typedef struct sy_optim_entry {
+    float* p;
+    const float* g;
+    float* buf;
+    float* ema;
+    int64_t n;
+    float weight_decay;
+    float lr_mult;
+    int32_t chunk0;
+    int32_t reserved;
+} sy_optim_entry;
+SY_API int sy_sgd_ema_step(const sy_optim_entry* entries, int n_entries, int total_chunks, float lr, float momentum,
+                           float grad_scale, float ema_decay, int first_step, void* stream);
+
 /* Per-step weight staging: the nn.Parameters stay OIHW fp32 (the optimizer's master copy,
  * exps/train_utils/double_trainer.py:114-119); ONE launch re-derives, for every convolution of the step, the
  * layouts the MFMA kernels read.  Entry: a source block w[co_n][ci_n][taps] fp32 written as rows r0..r0+co_n of

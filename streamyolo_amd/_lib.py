@@ -54,6 +54,12 @@ class PackEntry(C.Structure):
                 ("tile0", C.c_int32), ("reserved", C.c_int32)]
 
 
+class OptimEntry(C.Structure):
+    """sy_optim_entry (include/streamyolo_hip.h)."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("buf", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_int64),
+                ("weight_decay", C.c_float), ("lr_mult", C.c_float), ("chunk0", C.c_int32), ("reserved", C.c_int32)]
+
+
 def pack_table(rows):
     """ctypes array of PackEntry with the tile0 prefix filled in -> (array, total_tiles)."""
     t = 0
@@ -88,6 +94,7 @@ SIGNATURES = {
     "sy_spp_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "sy_postprocess_workspace_bytes": (_L, [_I, _I]),
     "sy_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
+    "sy_sgd_ema_step": (_I, [_P, _I, _I, _F, _F, _F, _F, _I, _P]),
     "sy_pack_weights": (_I, [_P, _I, _I, _P]),
     "sy_bn_running_update": (_I, [_P, _I, _I, _P]),
     "sy_bn_finalize": (_I, [_P, _P, _I, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
