@@ -814,13 +814,22 @@ class _PlanFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(outs)
 
 
+def split_targets(model, targets):
+    """(labels, support): TALHead takes the pair `(t, st)` (yolox.py:37-38, tal_head.py:280-286); PIPEHead one tensor,
+    which then serves as its own support (model/pipe_head.py)."""
+    if getattr(model.head, "single_labels", False) and torch.is_tensor(targets):
+        return targets, targets
+    labels, support = targets
+    return labels, support
+
+
 def train_forward(model, x, targets):
     """YOLOX.forward in training mode (exps/model/yolox.py:33-46): returns the reference's loss dict."""
     if x.size()[1] == 3:
         x = torch.cat([x, x], dim=1)
     assert x.size()[1] == 6
     plan = get_train_plan(model, x)
-    labels, support = targets
+    labels, support = split_targets(model, targets)
     total, stats = _PlanFunction.apply(plan, x, labels, support, *plan.params)
     return {"total_loss": total, "iou_loss": stats[0], "l1_loss": stats[1], "conf_loss": stats[2],
             "cls_loss": stats[3], "num_fg": stats[4]}
@@ -840,7 +849,9 @@ class TrainStep:
         self.eager_steps = 0
         self.comm = None                            # stream the bucket all-reduces are issued from
         model.train()
-        model.head.use_l1 = True                    # double_trainer.py:209-216 (no_aug_epochs == max_epoch)
+        if not getattr(model.head, "single_labels", False):
+            model.head.use_l1 = True                # double_trainer.py:209-216 (no_aug_epochs == max_epoch); TALHead's L1
+                                                    # branch is unguarded (tal_head.py:435), PIPEHead honours use_l1
 
     def _ensure(self, x):
         if self.plan is None:
@@ -868,7 +879,7 @@ class TrainStep:
     def step(self, x, targets):
         plan = self._ensure(x)
         self._last = (x, targets)
-        lab, sup = targets
+        lab, sup = split_targets(self.model, targets)
         self._works, self._reduced = [], set()
         plan.on_bucket = self._reduce_bucket if (self.world > 1 and not self.use_graph) else None
         graphable = self.use_graph and x.is_cuda and plan.run_table is not None and plan.tuned

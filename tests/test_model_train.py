@@ -159,3 +159,29 @@ def test_overlapped_step_matches_single_stream(golden_dir):
     for k in z.files:
         if k.startswith("stat:") and "running" in k:
             assert _rel(sd[k[5:]].cpu(), z[k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("use_l1", [True, False])
+def test_pipe_head_training_matches_reference(backend, golden_dir, use_l1):
+    """YOLOX(DFPPAFPN, PIPEHead) — cfgs/l_s50_still_dfp_flip.py — against the reference's own pipe_head.py outputs
+    (oracle/make_golden_pipe.py): one label tensor, no trend weights, L1 term only when `use_l1`."""
+    z = np.load(os.path.join(golden_dir, "nano_pipe_train_2x64x96.npz"))
+    B, H, W = [int(v) for v in z["shape"]]
+    cfg = O.OracleConfig.named("nano")
+    model = sy.build_model("nano", head="pipe")
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0), strict=True)
+    model = model.to(backend).train().set_compute_dtype("fp32")
+    model.head.use_l1 = use_l1
+    x = synth_frames(B, H, W, seed=2).to(backend)
+    lab, _ = synth_labels(B, H, W, cfg.num_classes, num_gt=6, seed=3)
+    out = model(x, lab.to(backend))
+    out["total_loss"].backward()
+    tag = "l1" if use_l1 else "nol1"
+    got = np.array([float(out[k]) for k in NAMES])
+    assert np.abs(got - z["losses_" + tag]).max() / np.abs(z["losses_" + tag]).max() < 1e-3
+    named = dict(model.named_parameters())
+    for k in z.files:
+        if k.startswith("grad_%s:" % tag):
+            assert _rel(named[k.split(":", 1)[1]].grad.cpu(), z[k]) < 2e-3, k
+    norms = np.array([float(named[k].grad.double().norm()) for k in sorted(named)])
+    assert np.abs(norms - z["grad_norms_" + tag]).max() / np.abs(z["grad_norms_" + tag]).max() < 2e-3
