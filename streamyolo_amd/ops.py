@@ -338,6 +338,21 @@ def autotune_enabled(device):
     return device.type == "cuda" and os.environ.get("STREAMYOLO_AUTOTUNE", "1") != "0"
 
 
+def _time_launches(run, device, launches=4, rounds=2):
+    """Best of `rounds` timings of `launches` back-to-back launches (HIP events on the current stream), in ms."""
+    best = float("inf")
+    for _ in range(rounds):
+        torch.cuda.synchronize(device)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(launches):
+            run()
+        e.record()
+        torch.cuda.synchronize(device)
+        best = min(best, s.elapsed_time(e))
+    return best
+
+
 def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False):
     """Fastest sy_conv2d variant for this problem shape (H, W = INPUT size of the launch), or 0 (the
     library's static heuristic) when tuning is off.  Measured with HIP events on dummy tensors."""
@@ -377,14 +392,7 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
                        mode=mode, tile=t, wfrag=wf)
         try:
             run()
-            torch.cuda.synchronize(device)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(3):
-                run()
-            e.record()
-            torch.cuda.synchronize(device)
-            dt = s.elapsed_time(e)
+            dt = _time_launches(run, device)
         except _lib.HipLibraryError:
             continue
         if dt < best_t:
@@ -418,15 +426,10 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
         if (t & 15) == 2 and Cout < 64:
             continue
         try:
-            conv2d_wgrad(x, dy, dw, k, stride, oihw=True, workspace=workspace, tile=t, target_blocks=tb)
-            torch.cuda.synchronize(device)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(3):
+            def run():
                 conv2d_wgrad(x, dy, dw, k, stride, oihw=True, workspace=workspace, tile=t, target_blocks=tb)
-            e.record()
-            torch.cuda.synchronize(device)
-            dt = s.elapsed_time(e)
+            run()
+            dt = _time_launches(run, device)
         except _lib.HipLibraryError:
             continue
         if dt < best_t:
