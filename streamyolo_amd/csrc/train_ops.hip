@@ -65,6 +65,92 @@ __global__ __launch_bounds__(kBlock) void spp_pool_kernel(typename T::elem* buf,
     }
 }
 
+// LDS-tiled form of the same pooling (H*W small enough for one image's channel chunk to sit in LDS, which is
+// every SPP on the path: 19x30 at 600x960): one workgroup per (image, 16-byte channel chunk).  The square
+// windows are separable — a horizontal pass keeps, per row and level, the row maximum and the dw of its FIRST
+// occurrence, a vertical pass takes the first row (smallest dh) holding the maximum — which is exactly the first
+// maximum of the row-major scan above, so pooled values AND arg-max bytes are bit-identical to
+// spp_pool_kernel with 13 + 27 LDS reads per pixel instead of 169 global loads.
+// LDS layout: in[HW] chunks | rv[3][HW] chunks (row maxima) | ra[3][HW][kEPC] bytes (dw + 6 of the row maximum).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem* buf, int H, int W, int C, int ld,
+                                                               long long bs, unsigned char* argmax) {
+    typedef typename T::elem elem;
+    constexpr int E = T::kEPC;
+    SY_DYN_SMEM(smem);
+    const int HW = H * W;
+    const int cpp = C / E;
+    const int cc = blockIdx.x % cpp, n = blockIdx.x / cpp;
+    unsigned char* s_in = smem;
+    unsigned char* s_rv = smem + (size_t)HW * 16;
+    unsigned char* s_ra = s_rv + (size_t)3 * HW * 16;
+    elem* base = buf + n * bs + cc * E;
+    for (int p = threadIdx.x; p < HW; p += kBlock) Chunk<T>::load(base + (long long)p * ld).store(s_in + (size_t)p * 16);
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += kBlock) {
+        const int w = p % W, row = p - w;
+        float m[3][E];
+        unsigned char a[3][E];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int j = 0; j < E; ++j) { m[l][j] = -INFINITY; a[l][j] = 6; }
+        for (int dw = -6; dw <= 6; ++dw) {
+            const int ww = w + dw;
+            if (ww < 0 || ww >= W) continue;
+            const int aw = dw < 0 ? -dw : dw;
+            Chunk<T> c = Chunk<T>::load(s_in + (size_t)(row + ww) * 16);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const float v = T::to_f32(c.e[j]);
+                if (v > m[2][j]) { m[2][j] = v; a[2][j] = (unsigned char)(dw + 6); }
+                if (aw <= 4 && v > m[1][j]) { m[1][j] = v; a[1][j] = (unsigned char)(dw + 6); }
+                if (aw <= 2 && v > m[0][j]) { m[0][j] = v; a[0][j] = (unsigned char)(dw + 6); }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            Chunk<T> o;
+#pragma unroll
+            for (int j = 0; j < E; ++j) o.e[j] = T::from_f32(m[l][j]);
+            o.store(s_rv + ((size_t)l * HW + p) * 16);
+            __builtin_memcpy(s_ra + ((size_t)l * HW + p) * E, a[l], E);
+        }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += kBlock) {
+        const int w = p % W, h = p / W;
+        elem* dst = base + (long long)p * ld;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int r = 2 * (l + 1);
+            float m[E];
+            unsigned char a[E];
+#pragma unroll
+            for (int j = 0; j < E; ++j) { m[j] = -INFINITY; a[j] = 0; }
+            for (int dh = -r; dh <= r; ++dh) {
+                const int hh = h + dh;
+                if (hh < 0 || hh >= H) continue;
+                const int q = hh * W + w;
+                Chunk<T> c = Chunk<T>::load(s_rv + ((size_t)l * HW + q) * 16);
+                unsigned char ra[E];
+                __builtin_memcpy(ra, s_ra + ((size_t)l * HW + q) * E, E);
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const float v = T::to_f32(c.e[j]);
+                    if (v > m[j]) { m[j] = v; a[j] = (unsigned char)((dh + 6) * 13 + ra[j]); }
+                }
+            }
+            Chunk<T> o;
+#pragma unroll
+            for (int j = 0; j < E; ++j) o.e[j] = T::from_f32(m[j]);
+            o.store(dst + (l + 1) * C);
+            if (argmax != nullptr)
+                __builtin_memcpy(argmax + (((long long)n * HW + p) * 3 + l) * C + cc * E, a, E);
+        }
+    }
+}
+
 // backward (gather form, deterministic, no atomics): source pixel (h,w) collects the pooled gradient of
 // every window whose recorded arg-max is (h,w), and adds it onto slice 0's gradient.
 template <typename T>
@@ -114,6 +200,68 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_kernel(typename T::elem* 
         Chunk<T> o;
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(acc[j]);
+        o.store(gslot0);
+    }
+}
+
+// LDS-tiled backward: one workgroup per (image, channel chunk) parks the chunk's arg-max bytes and pooled
+// gradients in LDS, then every source pixel runs the SAME ordered scan as spp_pool_bwd_kernel over LDS
+// (same additions in the same order -> bit-identical, deterministic).
+// LDS layout: g[HW][3] chunks | am[HW][3][kEPC] bytes.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::elem* dbuf, const unsigned char* argmax,
+                                                                   int H, int W, int C, int ld, long long bs) {
+    typedef typename T::elem elem;
+    constexpr int E = T::kEPC;
+    SY_DYN_SMEM(smem);
+    const int HW = H * W;
+    const int cpp = C / E;
+    const int cc = blockIdx.x % cpp, n = blockIdx.x / cpp;
+    unsigned char* s_g = smem;
+    unsigned char* s_am = smem + (size_t)HW * 3 * 16;
+    elem* base = dbuf + n * bs + cc * E;
+    for (int i = threadIdx.x; i < HW * 3; i += kBlock) {
+        const int p = i / 3, l = i - 3 * p;
+        Chunk<T>::load(base + (long long)p * ld + (l + 1) * C).store(s_g + (size_t)i * 16);
+        __builtin_memcpy(s_am + (size_t)i * E, argmax + (((long long)n * HW + p) * 3 + l) * C + cc * E, E);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += kBlock) {
+        const int w = p % W, h = p / W;
+        elem* gslot0 = base + (long long)p * ld;
+        Chunk<T> g0 = Chunk<T>::load(gslot0);
+        float acc[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[j] = T::to_f32(g0.e[j]);
+        for (int dh = -6; dh <= 6; ++dh) {
+            const int ch = h - dh;
+            if (ch < 0 || ch >= H) continue;
+            const int ah = dh < 0 ? -dh : dh;
+            for (int dw = -6; dw <= 6; ++dw) {
+                const int cw = w - dw;
+                if (cw < 0 || cw >= W) continue;
+                const int aw = dw < 0 ? -dw : dw;
+                const int d = ah > aw ? ah : aw;
+                const unsigned char code = (unsigned char)((dh + 6) * 13 + (dw + 6));
+                const int q = ch * W + cw;
+                const int l0 = d <= 2 ? 0 : (d <= 4 ? 1 : 2);
+                for (int l = l0; l < 3; ++l) {
+                    unsigned char cb[E];
+                    __builtin_memcpy(cb, s_am + ((size_t)q * 3 + l) * E, E);
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < E; ++j) any = any || (cb[j] == code);
+                    if (!any) continue;
+                    Chunk<T> g = Chunk<T>::load(s_g + ((size_t)q * 3 + l) * 16);
+#pragma unroll
+                    for (int j = 0; j < E; ++j)
+                        if (cb[j] == code) acc[j] += T::to_f32(g.e[j]);
+                }
+            }
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int j = 0; j < E; ++j) o.e[j] = T::from_f32(acc[j]);
         o.store(gslot0);
     }
 }
@@ -366,6 +514,22 @@ inline int row_grid(long long pixels, int C, int e, int cap) {
     return (int)b;
 }
 
+// the LDS-tiled SPP kernels take up to 144 KiB of dynamic LDS (of the CU's 160 KiB); larger feature maps use the scan kernels
+constexpr size_t kSppTileLds = 144 * 1024;
+inline bool spp_force_scan() { const char* v = getenv("SY_SPP_SCAN"); return v != nullptr && v[0] == '1'; }
+inline bool spp_lds_ok(const void* fn, int slot) {           // slot = kernel (0 fwd, 1 bwd) * 3 + dtype: set once each
+#ifdef SY_EMU
+    return true;
+#else
+    static bool done[6] = {false, false, false, false, false, false};
+    if (!done[slot]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppTileLds) != hipSuccess) return false;
+        done[slot] = true;
+    }
+    return true;
+#endif
+}
+
 }  // namespace
 
 extern "C" int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, void* argmax, int dtype,
@@ -374,6 +538,12 @@ extern "C" int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_
     const int e = epc_of(dtype);
     if (C % e || ld % e) return SY_ERR_UNSUPPORTED;
     const long long work = (long long)N * H * W * (C / e);
+    const size_t tile_lds = (size_t)H * W * (16 + 3 * 16 + 3 * e);      // in | row maxima | row arg-max bytes
+    if (tile_lds <= kSppTileLds && !spp_force_scan()) {
+        SY_DISPATCH_DTYPE(dtype, if (!spp_lds_ok((const void*)spp_pool_tile_kernel<T>, T::kCode)) return SY_ERR_LAUNCH;
+                          SY_LAUNCH((spp_pool_tile_kernel<T>), dim3(N * (C / e)), dim3(kBlock), tile_lds, stream,
+                                    (typename T::elem*)buf, H, W, C, ld, (long long)bs, (unsigned char*)argmax));
+    }
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((spp_pool_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream,
                                        (typename T::elem*)buf, N, H, W, C, ld, (long long)bs, (unsigned char*)argmax));
 }
@@ -384,6 +554,12 @@ extern "C" int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int
     const int e = epc_of(dtype);
     if (C % e || ld % e) return SY_ERR_UNSUPPORTED;
     const long long work = (long long)N * H * W * (C / e);
+    const size_t tile_lds = (size_t)H * W * 3 * (16 + e);                // pooled gradients | arg-max bytes
+    if (tile_lds <= kSppTileLds && !spp_force_scan()) {
+        SY_DISPATCH_DTYPE(dtype, if (!spp_lds_ok((const void*)spp_pool_bwd_tile_kernel<T>, 3 + T::kCode)) return SY_ERR_LAUNCH;
+                          SY_LAUNCH((spp_pool_bwd_tile_kernel<T>), dim3(N * (C / e)), dim3(kBlock), tile_lds, stream,
+                                    (typename T::elem*)dbuf, (const unsigned char*)argmax, H, W, C, ld, (long long)bs));
+    }
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((spp_pool_bwd_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream,
                                        (typename T::elem*)dbuf, (const unsigned char*)argmax, N, H, W, C, ld,
                                        (long long)bs));

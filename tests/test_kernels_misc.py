@@ -66,6 +66,30 @@ def test_spp_pool_fwd_bwd(backend, dt):
         assert _rel(dv.slice(0, C).nchw().cpu(), x.grad) < 1e-6
 
 
+@pytest.mark.parametrize("dt,H,W", [("bf16", 19, 30), ("fp32", 7, 5), ("bf16", 3, 5)])
+def test_spp_tile_kernels_match_scan_kernels(backend, dt, H, W, monkeypatch):
+    """The LDS-tiled (separable) SPP kernels must reproduce the scan kernels bit for bit — pooled values, the
+    arg-max bytes (ties included: bf16 inputs quantised to a few levels) and the routed gradients."""
+    g = torch.Generator().manual_seed(5)
+    N, C = 2, 16
+    x = (torch.randn(N, C, H, W, generator=g) * 2).round() / 2          # many exact ties
+    dy = torch.randn(N, 4 * C, H, W, generator=g)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SY_SPP_SCAN", mode)
+        v = View.alloc(N, H, W, 4 * C, dt, backend, zero=True)
+        v.slice(0, C).set_nchw(x.to(backend))
+        am = torch.zeros((N, H, W, 3, C), dtype=torch.uint8, device=backend)
+        ops.spp_pool(v, am)
+        dv = View.alloc(N, H, W, 4 * C, dt, backend); dv.set_nchw(dy.to(backend))
+        ops.spp_pool_bwd(dv, am)
+        res[mode] = (v.nchw().cpu().clone(), am.cpu().clone(), dv.nchw().cpu().clone())
+    pools = [F.max_pool2d(x, k, 1, k // 2) for k in (5, 9, 13)]
+    assert torch.equal(res["0"][0].float(), torch.cat([x] + pools, 1))
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
 def test_bn_train_silu_fwd_bwd(backend, dt):
     g = torch.Generator().manual_seed(4)
