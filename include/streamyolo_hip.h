@@ -111,6 +111,29 @@ SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
  * Replaces yolox Focus.forward slicing + cat (exps/model/darknet.py:115) and torch.split (dfp_pafpn.py:120,145). */
 SY_API int sy_focus_pack(const float* in, int N, int Ctot, int c0, int H, int W, void* out, int dtype, void* stream);
 
+/* Device-side input pipeline: uint8 HWC frames -> model input in ONE launch.
+ * cur / sup: [B, Hs, Ws, 3] uint8 (BGR as cv2.imread delivers them; sup = NULL for a single on_pipe frame),
+ * image_stride / row_stride in bytes.  Steps, in the reference's order:
+ *   decimate (1 | 2): the load-time cv2.resize (exps/dataset/tal_flip_one_future_argoversedataset.py:179-187,
+ *       streamyolo_det.py:177) for the two ratios that need no cv2 tables: copy, or exact 2x = (a+b+c+d+2)>>2;
+ *   mirror[b] != 0: `_mirror`'s image[:, ::-1], the same flag for both frames of a pair
+ *       (exps/data/data_augment_flip.py:140-148, DoubleTrainTransform :219-222);
+ *   letterbox onto an H x W canvas filled with 114, image at the top-left (`preproc` :151-167; r must be 1);
+ *   bilinear resize of the canvas to Ho x Wo when they differ (Exp.preprocess's F.interpolate(mode="bilinear",
+ *       align_corners=False), cfgs/l_s50_onex_dfp_tal_filp.py:161-172);
+ *   layout SY_FRAMES_NCHW: out_cur = fp32 [B, 3 or 6, Ho, Wo] (current channels first — np.concatenate((img,
+ *       support_img)), exps/data/tal_flip_mosaicdetection.py:257); out_sup unused;
+ *   layout SY_FRAMES_FOCUS: out_cur / out_sup = Focus-packed [B, Ho/2, Wo/2, 16] of `dtype` (what sy_focus_pack
+ *       would produce from the NCHW tensor: the stem convolution's operand). */
+enum { SY_FRAMES_NCHW = 0, SY_FRAMES_FOCUS = 1 };
+SY_API int sy_frames_u8_pack(const uint8_t* cur, const uint8_t* sup, int B, int Hs, int Ws, int64_t image_stride,
+                             int row_stride, int decimate, const uint8_t* mirror, int H, int W, int Ho, int Wo,
+                             int layout, void* out_cur, void* out_sup, int dtype, void* stream);
+
+/* Exp.preprocess's multi-scale resize on the reference's own tensor: fp32 NCHW [N, C, H, W] -> [N, C, Ho, Wo],
+ * torch bilinear, align_corners=False (cfgs/l_s50_onex_dfp_tal_filp.py:161-172).  C = 3 or 6. */
+SY_API int sy_resize_bilinear_nchw(const float* in, int N, int C, int H, int W, float* out, int Ho, int Wo, void* stream);
+
 /* Nearest-neighbour resize to a target SIZE (trap T3), writing into a channel slice.
  * Replaces F.interpolate(size=..., mode='nearest') + torch.cat (dfp_pafpn.py:125-126,130-131). */
 SY_API int sy_resize_nearest(const void* in, int N, int Hi, int Wi, int C, int ldi, int64_t ibs,

@@ -81,3 +81,12 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
         detections = detections[keep]
         output[i] = detections if output[i] is None else torch.cat((output[i], detections))
     return output
+
+
+def xyxy2cxcywh(bboxes):
+    """yolox.utils.boxes.xyxy2cxcywh (yolox 0.3.0): IN PLACE on the array it is given, returns it."""
+    bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 0]
+    bboxes[:, 3] = bboxes[:, 3] - bboxes[:, 1]
+    bboxes[:, 0] = bboxes[:, 0] + bboxes[:, 2] * 0.5
+    bboxes[:, 1] = bboxes[:, 1] + bboxes[:, 3] * 0.5
+    return bboxes

@@ -88,6 +88,8 @@ SIGNATURES = {
     "sy_conv2d": (_I, [C.POINTER(ConvDesc), _P]),
     "sy_conv2d_wgrad": (_I, [C.POINTER(WgradDesc), _P]),
     "sy_focus_pack": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "sy_frames_u8_pack": (_I, [_P, _P, _I, _I, _I, _L, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sy_resize_bilinear_nchw": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sy_resize_nearest": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _I, _I, _L, _I, _P]),
     "sy_resize_nearest_bwd": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _I, _I, _L, _I, _I, _P]),
     "sy_spp_pool": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _P]),

@@ -21,6 +21,7 @@ import math
 import torch
 
 from . import ops
+from .data import FramePairsU8
 from .ops import View, EPI_SILU, EPI_LINEAR, EPI_SIGMOID, EPI_DECODE, CONV_DGRAD
 from .model.packing import pack_conv_weight, pack_conv_weight_frag, fold_bn
 
@@ -332,7 +333,12 @@ class InferencePlan:
         x = x.float().contiguous()
         B = self.B
         n_fuse = 6
-        if self.pair:
+        if isinstance(x, FramePairsU8):                                # uint8 HWC frames straight to the stem operand
+            if self.pair:
+                x.pack_focus(_batch_slice(self.f0, 0, B), _batch_slice(self.f0, B, B))
+            else:
+                x.pack_focus(self.f0)
+        elif self.pair:
             ops.focus_pack(x, 0, _batch_slice(self.f0, 0, B))          # current frame  (dfp_pafpn.py:120)
             ops.focus_pack(x, 3, _batch_slice(self.f0, B, B))          # support frame  (:145)
         else:
@@ -352,7 +358,10 @@ class InferencePlan:
         fuse the current frame with the PRE-fusion PAN outputs kept from the previous call, then keep the
         current ones for the next call.  `first=True` = node 'star' (fuse with itself)."""
         assert not self.pair
-        ops.focus_pack(x.float().contiguous(), 0, self.f0)
+        if isinstance(x, FramePairsU8):
+            x.pack_focus(self.f0)
+        else:
+            ops.focus_pack(x.float().contiguous(), 0, self.f0)
         n_fuse = 6
         for op in self.ops[:self.n_backbone_ops - n_fuse]:
             self._run_op(op)

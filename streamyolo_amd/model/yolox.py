@@ -9,6 +9,7 @@ All arithmetic runs in HIP execution plans (streamyolo_amd/engine.py, train_engi
 import torch
 import torch.nn as nn
 
+from ..data import FramePairsU8
 from .dfp_pafpn import DFPPAFPN
 from .plan_cache import PlanCache
 from .tal_head import TALHead
@@ -44,7 +45,7 @@ class YOLOX(nn.Module):
                 from ..train_engine import train_forward
                 return train_forward(self, x, targets)
             if x.size()[1] == 3:                                   # dfp_pafpn.py:236-238
-                x = torch.cat([x, x], dim=1)
+                x = x.paired_with_self() if isinstance(x, FramePairsU8) else torch.cat([x, x], dim=1)
             assert x.size()[1] == 6
             plan = self._plans.inference(self.backbone, self.head, "off_pipe", x,
                                          decode=self.head.decode_in_inference, owner=self)

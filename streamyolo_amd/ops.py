@@ -167,6 +167,45 @@ def focus_pack(frames, c0, out):
           "sy_focus_pack")
 
 
+FRAMES_NCHW, FRAMES_FOCUS = 0, 1
+
+
+def frames_u8_pack(cur, sup, canvas, out_size, out_cur, out_sup=None, decimate=1, mirror=None):
+    """cur / sup: uint8 [B, Hs, Ws, 3] device tensors (sup None = single frame).  canvas = (H, W) letterbox size
+    (exp.input_size / test_size), out_size = (Ho, Wo).  out_cur: fp32 tensor [B, 3|6, Ho, Wo] (NCHW layout) or a
+    Focus-packed View [B, Ho/2, Wo/2, 16]; then out_sup is the support frame's View."""
+    assert cur.dtype == torch.uint8 and cur.dim() == 4 and cur.shape[3] == 3 and cur.stride(3) == 1 and cur.stride(2) == 3
+    B, Hs, Ws, _ = cur.shape
+    if sup is not None:
+        assert sup.dtype == torch.uint8 and sup.shape == cur.shape and sup.stride() == cur.stride()
+    if mirror is not None:
+        assert mirror.dtype == torch.uint8 and mirror.numel() == B and mirror.is_contiguous()
+    H, W = canvas
+    Ho, Wo = out_size
+    if isinstance(out_cur, View):
+        layout, dt = FRAMES_FOCUS, out_cur.dtype
+        for v in (out_cur, out_sup):
+            assert v is None or (v.C == 16 and v.ld == 16 and v.c_off == 0 and (v.N, v.H, v.W) == (B, Ho // 2, Wo // 2))
+        po, ps = out_cur.ptr(), (out_sup.ptr() if out_sup is not None else None)
+    else:
+        layout, dt = FRAMES_NCHW, DT_F32
+        assert out_cur.dtype == torch.float32 and out_cur.is_contiguous()
+        assert tuple(out_cur.shape) == (B, 3 if sup is None else 6, Ho, Wo)
+        po, ps = out_cur.data_ptr(), None
+    check(_lib.lib().sy_frames_u8_pack(cur.data_ptr(), _p(sup), B, Hs, Ws, cur.stride(0), cur.stride(1), int(decimate),
+                                       _p(mirror), H, W, Ho, Wo, layout, po, ps, dt, stream_of(cur)),
+          "sy_frames_u8_pack")
+
+
+def resize_bilinear_nchw(x, out):
+    """fp32 NCHW [N, 3|6, H, W] -> out [N, C, Ho, Wo]: torch bilinear, align_corners=False (Exp.preprocess)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous()
+    N, Cc, H, W = x.shape
+    assert out.shape[0] == N and out.shape[1] == Cc
+    check(_lib.lib().sy_resize_bilinear_nchw(x.data_ptr(), N, Cc, H, W, out.data_ptr(), out.shape[2], out.shape[3],
+                                             stream_of(x)), "sy_resize_bilinear_nchw")
+
+
 def resize_nearest(src, dst):
     assert src.C == dst.C and src.N == dst.N
     check(_lib.lib().sy_resize_nearest(src.ptr(), src.N, src.H, src.W, src.C, src.ld, src.bs, dst.ptr(), dst.H,

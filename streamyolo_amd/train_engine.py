@@ -26,6 +26,7 @@ import os
 import torch
 
 from . import ops
+from .data import FramePairsU8
 from .engine import _Builder, build_frame_net, build_fuse_net, build_head_net
 from .model.plan_cache import compute_dtype_for
 from .ops import View, EPI_LINEAR, CONV_DGRAD
@@ -309,8 +310,11 @@ class TrainPlan:
                 self.cache = StagedWeights(self.ops, self.dtype, self.device)
         self.cache.refresh()                                     # this step's weights -> MFMA operand layouts
         self.stat_arena.zero_()
-        ops.focus_pack(x, 0, self.f0_cur)
-        ops.focus_pack(x, 3, self.f0_sup)
+        if isinstance(x, FramePairsU8):                          # uint8 HWC frames: mirror / letterbox / resize / pack in one launch
+            x.pack_focus(self.f0_cur, self.f0_sup)
+        else:
+            ops.focus_pack(x, 0, self.f0_cur)
+            ops.focus_pack(x, 3, self.f0_sup)
         self._run("fwd", self._forward_ops)
         if self.run_table is None or not self.run_table.valid():
             mods = {}
@@ -826,7 +830,7 @@ def split_targets(model, targets):
 def train_forward(model, x, targets):
     """YOLOX.forward in training mode (exps/model/yolox.py:33-46): returns the reference's loss dict."""
     if x.size()[1] == 3:
-        x = torch.cat([x, x], dim=1)
+        x = x.paired_with_self() if isinstance(x, FramePairsU8) else torch.cat([x, x], dim=1)
     assert x.size()[1] == 6
     plan = get_train_plan(model, x)
     labels, support = split_targets(model, targets)

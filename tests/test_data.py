@@ -1,0 +1,138 @@
+"""Device input pipeline: sy_frames_u8_pack / sy_resize_bilinear_nchw against golden vectors
+minted from the reference's own `preproc` / `_mirror` / `DoubleTrainTransform` / `Exp.preprocess`
+(oracle/make_golden_input.py) and against the oracle restatement on larger seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import input_oracle as IO
+from streamyolo_amd import ops
+from streamyolo_amd.data import FramePairsU8, preprocess
+from streamyolo_amd.ops import View
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "input_pipeline.npz")))
+
+
+def test_oracle_matches_reference_golden(gold):
+    g = gold
+    H, W = g["a_ref"].shape[2:]
+    assert np.array_equal(IO.pair_tensor(g["a_cur"], g["a_sup"], (H, W), 1, g["a_mirror"]).numpy(), g["a_ref"])
+    assert np.array_equal(IO.pair_tensor(g["b_cur"], None, (H, W)).numpy(), g["b_ref"])
+    assert np.array_equal(IO.pair_tensor(g["c_cur"], None, (H, W), 2).numpy(), g["c_ref"])
+    assert np.array_equal(IO.pair_tensor(g["a_cur"][:1], g["a_sup"][:1], (H, W), 1, g["d_flag"]).numpy()[0], g["d_img"])
+    t = (torch.tensor([[[1.0, 10.0, 6.0, 8.0, 4.0]]]).repeat(2, 1, 1), torch.tensor([[[1.0, 11.0, 7.0, 8.0, 4.0]]]).repeat(2, 1, 1))
+    x, t = IO.exp_preprocess(torch.from_numpy(g["a_ref"]).clone(), t, tuple(g["e_tsize"]), (H, W))
+    assert np.array_equal(x.numpy(), g["e_ref"]) and np.array_equal(t[0].numpy(), g["e_t0"]) and np.array_equal(t[1].numpy(), g["e_t1"])
+
+
+def _dev(a, backend):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+
+
+def test_frames_to_nchw_bit_exact_vs_reference(backend, gold):
+    """uint8 HWC -> the reference's fp32 [B,6,H,W]: integer-valued, so bit-exact (mirror, letterbox, 2x decimation)."""
+    g = gold
+    H, W = g["a_ref"].shape[2:]
+    a = FramePairsU8(_dev(g["a_cur"], backend), _dev(g["a_sup"], backend), (H, W), mirror=_dev(g["a_mirror"], backend))
+    assert tuple(a.shape) == (2, 6, H, W)
+    assert np.array_equal(a.to_nchw().cpu().numpy(), g["a_ref"])
+    b = FramePairsU8(_dev(g["b_cur"], backend), None, (H, W))
+    assert np.array_equal(b.to_nchw().cpu().numpy(), g["b_ref"])
+    c = FramePairsU8(_dev(g["c_cur"], backend), None, (H, W), decimate=2)
+    assert np.array_equal(c.to_nchw().cpu().numpy(), g["c_ref"])
+    d = FramePairsU8(_dev(g["a_cur"][:1], backend), _dev(g["a_sup"][:1], backend), (H, W), mirror=_dev(g["d_flag"], backend))
+    assert np.array_equal(d.to_nchw().cpu().numpy()[0], g["d_img"])
+
+
+def test_exp_preprocess_matches_reference(backend, gold):
+    """Exp.preprocess: HIP bilinear (torch align_corners=False arithmetic) within 1e-5 relative of the reference's
+    F.interpolate output (fp32, 0-255 range), targets scaled in place exactly."""
+    g = gold
+    H, W = g["a_ref"].shape[2:]
+    tsize = tuple(int(v) for v in g["e_tsize"])
+    t = (torch.tensor([[[1.0, 10.0, 6.0, 8.0, 4.0]]]).repeat(2, 1, 1).to(backend),
+         torch.tensor([[[1.0, 11.0, 7.0, 8.0, 4.0]]]).repeat(2, 1, 1).to(backend))
+    x, t2 = preprocess(_dev(g["a_ref"], backend), t, tsize, (H, W))
+    assert tuple(x.shape) == g["e_ref"].shape
+    err = float((x.cpu() - torch.from_numpy(g["e_ref"])).abs().max())
+    assert err <= 1e-5 * 255.0, err
+    assert np.array_equal(t2[0].cpu().numpy(), g["e_t0"]) and np.array_equal(t2[1].cpu().numpy(), g["e_t1"])
+    # unchanged size: identity, same objects back (cfg :164)
+    x0 = _dev(g["a_ref"], backend)
+    y0, _ = preprocess(x0, t, (H, W), (H, W))
+    assert y0 is x0
+    # the uint8 route defers the resize into the pack kernel and must agree with resizing the fp32 tensor
+    f = FramePairsU8(_dev(g["a_cur"], backend), _dev(g["a_sup"], backend), (H, W), mirror=_dev(g["a_mirror"], backend))
+    t3 = (torch.zeros(2, 1, 5, device=backend), torch.zeros(2, 1, 5, device=backend))
+    f2, _ = preprocess(f, t3, tsize, (H, W))
+    assert float((f2.to_nchw().cpu() - torch.from_numpy(g["e_ref"])).abs().max()) <= 1e-5 * 255.0
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", ["same", "letterbox_mirror", "decimate", "resize"])
+def test_frames_to_focus_matches_oracle(backend, dt, case):
+    """Focus-packed stem operand straight from uint8 == oracle pipeline -> Focus slicing -> storage dtype."""
+    rng = np.random.RandomState(11)
+    B, H, W = 2, 20, 36
+    hs, ws, dec, mirror, tsize = H, W, 1, None, (H, W)
+    if case == "letterbox_mirror":
+        hs, mirror = H - 4, np.array([0, 1], dtype=np.uint8)
+    elif case == "decimate":
+        hs, ws, dec = 2 * H, 2 * W, 2
+    elif case == "resize":
+        tsize, mirror = (28, 44), np.array([1, 1], dtype=np.uint8)
+    cur = rng.randint(0, 256, (B, hs, ws, 3)).astype(np.uint8)
+    sup = rng.randint(0, 256, (B, hs, ws, 3)).astype(np.uint8)
+    ref = IO.pair_tensor(cur, sup, (H, W), dec, mirror)
+    tz = (torch.zeros(B, 1, 5), torch.zeros(B, 1, 5))
+    ref, _ = IO.exp_preprocess(ref, tz, tsize, (H, W))
+    f = FramePairsU8(_dev(cur, backend), _dev(sup, backend), (H, W), dec, _dev(mirror, backend), tsize)
+    vc = View.alloc(B, tsize[0] // 2, tsize[1] // 2, 16, dt, backend)
+    vs = View.alloc(B, tsize[0] // 2, tsize[1] // 2, 16, dt, backend)
+    f.pack_focus(vc, vs)
+    tdt = ops.TORCH_DTYPE[ops.dtype_code(dt)]
+    for v, c0 in ((vc, 0), (vs, 3)):
+        got = v.buf.cpu().float()
+        want = IO.focus_pack(ref[:, c0:c0 + 3])
+        assert torch.equal(got[..., 12:], torch.zeros_like(got[..., 12:]))
+        if case == "resize":
+            assert float((got[..., :12] - want.to(tdt).float()).abs().max()) <= (2.0 if dt == "bf16" else 1e-5 * 255.0)
+        else:
+            assert torch.equal(got[..., :12], want.to(tdt).float())
+
+
+def test_unsupported_ratio_is_an_error(backend):
+    """Ratios that would need cv2's interpolation tables are refused, not approximated."""
+    from streamyolo_amd._lib import HipLibraryError
+    cur = torch.zeros((1, 30, 50, 3), dtype=torch.uint8, device=backend)
+    with pytest.raises(HipLibraryError):
+        FramePairsU8(cur, None, (20, 36)).to_nchw()
+    with pytest.raises(HipLibraryError):
+        FramePairsU8(cur, None, (20, 36), decimate=3).to_nchw()
+
+
+def test_model_accepts_uint8_frames(backend):
+    """A FramePairsU8 through the eval facade == the reference-style fp32 tensor through it (same plan, same kernels)."""
+    import streamyolo_amd as sy
+    from oracle import streamyolo_oracle as O
+    from streamyolo_amd.utils.synth import synth_state_dict, load_bn_stats
+    cfg = O.OracleConfig.named("nano")
+    model = sy.build_model("nano")
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=load_bn_stats("nano")), strict=True)
+    model = model.to(backend).eval().set_compute_dtype("fp32")
+    rng = np.random.RandomState(5)
+    B, H, W = 1, 64, 96
+    cur = rng.randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    sup = rng.randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    f = FramePairsU8(_dev(cur, backend), _dev(sup, backend), (H, W))
+    with torch.no_grad():
+        a = model(f)
+        b = model(IO.pair_tensor(cur, sup, (H, W)).to(backend))
+        on_u8, _ = model(FramePairsU8(_dev(cur, backend), None, (H, W)), mode="on_pipe")
+        on_f, _ = model(IO.pair_tensor(cur, None, (H, W)).to(backend), mode="on_pipe")
+    assert torch.equal(a, b) and torch.equal(on_u8, on_f)
