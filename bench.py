@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--with-optimizer", type=int, default=0,
                     help="train: also run the fused SGD-nesterov + EMA step (sy_sgd_ema_step) inside every timed step "
                          "(off by default: BASELINE.json's metric is forward + loss + backward)")
+    ap.add_argument("--u8-input", type=int, default=0,
+                    help="stream: feed the raw uint8 HWC camera frame (2H x 2W, e.g. 1200x1920) — exact-2x decimation, "
+                         "letterbox and Focus packing run on the device (sy_frames_u8_pack) inside the timed step")
     ap.add_argument("--train-graph", type=int, default=0, help="train: hipGraph replay instead of launch tapes (slower on ROCm 7)")
     return ap.parse_args()
 
@@ -182,6 +185,12 @@ def main():
         from streamyolo_amd.postprocess import postprocess_device
         model.eval()
         frame = x[:, 0:3].contiguous()
+        if args.u8_input:
+            from streamyolo_amd.data import FramePairsU8
+            # same picture as the fp32 run (rounded to uint8), every pixel repeated 2x2 so the decimation returns it
+            raw = frame.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+            raw = raw.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+            frame = FramePairsU8(raw, None, (args.height, args.width), decimate=2)
         plan = model._plans.inference(model.backbone, model.head, "on_pipe", frame, owner=model)
         graph = None
 
@@ -285,6 +294,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "hipgraph": bool(args.train_graph if workload == "train" else args.graph),
                        "optimizer_in_step": bool(args.with_optimizer) if workload == "train" else None,
+                       "u8_input": bool(args.u8_input) if workload == "stream" else None,
                        "host_launch_ms_per_step": round(host_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -408,7 +408,10 @@ class InferencePlan:
             evs.append((kind, a, b))
         for _ in range(iters):
             B = self.B
-            if self.pair:
+            if isinstance(x, FramePairsU8):
+                timed("focus", lambda: x.pack_focus(*((_batch_slice(self.f0, 0, B), _batch_slice(self.f0, B, B))
+                                                      if self.pair else (self.f0,))))
+            elif self.pair:
                 timed("focus", lambda: (ops.focus_pack(x, 0, _batch_slice(self.f0, 0, B)),
                                         ops.focus_pack(x, 3, _batch_slice(self.f0, B, B))))
             else:
