@@ -204,10 +204,14 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_kernel(typename T::elem* 
     }
 }
 
-// LDS-tiled backward: one workgroup per (image, channel chunk) parks the chunk's arg-max bytes and pooled
-// gradients in LDS, then every source pixel runs the SAME ordered scan as spp_pool_bwd_kernel over LDS
-// (same additions in the same order -> bit-identical, deterministic).
-// LDS layout: g[HW][3] chunks | am[HW][3][kEPC] bytes.
+// LDS-tiled backward, separable like the forward: the arg-max of window (h, w, l) is reached through its row-stage
+// element (h + dh, w) and that element's own dw, so the routing factors into
+//   phase A  T[l][(h', w)] = sum of the pooled gradients of the <= 2r+1 centres of column w whose code selects row h'
+//            (dh ascending), and the dw they all carry (one row-stage element has ONE arg-max);
+//   phase B  source (h', x) += T[l][(h', x - dw)] for the <= 2r+1 row-stage elements whose dw points at x (l, dw ascending)
+// — 27 + 27 LDS probes per pixel instead of the 507 of the scan form.  No atomics: deterministic.  The additions are
+// grouped by row, so fp32 partial sums may differ from spp_pool_bwd_kernel's in the last bit.
+// LDS layout: g[HW][3] chunks | am[HW][3][E] bytes | T[3][HW][E] fp32 | dw[3][HW][E] bytes (0xFF: no contribution).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::elem* dbuf, const unsigned char* argmax,
                                                                    int H, int W, int C, int ld, long long bs) {
@@ -218,7 +222,9 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::e
     const int cpp = C / E;
     const int cc = blockIdx.x % cpp, n = blockIdx.x / cpp;
     unsigned char* s_g = smem;
-    unsigned char* s_am = smem + (size_t)HW * 3 * 16;
+    unsigned char* s_am = s_g + (size_t)HW * 3 * 16;
+    float* s_T = reinterpret_cast<float*>(s_am + (size_t)HW * 3 * E);      // HW * 3 * (16 + E) is a multiple of 4
+    unsigned char* s_dw = reinterpret_cast<unsigned char*>(s_T + (size_t)3 * HW * E);
     elem* base = dbuf + n * bs + cc * E;
     for (int i = threadIdx.x; i < HW * 3; i += kBlock) {
         const int p = i / 3, l = i - 3 * p;
@@ -226,37 +232,53 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::e
         __builtin_memcpy(s_am + (size_t)i * E, argmax + (((long long)n * HW + p) * 3 + l) * C + cc * E, E);
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < HW; p += kBlock) {
-        const int w = p % W, h = p / W;
+    for (int i = threadIdx.x; i < HW * 3; i += kBlock) {            // phase A: (level, row-stage element)
+        const int l = i / HW, p = i - l * HW;
+        const int w = p % W, hr = p / W;
+        const int r = 2 * (l + 1);
+        float t[E];
+        unsigned char rec[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) { t[j] = 0.0f; rec[j] = 0xFF; }
+        for (int dh = -r; dh <= r; ++dh) {
+            const int h = hr - dh;                                   // centre whose window row dh is this row
+            if (h < 0 || h >= H) continue;
+            const int q = h * W + w;
+            unsigned char cb[E];
+            __builtin_memcpy(cb, s_am + ((size_t)q * 3 + l) * E, E);
+            Chunk<T> g = Chunk<T>::load(s_g + ((size_t)q * 3 + l) * 16);
+            const int code0 = (dh + 6) * 13;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const unsigned d = (unsigned)((int)cb[j] - code0);
+                if (d < 13u) { t[j] += T::to_f32(g.e[j]); rec[j] = (unsigned char)d; }
+            }
+        }
+        __builtin_memcpy(s_T + (size_t)i * E, t, sizeof(t));
+        __builtin_memcpy(s_dw + (size_t)i * E, rec, E);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += kBlock) {                // phase B: source pixels
+        const int x = p % W, row = p - x;
         elem* gslot0 = base + (long long)p * ld;
         Chunk<T> g0 = Chunk<T>::load(gslot0);
         float acc[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) acc[j] = T::to_f32(g0.e[j]);
-        for (int dh = -6; dh <= 6; ++dh) {
-            const int ch = h - dh;
-            if (ch < 0 || ch >= H) continue;
-            const int ah = dh < 0 ? -dh : dh;
-            for (int dw = -6; dw <= 6; ++dw) {
-                const int cw = w - dw;
-                if (cw < 0 || cw >= W) continue;
-                const int aw = dw < 0 ? -dw : dw;
-                const int d = ah > aw ? ah : aw;
-                const unsigned char code = (unsigned char)((dh + 6) * 13 + (dw + 6));
-                const int q = ch * W + cw;
-                const int l0 = d <= 2 ? 0 : (d <= 4 ? 1 : 2);
-                for (int l = l0; l < 3; ++l) {
-                    unsigned char cb[E];
-                    __builtin_memcpy(cb, s_am + ((size_t)q * 3 + l) * E, E);
-                    bool any = false;
 #pragma unroll
-                    for (int j = 0; j < E; ++j) any = any || (cb[j] == code);
-                    if (!any) continue;
-                    Chunk<T> g = Chunk<T>::load(s_g + ((size_t)q * 3 + l) * 16);
+        for (int l = 0; l < 3; ++l) {
+            const int r = 2 * (l + 1);
+            for (int dw = -r; dw <= r; ++dw) {
+                const int w = x - dw;
+                if (w < 0 || w >= W) continue;
+                const size_t i = (size_t)l * HW + row + w;
+                unsigned char rec[E];
+                float t[E];
+                __builtin_memcpy(rec, s_dw + i * E, E);
+                __builtin_memcpy(t, s_T + i * E, sizeof(t));
 #pragma unroll
-                    for (int j = 0; j < E; ++j)
-                        if (cb[j] == code) acc[j] += T::to_f32(g.e[j]);
-                }
+                for (int j = 0; j < E; ++j)
+                    if (rec[j] == (unsigned char)(dw + 6)) acc[j] += t[j];
             }
         }
         Chunk<T> o;
@@ -554,7 +576,7 @@ extern "C" int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int
     const int e = epc_of(dtype);
     if (C % e || ld % e) return SY_ERR_UNSUPPORTED;
     const long long work = (long long)N * H * W * (C / e);
-    const size_t tile_lds = (size_t)H * W * 3 * (16 + e);                // pooled gradients | arg-max bytes
+    const size_t tile_lds = (size_t)H * W * 3 * (16 + e + 4 * e + e);    // pooled gradients | arg-max bytes | row sums | row dw
     if (tile_lds <= kSppTileLds && !spp_force_scan()) {
         SY_DISPATCH_DTYPE(dtype, if (!spp_lds_ok((const void*)spp_pool_bwd_tile_kernel<T>, 3 + T::kCode)) return SY_ERR_LAUNCH;
                           SY_LAUNCH((spp_pool_bwd_tile_kernel<T>), dim3(N * (C / e)), dim3(kBlock), tile_lds, stream,
