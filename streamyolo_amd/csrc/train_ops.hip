@@ -642,7 +642,8 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e || lddy % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e) || C > 1024) return SY_ERR_UNSUPPORTED;
-    if (copies > 1) {       // fold once here instead of in every workgroup of the apply pass (sums is consumed by it)
+    static const int fold_inline = env_cap("SY_BN_FOLD_INLINE", 2);      // replicas <= this: every workgroup folds them itself
+    if (copies > fold_inline) {       // many replicas: fold once here instead of in every workgroup of the apply pass
         SY_LAUNCH(fold_replicas_kernel, dim3((2 * C + kBlock - 1) / kBlock, nseg), dim3(kBlock), 0, stream,
                   const_cast<float*>(sums), 2 * C, copies);
         copies = 1;

@@ -191,8 +191,12 @@ class StagedWeights:
 
 
 class TrainPlan:
-    BWD_COPIES = 16              # replicas of each BN-backward reduction (same reason)
-    STAT_COPIES = 32             # replicas of each conv's sum / sum^2 arrays (atomic-contention control)
+    # replicas of each BN-backward reduction: 2, folded by every workgroup of the apply pass itself (no fold launch);
+    # measured 28.3 vs 28.6 ms per l step against 16 replicas + fold kernel (profiles/r01/f_*)
+    BWD_COPIES = int(os.environ.get("STREAMYOLO_BWD_COPIES", "2"))
+    # replicas of each conv's sum / sum^2 arrays: 4 are as fast as 32 but the longer fp32 atomic chains make the batch
+    # variance (E[y^2] - mean^2) visibly order-dependent (tape-replay test: 1e-4 instead of 1e-6 between identical steps)
+    STAT_COPIES = int(os.environ.get("STREAMYOLO_STAT_COPIES", "32"))
     WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
     RING = 3                     # raw-gradient scratch slots (wgrad of layer i overlaps BN backward / dgrad of i-1, i-2)
     STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
