@@ -1,0 +1,212 @@
+"""Streaming harness + evaluator glue: the callers on either side of the on_pipe hot path.
+
+Mirrors, name for name where the reference has a name:
+  inference()                 sAP/streamyolo/streamyolo_det.py:62-83     decoded output -> (boxes / in_scale, scores, labels, None)
+  StreamingDetector           streamyolo_det.py:96-124, :176-181         model.half() on_pipe loop state (buffer), warm-up, one frame
+  run_sequence()              streamyolo_det.py:138-199                  the real-time scheduling loop of one sequence
+  runtime_summary()           streamyolo_det.py:201-229 + sAP/util print_stats   timing statistics
+  pair_with_ground_truth()    sAP/streamyolo/streaming_eval.py:74-139    time-based prediction / ground-truth pairing -> COCO dicts
+  convert_to_coco_format()    exps/evaluators/onex_stream_evaluator.py:167-209   offline evaluator rows with the +1 frame-id shift
+
+Per-pixel and per-box arithmetic is on the device (sy_frames_u8_pack, the on_pipe plan, sy_postprocess); this file is the
+Python control flow the reference also keeps in Python.  Dataset access (pycocotools) and image decoding (cv2.imread)
+stay with the caller: every function takes plain lists / arrays.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .data import FramePairsU8
+from .postprocess import postprocess_device
+
+
+def inference(outputs, num_classes=8, conf_thre=0.01, nms_thresh=0.65, in_scale=0.5):
+    """`inference(result[0])` of streamyolo_det.py:62-83 for ONE image's decoded rows [A, 5+nc] (or [1, A, 5+nc]):
+    returns (bboxes xyxy / in_scale, scores = obj * class_conf, labels int32, None) as numpy arrays in descending
+    score order.  Filter + class-aware NMS run in sy_postprocess; one D2H copy of the kept rows."""
+    pred = outputs if outputs.dim() == 3 else outputs.unsqueeze(0)
+    det, _, cnt = postprocess_device(pred, num_classes, conf_thre, nms_thresh)
+    n = int(cnt[0])
+    d = det[0, :n].cpu().numpy()
+    return d[:, :4] / in_scale, d[:, 4] * d[:, 5], d[:, 6].astype(np.int32), None
+
+
+class StreamingDetector:
+    """The model-side state of streamyolo_det.py's loop: `model.eval().half()` (:104-109), ten warm-up calls (:113-120),
+    then per camera frame `preproc` -> `model(frame, buffer=buffer, mode='on_pipe')` -> `inference` (:176-181), the
+    buffer being reset at every sequence start (:150).
+
+    Frames are the raw uint8 HWC arrays `cv2.imread` returns.  With in_scale = 0.5 the reference's cv2.resize is the
+    exact 2x decimation, done on the device together with the Focus packing (sy_frames_u8_pack); other scales would
+    need cv2's interpolation tables and are refused (streamyolo_amd/data.py)."""
+
+    def __init__(self, model, frame_hw, in_scale=0.5, num_classes=8, conf_thre=0.01, nms_thresh=0.65, dtype="fp16",
+                 device="cuda"):
+        if in_scale not in (0.5, 1.0):
+            raise NotImplementedError("in_scale %r: only 1.0 and the exact 0.5 decimation are pinned" % (in_scale,))
+        self.model = model.to(device).eval().set_compute_dtype(dtype)
+        self.device = torch.device(device)
+        self.in_scale, self.decimate = in_scale, int(round(1.0 / in_scale))
+        self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
+        self.canvas = (int(self.frame_hw[0] * in_scale), int(self.frame_hw[1] * in_scale))
+        self.num_classes, self.conf_thre, self.nms_thresh = num_classes, conf_thre, nms_thresh
+        self._slot = torch.empty((1,) + self.frame_hw + (3,), dtype=torch.uint8, device=self.device)
+        self._in = FramePairsU8(self._slot, None, self.canvas, self.decimate)
+        self.plan = model._plans.inference(model.backbone, model.head, "on_pipe", self._in, owner=model)
+        self._first = True
+
+    def warm_up(self, n=10):
+        """streamyolo_det.py:113-120 (ten calls on a dummy frame; here they also build / tune the plan)."""
+        self._slot.fill_(1)
+        with torch.no_grad():
+            for i in range(n):
+                self.plan.run_stream(self._in, first=(i == 0))
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        self.reset()
+
+    def reset(self):
+        """`buffer = None` at the start of a sequence (:150): the next frame fuses with itself (node 'star')."""
+        self._first = True
+
+    def __call__(self, frame):
+        """One camera frame (uint8 [H, W, 3] numpy array or tensor) -> (bboxes, scores, labels, None), host arrays.
+        Ends with the device synchronised (the D2H copy of the detections), as the reference's loop does (:183)."""
+        f = torch.as_tensor(frame)
+        assert f.dtype == torch.uint8 and tuple(f.shape) == self.frame_hw + (3,)
+        self._slot[0].copy_(f, non_blocking=True)
+        with torch.no_grad():
+            out = self.plan.run_stream(self._in, first=self._first)
+            self._first = False
+            return inference(out, self.num_classes, self.conf_thre, self.nms_thresh, self.in_scale)
+
+
+def run_sequence(frames, detect, fps=30.0, det_stride=1, dynamic_schedule=False, clock=time.perf_counter, reset=None):
+    """The scheduling loop of one sequence (streamyolo_det.py:138-199): real time runs at `fps`; whenever the detector is
+    free it takes the LATEST frame (index floor(t * fps)), skipping it if already seen, if the stride counter says so, or
+    — dynamic schedule — if more than half of that frame's interval has passed; results are stamped with their finish
+    time.  `detect(frame)` returns the parsed result and must have finished its device work on return.  `clock` is
+    injectable (tests drive it with a simulated clock).  Returns the reference's per-sequence pickle dict (minus
+    `results_raw`, the undecoded device tensors)."""
+    n_frame = len(frames)
+    timestamps, results_parsed, input_fidx, runtime = [], [], [], []
+    last_fidx = None
+    stride_cnt = 0
+    t_total = n_frame / fps
+    if reset is not None:
+        reset()
+    t_start = clock()
+    while 1:
+        t1 = clock()
+        t_elapsed = t1 - t_start
+        if t_elapsed >= t_total:
+            break
+        fidx_continous = t_elapsed * fps
+        fidx = int(np.floor(fidx_continous))
+        if fidx == last_fidx:
+            continue
+        last_fidx = fidx
+        if dynamic_schedule:
+            if fidx_continous - fidx > 0.5:
+                continue
+        else:
+            if stride_cnt % det_stride == 0:
+                stride_cnt = 1
+            else:
+                stride_cnt += 1
+                continue
+        result = detect(frames[fidx])
+        t2 = clock()
+        t_elapsed = t2 - t_start
+        if t_elapsed >= t_total:
+            break
+        timestamps.append(t_elapsed)
+        results_parsed.append(result)
+        input_fidx.append(fidx)
+        runtime.append(t2 - t1)
+    return {"results_parsed": results_parsed, "timestamps": timestamps, "input_fidx": input_fidx, "runtime": runtime}
+
+
+def runtime_summary(runtime_all, n_total, fps=30.0):
+    """streamyolo_det.py:201-229: the `time_info.pkl` dict plus print_stats' numbers (sAP/util/__init__.py:13-36) in ms."""
+    r = np.asarray(runtime_all, dtype=np.float64)
+    out = {"runtime_all": list(runtime_all), "n_processed": int(r.size), "n_total": int(n_total),
+           "n_small_runtime": int((r < 1.0 / fps).sum())}
+    if r.size > 1:
+        out["stats_ms"] = {"mean": 1e3 * r.mean(), "std": 1e3 * r.std(ddof=1), "min": 1e3 * r.min(), "max": 1e3 * r.max()}
+    elif r.size == 1:
+        out["stats_ms"] = {"scalar": 1e3 * float(r[0])}
+    return out
+
+
+def ltrb2ltwh(bboxes):
+    """sAP/util/bbox.py:15-21,74-76 (copying form)."""
+    b = np.array(bboxes, copy=True)
+    if len(b):
+        if b.ndim == 1:
+            b[2:] -= b[:2]
+        else:
+            b[:, 2:] -= b[:, :2]
+    return b
+
+
+def pair_with_ground_truth(results, image_ids, fps=30.0, eta=0.0):
+    """streaming_eval.py:74-139 for one sequence: ground-truth frame ii (time (ii - eta) / fps) is paired with the LAST
+    result whose timestamp is <= that time.  `results` = run_sequence's dict, `image_ids` = the dataset ids of the
+    sequence's frames in order.  Returns (coco_rows, {"in_time", "miss", "mismatch"})."""
+    results_parsed, timestamps, input_fidx = results["results_parsed"], results["timestamps"], results["input_fidx"]
+    rows, in_time, miss, mismatch = [], 0, 0, 0
+    tidx_p1 = 0
+    for ii, image_id in enumerate(image_ids):
+        t = (ii - eta) / fps
+        while tidx_p1 < len(timestamps) and timestamps[tidx_p1] <= t:
+            tidx_p1 += 1
+        if tidx_p1 == 0:
+            miss += 1
+            bboxes, scores, labels, masks = [], [], [], None
+        else:
+            tidx = tidx_p1 - 1
+            ifidx = input_fidx[tidx]
+            in_time += int(ii == ifidx)
+            mismatch += ii - ifidx
+            bboxes, scores, labels, masks = results_parsed[tidx][:4]
+        n = len(bboxes)
+        if n:
+            bboxes_ltwh = ltrb2ltwh(bboxes)
+        for i in range(n):
+            row = {"image_id": image_id, "bbox": bboxes_ltwh[i], "score": scores[i], "category_id": labels[i]}
+            if masks is not None:
+                row["segmentation"] = masks[i]
+            rows.append(row)
+    return rows, {"in_time": in_time, "miss": miss, "mismatch": mismatch}
+
+
+def convert_to_coco_format(outputs, info_imgs, ids, img_size, class_ids, images, skip_ids=(15060, 15061)):
+    """ONEX_COCOEvaluator.convert_to_coco_format (exps/evaluators/onex_stream_evaluator.py:167-209), dataset access
+    replaced by plain arguments: `class_ids` = dataset.class_ids, `images` = coco.dataset['images'] (each with 'fid').
+    A detection made on frame t is scored against frame t+1 (`image_id = img_id + 1`); frames whose successor starts a
+    new sequence are dropped, and so — exactly as in the reference, whose append sits inside the final `else` — are
+    the detections of every sequence's first frame."""
+    data_list = []
+    for output, img_h, img_w, img_id in zip(outputs, info_imgs[0], info_imgs[1], ids):
+        if output is None:
+            continue
+        output = output.cpu()
+        bboxes = output[:, 0:4]
+        scale = min(img_size[0] / float(img_h), img_size[1] / float(img_w))
+        bboxes /= scale
+        bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 0]          # yolox.utils.xyxy2xywh
+        bboxes[:, 3] = bboxes[:, 3] - bboxes[:, 1]
+        cls = output[:, 6]
+        scores = output[:, 4] * output[:, 5]
+        for ind in range(bboxes.shape[0]):
+            label = class_ids[int(cls[ind])]
+            if int(img_id) in skip_ids:
+                continue
+            elif images[int(img_id + 1)]["fid"] == 0:
+                continue
+            elif images[int(img_id)]["fid"] == 0:
+                continue                                    # reference: idd = img_id, but nothing is appended (:186-187)
+            data_list.append({"image_id": int(img_id + 1), "category_id": label, "bbox": bboxes[ind].numpy().tolist(),
+                              "score": scores[ind].numpy().item(), "segmentation": []})
+    return data_list

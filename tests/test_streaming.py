@@ -1,0 +1,117 @@
+"""Streaming harness + evaluator glue against golden vectors produced by the reference's OWN
+loops (oracle/make_golden_stream.py executes streamyolo_det.py::main / inference, streaming_eval.py::main and
+ONEX_COCOEvaluator.convert_to_coco_format unmodified, under a simulated clock and stubbed surroundings)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from streamyolo_amd import streaming as S
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with open(os.path.join(golden_dir, "stream_glue.json")) as fh:
+        return json.load(fh)
+
+
+class SimClock:
+    def __init__(self):
+        self.t, self.tick = 100.0, 1e-4
+
+    def __call__(self):
+        self.t += self.tick
+        return self.t
+
+
+def test_scheduling_loop_matches_reference_main(gold):
+    for c in gold["schedule"]:
+        clock = SimClock()
+        lat = iter(c["latencies"])
+
+        def detect(frame):
+            clock.t += next(lat)
+            return ("bres%d" % frame, "s", "l", None)
+        r = S.run_sequence(list(range(c["n_frames"])), detect, fps=c["fps"], det_stride=c["det_stride"],
+                           dynamic_schedule=c["dynamic"], clock=clock)
+        assert r["input_fidx"] == c["input_fidx"], c["name"]
+        assert np.array_equal(np.asarray(r["timestamps"]), np.asarray(c["timestamps"]))
+        assert np.array_equal(np.asarray(r["runtime"]), np.asarray(c["runtime"]))
+        assert [list(x) for x in r["results_parsed"]] == c["results_parsed"]
+        info = S.runtime_summary(r["runtime"], c["n_frames"], c["fps"])
+        assert (info["n_processed"], info["n_total"], info["n_small_runtime"]) == (c["n_processed"], c["n_total"], c["n_small_runtime"])
+
+
+def test_pairing_matches_reference_streaming_eval(gold):
+    sched = {c["name"]: c for c in gold["schedule"]}
+    for p in gold["pairing"]:
+        c = sched[p["schedule"]]
+        rp = [(np.asarray(b, dtype=np.float32).reshape(-1, 4), np.asarray(s, dtype=np.float32), np.asarray(l, dtype=np.int32), None)
+              for b, s, l in p["results_parsed"]]
+        results = {"results_parsed": rp, "timestamps": c["timestamps"], "input_fidx": c["input_fidx"]}
+        rows, assoc = S.pair_with_ground_truth(results, [1000 + i for i in range(c["n_frames"])], fps=c["fps"], eta=p["eta"])
+        assert assoc == p["assoc"]
+        assert len(rows) == len(p["rows"])
+        for a, b in zip(rows, p["rows"]):
+            assert a["image_id"] == b["image_id"] and int(a["category_id"]) == b["category_id"]
+            assert np.array_equal(np.asarray(a["bbox"], dtype=np.float32), np.asarray(b["bbox"], dtype=np.float32))
+            assert np.float32(a["score"]) == np.float32(b["score"])
+
+
+def test_runtime_summary_matches_print_stats(gold):
+    ps = gold["print_stats"]
+    st = S.runtime_summary(ps["runtime"], len(ps["runtime"]))["stats_ms"]
+    line = "Runtime (ms): mean: %.3g; std: %.3g; min: %.3g; max: %.3g" % (st["mean"], st["std"], st["min"], st["max"])
+    assert line == ps["line"]
+
+
+def test_convert_to_coco_format_matches_reference(gold):
+    g = gold["coco"]
+    outs = [None if o is None else torch.tensor(o) for o in g["outputs"]]
+    n = len(outs)
+    rows = S.convert_to_coco_format(outs, (torch.full((n,), 1200), torch.full((n,), 1920)), torch.arange(n), (600, 960),
+                                    g["class_ids"], g["images"])
+    assert rows == g["rows"]
+
+
+def test_inference_matches_reference(backend, gold):
+    """streamyolo_det.py::inference on one image's decoded rows: same boxes (/in_scale), scores, labels, same order."""
+    g = gold["inference"]
+    dec = torch.tensor(g["decoded"]).to(backend)
+    b, s, l, m = S.inference(dec, num_classes=8, conf_thre=0.01, nms_thresh=0.65, in_scale=0.5)
+    assert m is None and l.dtype == np.int32
+    assert np.array_equal(l, np.asarray(g["labels"], dtype=np.int32))
+    assert np.array_equal(b, np.asarray(g["bboxes"], dtype=np.float32))
+    assert np.array_equal(s, np.asarray(g["scores"], dtype=np.float32))
+
+
+def test_streaming_detector_end_to_end(backend):
+    """StreamingDetector (uint8 camera frames, 2x decimation on the device, on_pipe buffer carried across frames, reset at
+    sequence start) == the facade called the reference's way on the CPU-decimated fp32 frames."""
+    import streamyolo_amd as sy
+    from oracle import input_oracle as IO
+    from oracle import streamyolo_oracle as O
+    from streamyolo_amd.utils.synth import synth_state_dict, load_bn_stats
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=load_bn_stats("nano"))
+    model = sy.build_model("nano"); model.load_state_dict(sd, strict=True)
+    det = S.StreamingDetector(model, (128, 192), in_scale=0.5, dtype="fp32", device=backend)
+    ref = sy.build_model("nano"); ref.load_state_dict(sd, strict=True)
+    ref = ref.to(backend).eval().set_compute_dtype("fp32")
+    rng = np.random.RandomState(3)
+    frames = [rng.randint(0, 256, (128, 192, 3)).astype(np.uint8) for _ in range(3)]
+    det.warm_up(2)
+    got = [det(f) for f in frames]
+    buf, want = None, []
+    with torch.no_grad():
+        for f in frames:
+            x = IO.pair_tensor(f[None], None, (64, 96), 2).to(backend)
+            out, buf = ref(x, buffer=buf, mode="on_pipe")
+            want.append(S.inference(out, 8, 0.01, 0.65, 0.5))
+    for a, b in zip(got, want):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    det.reset()
+    again = det(frames[0])
+    assert np.array_equal(again[0], got[0][0])
