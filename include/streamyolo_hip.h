@@ -239,11 +239,14 @@ SY_API int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldd
                                  const float* shift, const float* mean, const float* invstd, float* sums,
                                  int copies, int64_t pixels, int C, int dtype, int nseg, void* stream);
 /* apply: dy = gamma*invstd*(dz - S0/M - xhat*S1/M) with S = sums folded over its `copies` replicas
- * ([copies][2][C]); optionally dgamma += S1, dbeta += S0. */
+ * ([copies][2][C]); optionally dgamma += S1, dbeta += S0.  dres (optional): the gradient view of the residual input of
+ * y = silu(bn(conv)) + res (Bottleneck shortcut, DFP add): dres = da, or dres += da when dres_accumulate — the same
+ * pass that already reads da (replaces a separate sy_view_copy). */
 SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                 const float* shift, const float* mean, const float* invstd,
                                 const float* gamma, const float* sums, int copies, void* dy, int lddy,
-                                int64_t pixels, int C, float* dgamma, float* dbeta, int dtype, int nseg, void* stream);
+                                int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
+                                int dres_accumulate, int dtype, int nseg, void* stream);
 
 /* SimOTA assignment + Trend-Aware loss, forward and gradient, for a whole batch, no host sync.
  * raw [B, A, 5+nc] fp32 raw head logits (reg4, obj, cls); labels/support [B, max_labels, 5] fp32 rows

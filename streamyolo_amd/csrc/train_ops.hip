@@ -460,7 +460,8 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
                                                                    const float* gamma, const float* sums,
                                                                    typename T::elem* dy, int lddy, long long pixels,
                                                                    int C, int copies, float* dgamma, float* dbeta,
-                                                                   long long seg_sum_stride) {
+                                                                   long long seg_sum_stride, typename T::elem* dres,
+                                                                   int lddres, int dres_acc) {
     // fold the replicas of the two reduction sums once per workgroup, cooperatively, through LDS
     __shared__ float s_fold[2 * 1024];
     {   // segment blockIdx.y
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         const int ao = blockIdx.y * C;
         y += ro * ldy; da += ro * ldda; dy += ro * lddy; scale += ao; shift += ao; mean += ao; invstd += ao;
         sums += blockIdx.y * seg_sum_stride;
+        if (dres != nullptr) dres += ro * lddres;
     }
     const int cpp = C / T::kEPC;
     const int rows = kBlock / cpp;
@@ -508,6 +510,15 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
             o.e[j] = T::from_f32(gi[j] * (dz - m0[j] - (yy - mu[j]) * is[j] * m1[j]));
         }
         o.store(dy + pix * lddy + c0);
+        if (dres != nullptr) {          // y = silu(bn(conv)) + res: the residual branch receives da unchanged (view_copy fused)
+            typename T::elem* dst = dres + pix * lddres + c0;
+            if (dres_acc) {
+                Chunk<T> r = Chunk<T>::load(dst);
+#pragma unroll
+                for (int j = 0; j < T::kEPC; ++j) gv.e[j] = T::from_f32(T::to_f32(gv.e[j]) + T::to_f32(r.e[j]));
+            }
+            gv.store(dst);
+        }
     }
 }
 
@@ -634,13 +645,14 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
 extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                     const float* shift, const float* mean, const float* invstd, const float* gamma,
                                     const float* sums, int copies, void* dy, int lddy, int64_t pixels, int C,
-                                    float* dgamma, float* dbeta, int dtype, int nseg, void* stream) {
+                                    float* dgamma, float* dbeta, void* dres, int lddres, int dres_accumulate, int dtype,
+                                    int nseg, void* stream) {
     if (y == nullptr || da == nullptr || sums == nullptr || dy == nullptr || pixels <= 0 || C <= 0 || copies <= 0 || nseg < 1)
         return SY_ERR_ARG;
     const long long seg_sum_stride = (long long)copies * 2 * C;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
     const int e = epc_of(dtype);
-    if (C % e || ldy % e || ldda % e || lddy % e) return SY_ERR_UNSUPPORTED;
+    if (C % e || ldy % e || ldda % e || lddy % e || (dres != nullptr && lddres % e)) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e) || C > 1024) return SY_ERR_UNSUPPORTED;
     static const int fold_inline = env_cap("SY_BN_FOLD_INLINE", 2);      // replicas <= this: every workgroup folds them itself
     if (copies > fold_inline) {       // many replicas: fold once here instead of in every workgroup of the apply pass
@@ -652,5 +664,5 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
-                                       dgamma, dbeta, seg_sum_stride));
+                                       dgamma, dbeta, seg_sum_stride, (typename T::elem*)dres, lddres, dres_accumulate));
 }

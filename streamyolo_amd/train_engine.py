@@ -647,13 +647,11 @@ class TrainPlan:
         G = self.grads
         bn = op.mod.bn
         dY = G.view(op.y)
-        if op.res is not None:                                       # y = silu(bn(conv)) + res
-            dres, acc = G.target(op.res)
-            ops.view_copy(dY, dres, accumulate=acc)
+        dres, acc = (None, False) if op.res is None else G.target(op.res)    # y = silu(bn(conv)) + res: dres (+)= dY
         scale, shift, mean, invstd = op.aff
         ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
         ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, bn.weight, op.bsum, dyraw,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)])
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], dres=dres, dres_accumulate=acc)
 
     def _wgrad(self, op, x, dyraw):
         w = op.mod.conv.weight
@@ -687,16 +685,17 @@ class TrainPlan:
         dYa, dYb = G.view(a.y), G.view(b2.y)
         assert dYa.root[0] is dYb.root[0]
         dY2 = dYa.pair()
+        dres2, acca = None, False
         if a.res is not None:                                        # y = silu(bn(conv)) + res, both frames at once
             dra, acca = G.target(a.res)
             drb, accb = G.target(b2.res)
             assert acca == accb and dra.root[0] is drb.root[0]
-            ops.view_copy(dY2, dra.pair(), accumulate=acca)
+            dres2 = dra.pair()                                       # written by the BN backward apply pass below
         _, _, u_bsum, (scale, shift, mean, invstd) = a.unit
         raw2 = a.yraw.pair()
         ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
         ops.bn_silu_bwd_apply(raw2, dY2, scale, shift, mean, invstd, bn.weight, u_bsum, dy2,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2)
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2, dres=dres2, dres_accumulate=acca)
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot)
         if a.need_dx:
             dxa, acca = G.target(a.x)

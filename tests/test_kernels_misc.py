@@ -128,6 +128,15 @@ def test_bn_train_silu_fwd_bwd(backend, dt):
     ops.bn_silu_bwd_apply(yv, dav, scale, shift, mean, invstd, gamma.detach().to(dev), sums, dyv, dgam, dbet)
     assert _rel(dbet.cpu(), beta.grad) < 1e-4 and _rel(dgam.cpu(), gamma.grad) < 1e-4
     assert _rel(dyv.nchw().cpu(), y.grad) < (3e-2 if dt == "bf16" else 1e-4)
+    # residual branch gradient written by the same pass (a = silu(bn(y)) + res  =>  dres = da), then accumulated
+    wide = View.alloc(N, H, W, 2 * C, dt, dev, zero=True)
+    drv, dy2 = wide.slice(C, C), View.alloc(N, H, W, C, dt, dev)
+    ops.bn_silu_bwd_apply(yv, dav, scale, shift, mean, invstd, gamma.detach().to(dev), sums, dy2, dres=drv)
+    assert torch.equal(drv.nchw(), dav.nchw()) and torch.equal(dy2.buf, dyv.buf)
+    assert torch.equal(wide.slice(0, C).nchw(), torch.zeros_like(dav.nchw()))
+    ops.bn_silu_bwd_apply(yv, dav, scale, shift, mean, invstd, gamma.detach().to(dev), sums, dy2, dres=drv, dres_accumulate=True)
+    want = (dav.nchw().float() * 2).to(dav.buf.dtype)
+    assert torch.equal(drv.nchw(), want)
 
 
 def test_bn_running_update_batched(backend):
