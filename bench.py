@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--u8-input", type=int, default=0,
                     help="stream: feed the raw uint8 HWC camera frame (2H x 2W, e.g. 1200x1920) — exact-2x decimation, "
                          "letterbox and Focus packing run on the device (sy_frames_u8_pack) inside the timed step")
+    ap.add_argument("--h2d", type=int, default=0,
+                    help="stream: also copy the frame from pinned host memory inside every step (PCIe-inclusive latency; "
+                         "never the headline value)")
     ap.add_argument("--train-graph", type=int, default=0, help="train: hipGraph replay instead of launch tapes (slower on ROCm 7)")
     return ap.parse_args()
 
@@ -194,8 +197,13 @@ def main():
         plan = model._plans.inference(model.backbone, model.head, "on_pipe", frame, owner=model)
         graph = None
 
+        dev_buf = frame.cur if args.u8_input else frame
+        host_buf = dev_buf.cpu().pin_memory() if args.h2d else None
+
         def eager():
             with torch.no_grad():
+                if host_buf is not None:
+                    dev_buf.copy_(host_buf, non_blocking=True)
                 out = plan.run_stream(frame)
                 return postprocess_device(out, cfg.num_classes, 0.01, 0.65)
         with torch.no_grad():
@@ -295,6 +303,7 @@ def main():
                        "hipgraph": bool(args.train_graph if workload == "train" else args.graph),
                        "optimizer_in_step": bool(args.with_optimizer) if workload == "train" else None,
                        "u8_input": bool(args.u8_input) if workload == "stream" else None,
+                       "h2d_in_step": bool(args.h2d) if workload == "stream" else None,
                        "host_launch_ms_per_step": round(host_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1,9 +1,9 @@
 #!/bin/bash
 # stage archive (copy the outputs to profiles/rNN/<stage>_*): full GPU suite, bench matrix, kernel stats, PMC traffic, probes
-mkdir -p gpurun_out/e
+mkdir -p gpurun_out/f
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/e
+O=gpurun_out/f
 (timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -vE 'RCCL|HIP version|ROCm version|Hostname|Librccl' | tail -8) > $O/pytest_gpu_all.log 2>&1
 (timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2) > $O/smoke.log 2>&1
 (timeout 600 python bench.py --workload train --model l --steps 20 --warmup 5 --cpu-seconds 15 2>&1 | tail -1) > $O/bench_train_l.json 2>&1
@@ -11,6 +11,12 @@ O=gpurun_out/e
 (timeout 300 python bench.py --workload infer --model l --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1) > $O/bench_infer_l.json 2>&1
 (timeout 300 python bench.py --workload infer --model s --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1) > $O/bench_infer_s.json 2>&1
 (timeout 300 python bench.py --workload stream --model l --dtype fp16 --steps 50 --warmup 10 --no-cpu-baseline 2>&1 | tail -1) > $O/bench_stream_l_fp16.json 2>&1
+(timeout 300 python bench.py --workload stream --model l --dtype fp16 --steps 50 --warmup 10 --no-cpu-baseline --u8-input 1 2>&1 | tail -1) > $O/bench_stream_l_fp16_u8.json 2>&1
+(timeout 300 python bench.py --workload stream --model l --dtype fp16 --steps 50 --warmup 10 --no-cpu-baseline --u8-input 1 --h2d 1 2>&1 | tail -1) > $O/bench_stream_l_fp16_u8_h2d.json 2>&1
+(timeout 300 python bench.py --workload stream --model l --dtype fp16 --steps 50 --warmup 10 --no-cpu-baseline --h2d 1 2>&1 | tail -1) > $O/bench_stream_l_fp16_h2d.json 2>&1
+(timeout 300 python bench.py --workload train --model m --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1) > $O/bench_train_m.json 2>&1
+(timeout 300 python bench.py --workload train --model l --steps 20 --warmup 5 --no-cpu-baseline --with-optimizer 1 2>&1 | tail -1) > $O/bench_train_l_with_optimizer.json 2>&1
+(timeout 300 python tools/host_profile.py l 2>&1 | grep -v "^$" | tail -32) > $O/host_profile_train_l.txt 2>&1
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --workload train --model l --steps 5 --warmup 3 --no-cpu-baseline 2>&1 | tail -1) > $O/rocprof_bench_line.json 2>&1
 cp $O/prof/*/*kernel_stats.csv $O/train_l_b8_bf16_kernel_stats.csv
 rm -rf $O/prof

@@ -42,7 +42,9 @@ for q, (n, d) in perq.items():
 fam = defaultdict(lambda: [0, 0])
 for s, e, n, q in step:
     m = re.search(r"(\w+_kernel|\w+)(<[^>]*>)?\(", n)
-    key = re.sub(r"^void ", "", n.split("(")[0])[:70]
+    key = re.sub(r"^void ", "", n.replace("(anonymous namespace)::", "").split("(")[0])[:70]
     fam[key][0] += 1; fam[key][1] += e - s
 for k, (n, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:28]:
     print("%9.3f ms %5d  %s" % (d / 1e6, n, k))
+mfma = sum(d for k, (n, d) in fam.items() if "conv_igemm_kernel" in k or "conv_wgrad" in k or "wgrad_fold" in k)
+print("MFMA kernels (conv_igemm + conv_wgrad + wgrad_fold) in the last step: %.3f ms  (bench.py roofline.kernel_ms_per_step measures the same set with HIP events)" % (mfma / 1e6))
