@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--graph", type=int, default=1, help="infer / stream: replay the step from a hipGraph")
+    ap.add_argument("--graph", type=int, default=None,
+                    help="infer / stream: 1 = replay the step from a hipGraph (default), 2 = stream only: from a launch tape "
+                         "(what StreamingDetector uses; same latency, ~3.4 ms of host time per frame), 0 = Python wrappers")
     ap.add_argument("--with-optimizer", type=int, default=0,
                     help="train: also run the fused SGD-nesterov + EMA step (sy_sgd_ema_step) inside every timed step "
                          "(off by default: BASELINE.json's metric is forward + loss + backward)")
@@ -146,6 +148,8 @@ def main():
     from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels, load_bn_stats
 
     workload = args.workload
+    if args.graph is None:
+        args.graph = 1
     if workload is None:
         try:
             from streamyolo_amd import train_engine  # noqa: F401
@@ -200,15 +204,19 @@ def main():
         dev_buf = frame.cur if args.u8_input else frame
         host_buf = dev_buf.cpu().pin_memory() if args.h2d else None
 
+        post = lambda out: postprocess_device(out, cfg.num_classes, 0.01, 0.65)        # noqa: E731
+
         def eager():
             with torch.no_grad():
                 if host_buf is not None:
                     dev_buf.copy_(host_buf, non_blocking=True)
+                if args.graph == 2:
+                    return plan.run_stream_taped(frame, post=post, check_params=False)
                 out = plan.run_stream(frame)
-                return postprocess_device(out, cfg.num_classes, 0.01, 0.65)
+                return post(out)
         with torch.no_grad():
             plan.run_stream(frame, first=True)
-        if args.graph:
+        if args.graph == 1:
             for _ in range(2):
                 eager()
             torch.cuda.synchronize()
@@ -230,7 +238,7 @@ def main():
         def eager():
             with torch.no_grad():
                 return plan.run(x)
-        if args.graph:
+        if args.graph:   # infer: 1 (hipGraph); a tape of the off_pipe plan is not wired up
             for _ in range(2):
                 eager()
             torch.cuda.synchronize()
@@ -300,7 +308,8 @@ def main():
                                             else "eval forward off_pipe + decode"), B,
                                       "random-init synthetic weights (utils/synth.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "hipgraph": bool(args.train_graph if workload == "train" else args.graph),
+                       "hipgraph": bool(args.train_graph if workload == "train" else args.graph == 1),
+                       "launch_tape": True if workload == "train" and not args.train_graph else (args.graph == 2 if workload == "stream" else False),
                        "optimizer_in_step": bool(args.with_optimizer) if workload == "train" else None,
                        "u8_input": bool(args.u8_input) if workload == "stream" else None,
                        "h2d_in_step": bool(args.h2d) if workload == "stream" else None,

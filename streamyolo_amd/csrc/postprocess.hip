@@ -18,9 +18,10 @@
 //               sort of 64-bit keys (~score_bits << 32 | anchor), emit sorted offset boxes.
 //   2. mask   — 64x64 tiles of the upper-triangular suppression bit matrix, one wave per tile,
 //               grid-strided (the candidate count only exists on the device).
-//   3. sweep  — one wave per image walks the sorted list 64 boxes at a time: intra-chunk resolution
-//               with wave shuffles on the diagonal word, then ORs the kept rows into the running
-//               `removed` bitmap (independent, coalesced loads), and writes detections.
+//   3. sweep  — one 256-thread workgroup per image walks the sorted list 64 boxes at a time: wave 0 resolves the
+//               chunk with readlane steps on the diagonal word, then every thread ORs the chunk's kept rows into
+//               its word column of the running `removed` bitmap (64 unconditional, coalesced loads in flight);
+//               the detections are written afterwards by all threads from the per-chunk survivor words.
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
 
@@ -170,12 +171,24 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(unsigned char* ws, PostLay
     (void)tiles_per_image_cap;
 }
 
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const float* pred, int A, int nc, unsigned char* ws, PostLayout L,
-                                                       int max_det, float* out_det, int* out_index, int* out_count) {
+// One 256-thread workgroup per image.  The walk over the sorted list is serial in 64-box chunks (a chunk's survivors
+// depend on every earlier chunk), so the latency of ONE chunk step is what matters (185 steps when every anchor is a
+// candidate): wave 0 resolves the chunk from its diagonal word (prefetched one chunk ahead) with 64 readlane steps;
+// then ALL threads fold the chunk's 64 mask rows into the running `removed` bitmap, one 64-bit word column per thread,
+// the 64 row loads issued unconditionally in batches of 16 (independent, coalesced along the row) and OR-ed in under
+// the survivor bits — instead of one wave chasing a data-dependent load per surviving row.
+constexpr int kSweepThreads = 256;
+__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(const float* pred, int A, int nc, unsigned char* ws,
+                                                                  PostLayout L, int max_det, float* out_det,
+                                                                  int* out_index, int* out_count) {
     SY_DYN_SMEM(smem);
-    unsigned long long* removed = reinterpret_cast<unsigned long long*>(smem);     // [L.words]
+    unsigned long long* removed = reinterpret_cast<unsigned long long*>(smem);     // [L.words] suppressed-so-far bitmap
+    unsigned long long* kept = removed + L.words;                                   // [L.words] survivors of every chunk
+    int* base = reinterpret_cast<int*>(kept + L.words);                             // [L.words] survivors before the chunk
     const int img = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const bool wave0 = tid < 64;
     unsigned char* wsi = ws + (long long)img * L.image_bytes;
     const float* rec = reinterpret_cast<const float*>(wsi + L.rec_off);
     const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(wsi + L.mask_off);
@@ -185,50 +198,68 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const float* pred, int A,
     float* det = out_det + (long long)img * max_det * 7;
     int* oidx = out_index + (long long)img * max_det;
 
-    for (int w = lane; w < nblk; w += 64) removed[w] = 0ull;
+    for (int w = tid; w < nblk; w += kSweepThreads) removed[w] = 0ull;
+    unsigned long long diag_next = (wave0 && lane < count) ? mask[(long long)lane * L.words] : 0ull;
     __syncthreads();
-    int nkept = 0;
+    // ---- the serial walk: nothing but the survivor bits of each chunk and the bitmap update is on this chain ----
     for (int k = 0; k < nblk; ++k) {
-        const int i = k * 64 + lane;
-        const unsigned long long diag = (i < count) ? mask[(long long)i * L.words + k] : 0ull;
-        unsigned long long rem = removed[k];
-        unsigned long long alive = 0ull;
-        const int nl = (count - k * 64) < 64 ? (count - k * 64) : 64;
-        for (int l = 0; l < nl; ++l) {
-            const unsigned long long row = __shfl(diag, l);
-            if (!((rem >> l) & 1ull)) { alive |= (1ull << l); rem |= row; }
-        }
-        // fold the kept rows of this chunk into the running bitmap of later chunks
-        for (int w = k + 1 + lane; w < nblk; w += 64) {
-            unsigned long long acc = removed[w];
-            unsigned long long bits = alive;
-            while (bits) {
-                const int b = __ffsll(bits) - 1;
-                bits &= bits - 1;
-                acc |= mask[(long long)(k * 64 + b) * L.words + w];
+        if (wave0) {
+            const unsigned long long diag = diag_next;
+            const int in = (k + 1) * 64 + lane;                        // next chunk's diagonal word, in flight during the fold
+            diag_next = (k + 1 < nblk && in < count) ? mask[(long long)in * L.words + k + 1] : 0ull;
+            unsigned long long rem = sy_uniform64(removed[k]);         // rem / alive / row live in SGPRs: a scalar loop
+            unsigned long long alive = 0ull;
+            const int nl = sy_uniform((count - k * 64) < 64 ? (count - k * 64) : 64);
+            for (int l = 0; l < nl; ++l) {
+                const unsigned long long row = sy_readlane64(diag, l);
+                if (!((rem >> l) & 1ull)) { alive |= (1ull << l); rem |= row; }
             }
+            if (lane == 0) kept[k] = alive;
+        }
+        __syncthreads();
+        // fold the kept rows of this chunk into the running bitmap of later chunks: thread = word column (L.words <=
+        // kSweepThreads); the 64 row loads are issued unconditionally, all before the first use (rows past `count` are
+        // never selected).  Prefetching the next chunk's rows during the resolve was measured and bought nothing: the
+        // ~3.3 us per chunk are the two barriers and ~400 VALU instructions, not load latency.
+        const unsigned long long alive = kept[k];
+        const int w = k + 1 + tid;
+        if (alive != 0ull && w < nblk) {
+            const unsigned long long* col = mask + (long long)(k * 64) * L.words + w;
+            unsigned long long v[64];
+#pragma unroll
+            for (int j = 0; j < 64; ++j) v[j] = col[(long long)j * L.words];
+            unsigned long long acc = removed[w];
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                if ((alive >> j) & 1ull) acc |= v[j];
             removed[w] = acc;
         }
-        // emit this chunk's survivors in order
-        if ((alive >> lane) & 1ull) {
-            const int pos = nkept + __popcll(alive & ((1ull << lane) - 1ull));
-            if (pos < max_det) {
-                const int a = __builtin_bit_cast(int, rec[(long long)i * kRec + 5]);
-                const float* r = P + (long long)a * (5 + nc);
-                float best = r[5];
-                int bc = 0;
-                for (int c = 1; c < nc; ++c) { const float v = r[5 + c]; if (v > best) { best = v; bc = c; } }
-                const float hw = r[2] / 2, hh = r[3] / 2;
-                float* d = det + (long long)pos * 7;
-                d[0] = r[0] - hw; d[1] = r[1] - hh; d[2] = r[0] + hw; d[3] = r[1] + hh;
-                d[4] = r[4]; d[5] = best; d[6] = (float)bc;
-                oidx[pos] = a;
-            }
-        }
-        nkept += __popcll(alive);
         __syncthreads();
     }
-    if (lane == 0) out_count[img] = nkept < max_det ? nkept : max_det;
+    // ---- detections, in order, by all threads: position = survivors of earlier chunks + earlier bits of the own chunk ----
+    if (tid == 0) {
+        int n = 0;
+        for (int k = 0; k < nblk; ++k) { base[k] = n; n += __popcll(kept[k]); }
+        out_count[img] = n < max_det ? n : max_det;
+    }
+    __syncthreads();
+    for (int i = tid; i < count; i += kSweepThreads) {
+        const int k = i >> 6, b = i & 63;
+        const unsigned long long alive = kept[k];
+        if (!((alive >> b) & 1ull)) continue;
+        const int pos = base[k] + __popcll(alive & ((1ull << b) - 1ull));
+        if (pos >= max_det) continue;
+        const int a = __builtin_bit_cast(int, rec[(long long)i * kRec + 5]);
+        const float* r = P + (long long)a * (5 + nc);
+        float best = r[5];
+        int bc = 0;
+        for (int c = 1; c < nc; ++c) { const float v = r[5 + c]; if (v > best) { best = v; bc = c; } }
+        const float hw = r[2] / 2, hh = r[3] / 2;
+        float* d = det + (long long)pos * 7;
+        d[0] = r[0] - hw; d[1] = r[1] - hh; d[2] = r[0] + hw; d[3] = r[1] + hh;
+        d[4] = r[4]; d[5] = best; d[6] = (float)bc;
+        oidx[pos] = a;
+    }
 }
 
 }  // namespace
@@ -245,7 +276,7 @@ extern "C" int sy_postprocess(const float* pred, int B, int A, int num_classes, 
         return SY_ERR_ARG;
     if (B <= 0 || A <= 0 || num_classes <= 0 || max_det <= 0) return SY_ERR_ARG;
     const int sort_n = next_pow2(A);
-    if (sort_n > 16384) return SY_ERR_UNSUPPORTED;          // 128 KiB of LDS keys (160 KiB per CU on gfx950)
+    if (sort_n > 16384) return SY_ERR_UNSUPPORTED;          // 128 KiB of LDS keys (160 KiB per CU on gfx950); words <= 256 = kSweepThreads
     PostLayout L = make_layout(A);
     const size_t rank_smem = (size_t)sort_n * 8 + 128;
 #ifndef SY_EMU
@@ -261,7 +292,7 @@ extern "C" int sy_postprocess(const float* pred, int B, int A, int num_classes, 
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
     SY_LAUNCH(nms_mask_kernel, dim3(512, B), dim3(64), 0, stream, (unsigned char*)workspace, L, nms_thre, 0);
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
-    SY_LAUNCH(nms_sweep_kernel, dim3(B), dim3(64), (size_t)L.words * 8, stream, pred, A, num_classes,
+    SY_LAUNCH(nms_sweep_kernel, dim3(B), dim3(kSweepThreads), (size_t)L.words * 20, stream, pred, A, num_classes,
               (unsigned char*)workspace, L, max_det, out_det, out_index, out_count);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }

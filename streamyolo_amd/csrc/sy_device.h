@@ -235,6 +235,25 @@ static inline int sy_uniform(int v) { return v; }
 __device__ __forceinline__ int sy_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// 64-bit value of lane `l` (wave-uniform l): two v_readlane_b32 instead of the LDS-routed ds_bpermute of __shfl
+#ifdef SY_EMU
+static inline unsigned long long sy_readlane64(unsigned long long v, int l) { return __shfl(v, l); }
+#else
+__device__ __forceinline__ unsigned long long sy_readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#endif
+
+#ifdef SY_EMU
+static inline unsigned long long sy_uniform64(unsigned long long v) { return v; }
+#else
+__device__ __forceinline__ unsigned long long sy_uniform64(unsigned long long v) {      // wave-uniform 64-bit value -> SGPR pair
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+#endif
+
 // ---- XCD-aware workgroup order ------------------------------------------------------------------------------
 // MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs, each with a private L2.  Tiles that
 // share operand rows (the channel tiles of one pixel tile, neighbouring pixel tiles with their halo rows, the
