@@ -136,3 +136,30 @@ def test_model_accepts_uint8_frames(backend):
         on_u8, _ = model(FramePairsU8(_dev(cur, backend), None, (H, W)), mode="on_pipe")
         on_f, _ = model(IO.pair_tensor(cur, None, (H, W)).to(backend), mode="on_pipe")
     assert torch.equal(a, b) and torch.equal(on_u8, on_f)
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_hands_over_uint8_batches():
+    """DevicePrefetcher (the reference's DataPrefetcher for uint8 frames): side-stream H2D, wait_stream + record_stream
+    hand-over, batches in loader order, (None, None) when the loader is exhausted."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from streamyolo_amd import _lib
+    from streamyolo_amd.data import DevicePrefetcher
+    _lib.use_library(_lib.DEFAULT_PATH)
+    rng = np.random.RandomState(2)
+    H, W = 32, 64
+    batches = []
+    for i in range(3):
+        cur = torch.from_numpy(rng.randint(0, 256, (2, H, W, 3)).astype(np.uint8)).pin_memory()
+        sup = torch.from_numpy(rng.randint(0, 256, (2, H, W, 3)).astype(np.uint8)).pin_memory()
+        lab = torch.full((2, 4, 5), float(i))
+        batches.append(((cur, sup, np.array([i % 2, 1], dtype=np.uint8)), (lab, lab + 1), None, None))
+    pf = DevicePrefetcher(batches, canvas=(H, W), device="cuda:0")
+    for i in range(3):
+        inp, tgt = pf.next()
+        want = IO.pair_tensor(batches[i][0][0].numpy(), batches[i][0][1].numpy(), (H, W), 1, batches[i][0][2])
+        assert torch.equal(inp.to_nchw().cpu(), want)
+        assert tgt[0].is_cuda and float(tgt[0][0, 0, 0]) == float(i) and float(tgt[1][0, 0, 0]) == float(i + 1)
+    inp, tgt = pf.next()
+    assert inp is None and tgt is None
