@@ -190,6 +190,18 @@ class StagedWeights:
         return w_ro, b_ro, w_c, b_c.detach(), w_ro_t, w_c_t
 
 
+CSP_FORK = os.environ.get("STREAMYOLO_CSP_FORK", "1") != "0"
+
+
+def _csp_role(tag):
+    """'conv2' / 'conv3' for the two CSPLayer convs named <csp>.conv2 / <csp>.conv3 by engine._Builder.csp (the
+    Bottleneck convs are <csp>.m.<i>.conv1/2, SPP's are spp.conv1/2)."""
+    head, _, leaf = tag.rpartition(".")
+    if leaf not in ("conv2", "conv3") or ".m." in tag or head in ("", "spp"):
+        return None
+    return leaf
+
+
 class TrainPlan:
     # replicas of each BN-backward reduction: 2, folded by every workgroup of the apply pass itself (no fold launch);
     # measured 28.3 vs 28.6 ms per l step against 16 replicas + fold kernel (profiles/r01/f_*)
@@ -345,6 +357,16 @@ class TrainPlan:
         for i in range(nf):
             a, b2 = self.ops[i], self.ops[nf + i]
             if a.kind == "conv":
+                # CSPLayer: conv2(x) only meets the bottleneck chain conv1(x) -> m(...) again in conv3(cat[...]) —
+                # it runs on the side stream (idle during forward) beside the chain and joins before conv3
+                role = _csp_role(a.tag) if CSP_FORK else None
+                if role == "conv2":
+                    self._mark("side")
+                    self._forward_pair(a)
+                    self._mark("main", None)
+                    continue
+                if role == "conv3":
+                    self._mark("join")
                 self._forward_pair(a)
             else:
                 self._forward_op(a)
