@@ -96,45 +96,43 @@ def run_sequence(frames, detect, fps=30.0, det_stride=1, dynamic_schedule=False,
     free it takes the LATEST frame (index floor(t * fps)), skipping it if already seen, if the stride counter says so, or
     — dynamic schedule — if more than half of that frame's interval has passed; results are stamped with their finish
     time.  `detect(frame)` returns the parsed result and must have finished its device work on return.  `clock` is
-    injectable (tests drive it with a simulated clock).  Returns the reference's per-sequence pickle dict (minus
-    `results_raw`, the undecoded device tensors)."""
-    n_frame = len(frames)
-    timestamps, results_parsed, input_fidx, runtime = [], [], [], []
-    last_fidx = None
-    stride_cnt = 0
-    t_total = n_frame / fps
+    injectable (tests drive it with a simulated clock; it is read exactly where the reference reads perf_counter).
+    Returns the reference's per-sequence pickle dict (minus `results_raw`, the undecoded device tensors)."""
+    duration = len(frames) / fps                     # the sequence's length in real time
+    log = {"results_parsed": [], "timestamps": [], "input_fidx": [], "runtime": []}
+    seen = None                                      # index of the frame looked at last
+    since_det = 0                                    # fixed-stride schedule: frames since the last detection (0 = none yet)
     if reset is not None:
         reset()
-    t_start = clock()
-    while 1:
-        t1 = clock()
-        t_elapsed = t1 - t_start
-        if t_elapsed >= t_total:
+    t0 = clock()
+    while True:
+        began = clock()
+        now = began - t0
+        if now >= duration:
             break
-        fidx_continous = t_elapsed * fps
-        fidx = int(np.floor(fidx_continous))
-        if fidx == last_fidx:
-            continue
-        last_fidx = fidx
+        pos = now * fps                              # fractional frame position of "now"
+        latest = int(np.floor(pos))
+        if latest == seen:
+            continue                                 # nothing new yet: poll again
+        seen = latest
         if dynamic_schedule:
-            if fidx_continous - fidx > 0.5:
+            if pos - latest > 0.5:                   # too far into this frame's interval: wait for the next one
                 continue
         else:
-            if stride_cnt % det_stride == 0:
-                stride_cnt = 1
-            else:
-                stride_cnt += 1
+            take = since_det % det_stride == 0
+            since_det = 1 if take else since_det + 1
+            if not take:
                 continue
-        result = detect(frames[fidx])
-        t2 = clock()
-        t_elapsed = t2 - t_start
-        if t_elapsed >= t_total:
-            break
-        timestamps.append(t_elapsed)
-        results_parsed.append(result)
-        input_fidx.append(fidx)
-        runtime.append(t2 - t1)
-    return {"results_parsed": results_parsed, "timestamps": timestamps, "input_fidx": input_fidx, "runtime": runtime}
+        parsed = detect(frames[latest])
+        ended = clock()
+        finish = ended - t0
+        if finish >= duration:
+            break                                    # finished after the sequence ended: not recorded
+        log["timestamps"].append(finish)
+        log["results_parsed"].append(parsed)
+        log["input_fidx"].append(latest)
+        log["runtime"].append(ended - began)
+    return log
 
 
 def runtime_summary(runtime_all, n_total, fps=30.0):
@@ -161,34 +159,33 @@ def ltrb2ltwh(bboxes):
 
 
 def pair_with_ground_truth(results, image_ids, fps=30.0, eta=0.0):
-    """streaming_eval.py:74-139 for one sequence: ground-truth frame ii (time (ii - eta) / fps) is paired with the LAST
-    result whose timestamp is <= that time.  `results` = run_sequence's dict, `image_ids` = the dataset ids of the
+    """streaming_eval.py:74-139 for one sequence: ground-truth frame number n (time (n - eta) / fps) is paired with the
+    LAST result whose timestamp is <= that time.  `results` = run_sequence's dict, `image_ids` = the dataset ids of the
     sequence's frames in order.  Returns (coco_rows, {"in_time", "miss", "mismatch"})."""
-    results_parsed, timestamps, input_fidx = results["results_parsed"], results["timestamps"], results["input_fidx"]
-    rows, in_time, miss, mismatch = [], 0, 0, 0
-    tidx_p1 = 0
-    for ii, image_id in enumerate(image_ids):
-        t = (ii - eta) / fps
-        while tidx_p1 < len(timestamps) and timestamps[tidx_p1] <= t:
-            tidx_p1 += 1
-        if tidx_p1 == 0:
-            miss += 1
-            bboxes, scores, labels, masks = [], [], [], None
-        else:
-            tidx = tidx_p1 - 1
-            ifidx = input_fidx[tidx]
-            in_time += int(ii == ifidx)
-            mismatch += ii - ifidx
-            bboxes, scores, labels, masks = results_parsed[tidx][:4]
-        n = len(bboxes)
-        if n:
-            bboxes_ltwh = ltrb2ltwh(bboxes)
-        for i in range(n):
-            row = {"image_id": image_id, "bbox": bboxes_ltwh[i], "score": scores[i], "category_id": labels[i]}
+    stamps, sources, parsed = results["timestamps"], results["input_fidx"], results["results_parsed"]
+    rows = []
+    stats = {"in_time": 0, "miss": 0, "mismatch": 0}
+    ready = 0                                        # results finished by the current query time (monotone cursor)
+    for n, image_id in enumerate(image_ids):
+        query = (n - eta) / fps
+        while ready < len(stamps) and stamps[ready] <= query:
+            ready += 1
+        if ready == 0:                               # nothing has been produced yet
+            stats["miss"] += 1
+            continue
+        src = sources[ready - 1]
+        stats["in_time"] += int(src == n)
+        stats["mismatch"] += n - src
+        boxes, scores, labels, masks = parsed[ready - 1][:4]
+        if not len(boxes):
+            continue
+        ltwh = ltrb2ltwh(boxes)
+        for j in range(len(boxes)):
+            row = {"image_id": image_id, "bbox": ltwh[j], "score": scores[j], "category_id": labels[j]}
             if masks is not None:
-                row["segmentation"] = masks[i]
+                row["segmentation"] = masks[j]
             rows.append(row)
-    return rows, {"in_time": in_time, "miss": miss, "mismatch": mismatch}
+    return rows, stats
 
 
 def convert_to_coco_format(outputs, info_imgs, ids, img_size, class_ids, images, skip_ids=(15060, 15061)):
@@ -196,27 +193,20 @@ def convert_to_coco_format(outputs, info_imgs, ids, img_size, class_ids, images,
     replaced by plain arguments: `class_ids` = dataset.class_ids, `images` = coco.dataset['images'] (each with 'fid').
     A detection made on frame t is scored against frame t+1 (`image_id = img_id + 1`); frames whose successor starts a
     new sequence are dropped, and so — exactly as in the reference, whose append sits inside the final `else` — are
-    the detections of every sequence's first frame."""
-    data_list = []
-    for output, img_h, img_w, img_id in zip(outputs, info_imgs[0], info_imgs[1], ids):
-        if output is None:
+    the detections of every sequence's first frame, and the two hard-coded ids."""
+    rows = []
+    for det, h, w, img_id in zip(outputs, info_imgs[0], info_imgs[1], ids):
+        if det is None:
             continue
-        output = output.cpu()
-        bboxes = output[:, 0:4]
-        scale = min(img_size[0] / float(img_h), img_size[1] / float(img_w))
-        bboxes /= scale
-        bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 0]          # yolox.utils.xyxy2xywh
-        bboxes[:, 3] = bboxes[:, 3] - bboxes[:, 1]
-        cls = output[:, 6]
-        scores = output[:, 4] * output[:, 5]
-        for ind in range(bboxes.shape[0]):
-            label = class_ids[int(cls[ind])]
-            if int(img_id) in skip_ids:
-                continue
-            elif images[int(img_id + 1)]["fid"] == 0:
-                continue
-            elif images[int(img_id)]["fid"] == 0:
-                continue                                    # reference: idd = img_id, but nothing is appended (:186-187)
-            data_list.append({"image_id": int(img_id + 1), "category_id": label, "bbox": bboxes[ind].numpy().tolist(),
-                              "score": scores[ind].numpy().item(), "segmentation": []})
-    return data_list
+        t = int(img_id)
+        if t in skip_ids or images[t + 1]["fid"] == 0 or images[t]["fid"] == 0:
+            continue                                 # (reference :183-187: no row is ever emitted for these frames)
+        det = det.cpu()
+        r = min(img_size[0] / float(h), img_size[1] / float(w))      # undo the letterbox scale
+        xywh = det[:, 0:4] / r
+        xywh[:, 2:4] -= xywh[:, 0:2]                                  # yolox.utils.xyxy2xywh
+        conf = det[:, 4] * det[:, 5]
+        for k in range(det.shape[0]):
+            rows.append({"image_id": t + 1, "category_id": class_ids[int(det[k, 6])], "bbox": xywh[k].numpy().tolist(),
+                         "score": conf[k].numpy().item(), "segmentation": []})
+    return rows
