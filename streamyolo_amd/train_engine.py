@@ -682,6 +682,12 @@ class TrainPlan:
         if wt is None:
             wt = ops.tuned_wgrad(x.dtype, x.N, x.H, x.W, x.C, dyraw.H, dyraw.W, dyraw.C, op.k, op.stride,
                                  self.device, self.wgrad_ws)
+            # split-K workgroups per wgrad launch: the autotuner times kernels alone and likes ~1024, but the wgrads run
+            # BESIDE the main stream's kernels — 512 leaves those their CUs: -0.3 ms per l step although the wgrad
+            # kernels themselves get ~2 % slower (measured, tools/gpu_sweep2.sh)
+            cap = int(os.environ.get("STREAMYOLO_WGRAD_BLOCKS_CAP", "512"))
+            if cap > 0 and wt[1] > cap:
+                wt = (wt[0], cap)
             op._tiles[key] = wt
         if w.shape[1] == x.C:
             ops.conv2d_wgrad(x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
