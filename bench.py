@@ -54,7 +54,8 @@ def parse():
                          "(off by default: BASELINE.json's metric is forward + loss + backward)")
     ap.add_argument("--u8-input", type=int, default=0,
                     help="stream: feed the raw uint8 HWC camera frame (2H x 2W, e.g. 1200x1920) — exact-2x decimation, "
-                         "letterbox and Focus packing run on the device (sy_frames_u8_pack) inside the timed step")
+                         "letterbox and Focus packing run on the device (sy_frames_u8_pack) inside the timed step; "
+                         "train: feed uint8 HWC frame pairs with per-pair mirror flags instead of the fp32 [B,6,H,W] tensor")
     ap.add_argument("--h2d", type=int, default=0,
                     help="stream: also copy the frame from pinned host memory inside every step (PCIe-inclusive latency; "
                          "never the headline value)")
@@ -175,6 +176,13 @@ def main():
         lab, sup = synth_labels(B, args.height, args.width, cfg.num_classes, seed=3 + rank)
         stepper = TrainStep(model, world_size=world, process_group=dist, graph=bool(args.train_graph))
         lab, sup = lab.to(dev), sup.to(dev)
+        if args.u8_input:
+            # the same pictures as uint8 HWC frame pairs (what a loader hands to DevicePrefetcher), every second pair
+            # mirrored: mirror + letterbox + Focus packing then run on the device inside the step (sy_frames_u8_pack)
+            from streamyolo_amd.data import FramePairsU8
+            u8 = x.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            flags = torch.tensor([i % 2 for i in range(B)], dtype=torch.uint8, device=dev)
+            x = FramePairsU8(u8[..., 0:3].contiguous(), u8[..., 3:6].contiguous(), (args.height, args.width), mirror=flags)
 
         opt = [None]
 
@@ -311,7 +319,7 @@ def main():
                        "hipgraph": bool(args.train_graph if workload == "train" else args.graph == 1),
                        "launch_tape": True if workload == "train" and not args.train_graph else (args.graph == 2 if workload == "stream" else False),
                        "optimizer_in_step": bool(args.with_optimizer) if workload == "train" else None,
-                       "u8_input": bool(args.u8_input) if workload == "stream" else None,
+                       "u8_input": bool(args.u8_input) if workload in ("stream", "train") else None,
                        "h2d_in_step": bool(args.h2d) if workload == "stream" else None,
                        "host_launch_ms_per_step": round(host_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
