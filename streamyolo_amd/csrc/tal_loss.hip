@@ -228,8 +228,13 @@ __global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float*
         const float* r = R + (long long)a * nch;
         const float p = sqrtf((1.0f / (1.0f + expf(-r[5 + s_gcls[g]]))) * cobj[c]);
         const float cls_cost = csum[c] - (-clamp_log(1.0f - p)) + (-clamp_log(p));
-        ioum[(long long)g * L.acap + c] = iou;
-        cost[(long long)g * L.acap + c] = cls_cost + 3.0f * (-logf(iou + 1e-8f)) + ((inb && inc) ? 0.0f : 100000.0f);
+        // a diverged step (exp(raw) -> inf) makes IoU / cost NaN, and NaN fails every comparison of the sweeps below:
+        // NaN IoU counts as 0 and NaN cost as +huge, so every sweep still finds a candidate (the reference would carry
+        // the NaN into the loss; here the loss terms computed from the raw tensor stay NaN, only the indexing is safe)
+        const float iou_s = (iou == iou) ? iou : 0.0f;
+        const float cst = cls_cost + 3.0f * (-logf(iou_s + 1e-8f)) + ((inb && inc) ? 0.0f : 100000.0f);
+        ioum[(long long)g * L.acap + c] = iou_s;
+        cost[(long long)g * L.acap + c] = (cst == cst) ? cst : 3.0e38f;
     }
     __syncthreads();
 
@@ -253,11 +258,12 @@ __global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float*
                 if (after && (v < bv || (v == bv && c < bi))) { bv = v; bi = c; }
             }
             wave_argmin(bv, bi);
+            if (bi >= C) break;                       // no candidate left (cannot happen with sanitised IoUs; bounds the index)
             sum += -bv;
             last_v = -bv;
             last_i = bi;
         }
-        int kg = (int)sum;
+        int kg = (sum == sum && sum < 1.0e9f) ? (int)sum : 1;
         if (kg < 1) kg = 1;
         if (kg > C) kg = C;
         if (lane == 0) s_k[g] = kg;
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float*
                 if (after && (v < bv || (v == bv && c < bi))) { bv = v; bi = c; }
             }
             wave_argmin(bv, bi);
+            if (bi >= C) break;                       // uniform: fewer comparable candidates than k
             lcv = bv;
             lci = bi;
             if (lane == 0) { atomicAdd(&mcnt[bi], 1); mgt[bi] = g; }

@@ -200,7 +200,8 @@ class ParamCache:
 
     @staticmethod
     def _ver(*ts):
-        return tuple((t.data_ptr(), t._version) for t in ts)
+        # + the weights epoch: FusedSGDEMA.step / BnRunningTable.run write through raw pointers (no _version bump)
+        return tuple((t.data_ptr(), t._version) for t in ts) + (ops.weights_epoch(),)
 
     def conv_eval(self, mod):
         """(packed weight, scale, shift) with eval-mode BN folded (eps read at call time — trap T1)."""
@@ -290,6 +291,7 @@ class InferencePlan:
                 # the support-frame inputs of the fusion are re-pointed at the caller's buffer per call
                 sup = tuple(View.alloc(p.N, p.H, p.W, p.C, self.dtype, device, zero=True) for p in pans)
             self.sup_in = sup
+            self._sup_own = [v.buf for v in sup]                   # plan-owned support buffers (run_stream's state)
             self.fused = build_fuse_net(b, pafpn, cur, sup)
         self.n_backbone_ops = len(b.ops)
         self.preds, self.A, self.out = None, 0, None
@@ -347,11 +349,18 @@ class InferencePlan:
         for op in self.ops[:self.n_backbone_ops - n_fuse]:
             self._run_op(op)
         if not self.pair:
+            # the support inputs of the fusion point at the caller's buffer (or at the current frame: node 'star') for
+            # THIS call only; run_stream / its launch tape keep using the plan-owned support buffers
             src = self.cur_pans if buffer is None else buffer
             for dst, s in zip(self.sup_in, src):
                 dst.buf = s.buf if isinstance(s, View) else _nhwc_of(s, dst)
-        for op in self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]:
-            self._run_op(op)
+        try:
+            for op in self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]:
+                self._run_op(op)
+        finally:
+            if not self.pair:
+                for dst, own in zip(self.sup_in, self._sup_own):
+                    dst.buf = own
         return self.fused
 
     def run_stream(self, x, first=False):
@@ -385,7 +394,8 @@ class InferencePlan:
         src = (x.cur.data_ptr(), None if x.mirror is None else x.mirror.data_ptr(), x.canvas, x.out_size, x.decimate) \
             if isinstance(x, FramePairsU8) else (x.data_ptr(), x.dtype, tuple(x.shape))
         # check_params=False: the caller guarantees frozen weights (streaming inference) and saves ~0.1 ms of host time
-        return src, (tuple((p.data_ptr(), p._version) for p in self._tape_params()) if check_params else None)
+        return src, ((ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in self._tape_params())
+                     if check_params else None)
 
     def _tape_params(self):
         if self._tape_param_list is None:

@@ -97,6 +97,21 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# ---- weights epoch ---------------------------------------------------------------------------------------------
+# Kernels that rewrite parameters / BatchNorm buffers through raw pointers (sy_sgd_ema_step, sy_bn_running_update) do
+# not bump torch's tensor._version, which is what the inference-side caches (engine.ParamCache, the streaming launch
+# tape) watch.  They bump this counter instead and the caches include it in their signatures.
+_weights_epoch = [0]
+
+
+def weights_epoch():
+    return _weights_epoch[0]
+
+
+def bump_weights_epoch():
+    _weights_epoch[0] += 1
+
+
 def conv_out_size(h, k, stride):
     return (h + 2 * ((k - 1) // 2) - k) // stride + 1
 
@@ -276,6 +291,7 @@ class BnRunningTable:
     def run(self):
         check(_lib.lib().sy_bn_running_update(self.table.data_ptr(), self.n, self.max_c, stream_of(self.table)),
               "sy_bn_running_update")
+        bump_weights_epoch()                       # running statistics changed behind torch's back
 
 
 def bn_silu_apply(y, scale, shift, out, res=None, nseg=1):
@@ -349,8 +365,9 @@ def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value,
     """SimOTA + Trend-Aware loss forward and gradient (sy_tal_loss).  raw [B,A,5+nc] fp32 contiguous;
     labels/support [B, max_labels, 5] fp32.  Returns (losses[8], d_raw, fg_mask) device tensors."""
     assert raw.dtype == torch.float32 and raw.is_contiguous()
-    labels = labels.to(raw.device, torch.float32).contiguous()
-    support = support.to(raw.device, torch.float32).contiguous()
+    # wider label rows (the reference's mixup branch, tal_head.py:277-283, slices [..., :5] itself): the kernel's row pitch is 5
+    labels = labels[..., :5].to(raw.device, torch.float32).contiguous()
+    support = support[..., :5].to(raw.device, torch.float32).contiguous()
     assert labels.shape[1] == ws.max_labels and support.shape == labels.shape
     check(_lib.lib().sy_tal_loss(raw.data_ptr(), ws.B, ws.A, num_classes, labels.data_ptr(), support.data_ptr(),
                                  ws.max_labels, C.cast(ws.lh, C.c_void_p), C.cast(ws.lw, C.c_void_p),

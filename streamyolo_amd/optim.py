@@ -96,6 +96,7 @@ class FusedSGDEMA:
                                              float(grad_scale), float(d), 1 if self.steps == 0 else 0,
                                              ops.stream_of(self.table)), "sy_sgd_ema_step")
         self.steps += 1
+        ops.bump_weights_epoch()                   # parameters rewritten through raw pointers (tensor._version unchanged)
 
     def ema_state_dict(self):
         """The EMA weights under the reference's checkpoint keys (what `ema_model.ema.state_dict()` returns)."""

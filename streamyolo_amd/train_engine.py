@@ -9,7 +9,7 @@ kernels), a host-synchronising assignment loop, then autograd's generic backward
             -> sy_bn_finalize (batch statistics, running-stat update with the module's momentum/eps —
             trap T1) -> sy_bn_silu_apply (+ Bottleneck / DFP residual) into the consumer's channel
             slice.  Current frame first, then support frame, with SEPARATE statistics (trap T2).
-  loss      raw [B, A, 5+nc] fp32 -> TAL loss (model/tal_loss.py) -> d_raw.
+  loss      raw [B, A, 5+nc] fp32 -> SimOTA + TAL loss and its closed-form gradient (csrc/tal_loss.hip) -> d_raw.
   backward  reverse walk: BN/SiLU backward (reduce + apply), MFMA wgrad straight into a flat fp32
             gradient arena laid out like the parameters (so .grad tensors are views of it and the
             RCCL all-reduce is ONE collective over one buffer), MFMA dgrad into gradient mirrors of
@@ -905,6 +905,9 @@ class TrainStep:
     def _capture(self, x, lab, sup):
         """Record the step into a hipGraph over static copies of the inputs.  The side-stream forks join back inside
         forward() / backward(), so the capture is one connected graph whose independent branches may run concurrently."""
+        if isinstance(x, FramePairsU8):
+            raise NotImplementedError("TrainStep(graph=True) takes the fp32 [B,6,H,W] tensor; uint8 frame pairs "
+                                      "(FramePairsU8) run through the launch tapes (graph=False, the default)")
         self.gx, self.glab, self.gsup = x.float().contiguous().clone(), lab.clone(), sup.clone()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

@@ -96,3 +96,29 @@ def test_fused_optimizer_on_the_training_arena():
     assert losses[-1] < losses[0]                                # same batch, SGD on it: the loss goes down
     ema = opt.ema_state_dict()
     assert set(ema) == set(m.state_dict())
+
+
+def test_cached_eval_plan_follows_raw_pointer_weight_updates(backend):
+    """FusedSGDEMA.step and the BatchNorm running-statistics launch write parameters / buffers through raw pointers
+    (tensor._version does not move): an inference plan built BEFORE the update must repack its weights and refold its
+    BatchNorm afterwards (ops.weights_epoch), i.e. train -> eval -> optimizer step -> eval serves the new weights."""
+    from streamyolo_amd.utils.synth import synth_frames, load_bn_stats
+    cfg = O.OracleConfig.named("nano")
+    m = sy.build_model("nano")
+    m.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=load_bn_stats("nano")), strict=True)
+    m = m.to(backend).eval().set_compute_dtype("fp32")
+    x = synth_frames(1, 64, 96, seed=2).to(backend)
+    with torch.no_grad():
+        out0 = m(x).clone()
+    g = torch.Generator().manual_seed(7)
+    for p in m.parameters():
+        p.grad = (torch.randn(p.shape, generator=g) * 0.05).to(backend)
+    versions = [p._version for p in m.parameters()]
+    FusedSGDEMA(m).step(0.05)
+    assert versions == [p._version for p in m.parameters()]      # the raw-pointer write is invisible to torch ...
+    with torch.no_grad():
+        out1 = m(x).clone()                                      # ... the cached plan must notice anyway
+        fresh = copy.deepcopy(m)                                 # deepcopy: empty plan cache, same (updated) weights
+        want = fresh(x)
+    assert _rel(out1.cpu(), want.cpu()) < 1e-6
+    assert _rel(out1.cpu(), out0.cpu()) > 1e-3                   # and the update was big enough to matter
