@@ -60,6 +60,10 @@ def parse():
                     help="stream: also copy the frame from pinned host memory inside every step (PCIe-inclusive latency; "
                          "never the headline value)")
     ap.add_argument("--train-graph", type=int, default=0, help="train: hipGraph replay instead of launch tapes (slower on ROCm 7)")
+    ap.add_argument("--path", default="trainstep", choices=["trainstep", "dropin"],
+                    help="train: 'trainstep' = streamyolo_amd.TrainStep (sync-free fast path, gradients stay in the flat arena); "
+                         "'dropin' = the UNCHANGED reference trainer's call sequence, model(inps, targets)['total_loss'].backward() "
+                         "(exps/train_utils/double_trainer.py:107-114), through the autograd.Function of train_forward")
     return ap.parse_args()
 
 
@@ -112,20 +116,25 @@ def cpu_baseline(args, workload, flops_pair):
 
 
 def pmc_traffic(workload, args, B):
+    return pmc_traffic_full(workload, args, B)[:2]
+
+
+def pmc_traffic_full(workload, args, B):
     """HBM-side bytes per step of the MFMA kernels from the committed PMC passes of this exact configuration
     (tools/pmc_traffic.py: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE in separate passes).  PMC collection
     serialises kernels, so it is not re-run inside the timed bench; null when no matching measurement exists."""
     import glob
     if (args.height, args.width) != (600, 960) or args.dtype != "bf16" or B != 8:
-        return None, None
+        return None, None, None
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%s_%s.json" % (workload, args.model))))
     if not hits:
-        return None, None
+        return None, None, None
     try:
         with open(hits[-1]) as fh:
-            return float(json.load(fh)["mfma_kernels_bytes"]), os.path.relpath(hits[-1], ROOT)
+            d = json.load(fh)
+            return float(d["mfma_kernels_bytes"]), os.path.relpath(hits[-1], ROOT), d.get("commit")
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, None, None
 
 
 def main():
@@ -165,7 +174,7 @@ def main():
         flops_pair = O.conv_flops_per_pair(cfg, args.height, args.width, mode="on_pipe")
 
     model = sy.build_model(args.model)
-    bn = load_bn_stats(args.model) if args.model in ("nano", "s", "l") else None
+    bn = load_bn_stats(args.model) if args.model in ("nano", "s", "m", "l") else None
     model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=bn), strict=True)
     model = model.to(dev).set_compute_dtype(args.dtype)
     B = args.batch if args.batch is not None else (1 if workload == "stream" else 8)
@@ -187,14 +196,26 @@ def main():
         opt = [None]
 
         def step():
-            out = stepper.step(x, (lab, sup))
+            if args.path == "dropin":
+                for p_ in model.parameters():                 # optimizer.zero_grad() (set_to_none)
+                    p_.grad = None
+                out = model(x, (lab, sup))
+                out["total_loss"].backward()
+            else:
+                out = stepper.step(x, (lab, sup))
             if args.with_optimizer:
                 if opt[0] is None:
                     from streamyolo_amd.optim import FusedSGDEMA
                     opt[0] = FusedSGDEMA(model)
                 opt[0].step(1e-5)               # tiny lr: the synthetic batch must not blow the random-init weights up
             return out
-        profile = stepper.profile
+        if args.path == "dropin":
+            model.train()
+            model.head.use_l1 = True
+            from streamyolo_amd.train_engine import get_train_plan
+            profile = lambda n: get_train_plan(model, x).profile(x, (lab, sup), n)      # noqa: E731
+        else:
+            profile = stepper.profile
     elif workload == "stream":
         # BASELINE.json configs[4]: on_pipe steady state, one 600x960 frame per step, decode + NMS included
         from streamyolo_amd.postprocess import postprocess_device
@@ -269,12 +290,20 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # per-step durations: one HIP event on the launch stream after every step (no synchronisation inside the timed region);
+    # median and p10 / p90 over the timed steps beside the mean that `value` is computed from
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # launch-side time (the GPU runs behind it)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, max(0, int(round(q * (len(per_step) - 1)))))]      # noqa: E731
+    step_stats = {"median": round(pct(0.5), 4), "p10": round(pct(0.1), 4), "p90": round(pct(0.9), 4)}
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,11 +318,11 @@ def main():
         prof = profile(3)                                       # {kind: ms per step}
         mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad"))
         ach = flops_pair * B / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(workload, args, B)
+        traffic, traffic_src, traffic_commit = pmc_traffic_full(workload, args, B)
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel" + ("+conv_wgrad_tr_kernel" if workload == "train" else ""),
                     "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_unit": "bytes/step (MFMA kernels)",
-                    "traffic_source": traffic_src,
+                    "traffic_source": traffic_src, "traffic_commit": traffic_commit,
                     "flops_per_step": flops_pair * B, "kernel_ms_per_step": mfma_ms,
                     "per_kind_ms": {k: round(v, 4) for k, v in prof.items()},
                     "whole_step_frac": flops_pair * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype]}
@@ -307,7 +336,7 @@ def main():
             "metric": ("frames/sec (600x960) StreamYOLO-%s on_pipe fwd + decode + NMS" % args.model) if workload == "stream"
             else "frame-pairs/sec (600x960) StreamYOLO-%s %s" % (args.model, "fwd+bwd" if workload == "train" else "fwd (eval)"),
             "value": value, "unit": "frames/s" if workload == "stream" else "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "step_ms": step_stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "StreamYOLO-%s %dx%d %s, %d frame pairs/GPU/step, %s"
                                    % (args.model, args.height, args.width,
@@ -319,6 +348,7 @@ def main():
                        "hipgraph": bool(args.train_graph if workload == "train" else args.graph == 1),
                        "launch_tape": True if workload == "train" and not args.train_graph else (args.graph == 2 if workload == "stream" else False),
                        "optimizer_in_step": bool(args.with_optimizer) if workload == "train" else None,
+                       "path": args.path if workload == "train" else None,
                        "u8_input": bool(args.u8_input) if workload in ("stream", "train") else None,
                        "h2d_in_step": bool(args.h2d) if workload == "stream" else None,
                        "host_launch_ms_per_step": round(host_ms, 3)},

@@ -26,8 +26,8 @@ def _gen(key, seed):
 
 
 def load_bn_stats(name, root=None):
-    """Calibrated BN running statistics for model `name` ('nano' | 's' | 'l'), minted once by
-    oracle/make_golden.py (one training-mode pass of the reference over synthetic frames) and
+    """Calibrated BN running statistics for model `name` ('nano' | 's' | 'm' | 'l'), minted once by
+    oracle/make_golden.py / make_golden_m.py (one training-mode pass of the reference over synthetic frames) and
     committed as tests/golden/bnstats_<name>.npz.  With them the eval-mode network keeps O(1)
     activations through all ~130 convs, so output parity is sensitive to every layer."""
     import os

@@ -289,3 +289,104 @@ def test_segmented_conv_stats_and_batchnorm(backend, dt):
     ops.bn_silu_bwd_apply(yv, dav, scale, shift, mean, invstd, gd, sums, dyv, dgam, dbet, nseg=2)
     assert _rel(dbet.cpu(), beta.grad) < 1e-4 and _rel(dgam.cpu(), gamma.grad) < 1e-4
     assert _rel(dyv.nchw().cpu(), yq.grad) < (3e-2 if dt == "bf16" else 1e-4)
+
+
+# ---- property tests (hypothesis; NMS keep-set vs an independent greedy walk; decode invertibility) ----
+def _greedy_nms_reference(pred, nc, conf, thr):
+    """Independent restatement (numpy, one pass over score-sorted candidates) of yolox postprocess + torchvision
+    batched_nms semantics: keep list of anchor indices in descending score order, suppress when IoU > thr (strict),
+    class-aware, IoU = inter / (a + b - inter)."""
+    p = pred.numpy().astype(np.float32)
+    box = np.stack([p[:, 0] - p[:, 2] / 2, p[:, 1] - p[:, 3] / 2, p[:, 0] + p[:, 2] / 2, p[:, 1] + p[:, 3] / 2], 1)
+    cls = p[:, 5:5 + nc].argmax(1)
+    cconf = p[:, 5:5 + nc].max(1)
+    score = (p[:, 4] * cconf).astype(np.float32)
+    cand = np.nonzero(score >= np.float32(conf))[0]
+    cand = cand[np.argsort(-score[cand], kind="stable")]
+    keep = []
+    for i in cand:
+        ok = True
+        for j in keep:
+            if cls[j] != cls[i]:
+                continue
+            lt = np.maximum(box[i, :2], box[j, :2]); rb = np.minimum(box[i, 2:], box[j, 2:])
+            wh = np.maximum(rb - lt, np.float32(0))
+            inter = wh[0] * wh[1]
+            a = (box[i, 2] - box[i, 0]) * (box[i, 3] - box[i, 1]); b = (box[j, 2] - box[j, 0]) * (box[j, 3] - box[j, 1])
+            if inter / (a + b - inter) > np.float32(thr):
+                ok = False
+                break
+        if ok:
+            keep.append(int(i))
+    return keep
+
+
+def test_nms_keep_set_property_random_boxes(backend):
+    """hypothesis-driven: for random box sets (clustered so that suppression actually happens) the device keep list
+    equals the independent greedy walk — set AND order — and is idempotent: NMS of the kept boxes keeps all of them."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    nc = 4
+
+    @settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(0, 2 ** 31 - 1), st.sampled_from([1, 7, 64, 129, 400]), st.floats(0.3, 0.8))
+    def run(seed, A, thr):
+        g = torch.Generator().manual_seed(seed)
+        centres = torch.rand(max(1, A // 6), 2, generator=g) * 200 + 50
+        which = torch.randint(0, centres.shape[0], (A,), generator=g)
+        p = torch.zeros(1, A, 5 + nc)
+        p[0, :, 0:2] = centres[which] + torch.randn(A, 2, generator=g) * 4
+        p[0, :, 2:4] = torch.rand(A, 2, generator=g) * 40 + 10
+        p[0, :, 4] = torch.rand(A, generator=g) * 0.5 + 0.25 + torch.arange(A) * 2.0 ** -20      # tie-free
+        p[0, :, 5:] = torch.rand(A, nc, generator=g)
+        det, idx, cnt = ops.postprocess(p.to(backend), nc, 0.2, float(thr))
+        n = int(cnt[0])
+        got = idx[0, :n].cpu().tolist()
+        assert got == _greedy_nms_reference(p[0], nc, 0.2, float(thr))
+        if n:
+            again, idx2, cnt2 = ops.postprocess(p[:, got].contiguous().to(backend), nc, 0.2, float(thr))
+            assert int(cnt2[0]) == n and idx2[0, :n].cpu().tolist() == list(range(n))
+    run()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A", [0, 4096, 11850])
+def test_nms_keep_set_at_survey_sizes(A):
+    """SURVEY.md §8(d) NMS unit inputs at N in {0, 4096, 11850} (1 and 64 run above on both back ends): bit-exact keep
+    lists, order included, against the oracle's torchvision-semantics restatement."""
+    from streamyolo_amd import _lib
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda:0")
+    nc = 8
+    pred = _random_preds(2, max(A, 1), nc, seed=100 + A)
+    if A == 0:
+        pred[..., 4] = 0.0
+    det, idx, cnt = ops.postprocess(pred.to(dev), nc, 0.01, 0.65)
+    for i, (rdet, ridx) in enumerate(O.postprocess(pred, nc, 0.01, 0.65)):
+        n = int(cnt[i])
+        assert n == ridx.numel() and np.array_equal(idx[i, :n].cpu().numpy(), ridx.numpy().astype(np.int32))
+        assert torch.equal(det[i, :n].cpu(), rdet)
+
+
+def test_decode_is_invertible(backend):
+    """The decode epilogue of the prediction convs: (xy + grid) * stride, exp(wh) * stride, sigmoid(obj / cls).  Inverting
+    it on the device output — raw = logit / log / (x / stride - grid) — must return the undecoded (EPI_LINEAR) output of
+    the same launch configuration, for every level geometry of a 96 x 160 input."""
+    from streamyolo_amd.ops import View, conv2d, EPI_DECODE, EPI_LINEAR
+    g = torch.Generator().manual_seed(3)
+    for (H, W, stride) in ((12, 20, 8), (6, 10, 16), (3, 5, 32)):
+        B, cin, nch = 2, 32, 13
+        x = View.alloc(B, H, W, cin, "fp32", backend)
+        x.buf.copy_(torch.randn(B, H, W, cin, generator=g).to(backend) * 0.3)
+        w = (torch.randn(5, cin, generator=g) * 0.2).to(backend)
+        b = (torch.randn(5, generator=g) * 0.1).to(backend)
+        outs = []
+        for epi in (EPI_LINEAR, EPI_DECODE):
+            out = torch.zeros(B, H * W, nch, device=backend)
+            conv2d(x, w, None, 1, 1, None, b, epilogue=epi, dec_stride=stride, y_f32=True, y_ptr=out.data_ptr(), y_ld=nch,
+                   y_bs=H * W * nch, cout=5)
+            outs.append(out.cpu())
+        raw, dec = outs
+        gy, gx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        grid = torch.stack([gx, gy], -1).reshape(1, H * W, 2).float()
+        inv = torch.cat([dec[..., 0:2] / stride - grid, (dec[..., 2:4] / stride).log(), torch.logit(dec[..., 4:5])], -1)
+        assert (inv - raw[..., :5]).abs().max() < 2e-4 * max(1.0, float(raw[..., :5].abs().max()))

@@ -18,6 +18,29 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def _per_param_l2(model, ref_grads):
+    """(worst, name, median) of ||g - g_ref|| / ||g_ref|| over the parameters, every parameter normalised by its OWN
+    reference norm (a small-gradient tensor that is 100 % wrong cannot hide behind the largest one)."""
+    errs = []
+    for name, p in model.named_parameters():
+        r = ref_grads[name].double()
+        errs.append((float((p.grad.detach().cpu().double() - r).norm() / r.norm().clamp_min(1e-30)), name))
+    errs.sort()
+    return errs[-1][0], errs[-1][1], errs[len(errs) // 2][0]
+
+
+def _oracle_step(name, B, H, W, ngt, sd=None):
+    cfg = O.OracleConfig.named(name)
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0) if sd is None else sd
+    x = synth_frames(B, H, W, seed=2)
+    lab, sup = synth_labels(B, H, W, cfg.num_classes, num_gt=ngt, seed=3)
+    osd = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.clone())
+           for k, v in sd.items()}
+    ref = O.forward_train(osd, x, lab, sup, cfg)
+    ref["total_loss"].backward()
+    return ref, {k: v.grad for k, v in osd.items() if v.is_floating_point() and v.requires_grad}
+
+
 def _setup(name, tag, golden_dir, device, dt, ngt=6):
     z = np.load(os.path.join(golden_dir, tag + ".npz"))
     B, H, W = [int(v) for v in z["shape"]]
@@ -97,8 +120,37 @@ def test_launch_tape_replay_matches_direct_step(backend, golden_dir):
     assert abs(float(out["total_loss"]) - res[0][0]) / abs(res[0][0]) > 1e-3
 
 
+# speed-mode bounds <= 3x the measured error (profiles/r02 pytest log): bf16 loss 3.0e-3 measured
+S_TRAIN_TOL = {"fp32": (1e-3, 2e-3), "bf16": (1e-2, 1.5e-1)}          # (loss, worst per-parameter relative L2 gradient error)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt,ltol", [("fp32", 1e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_train_step_s_160x256_per_parameter_gradients(dt):
+    """Every parameter gradient of the s step against the oracle's autograd, each normalised by its own norm — in the
+    exact-fp32 mode AND in the bf16 speed mode bench.py times."""
+    from streamyolo_amd import _lib
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda:0")
+    ref, rgrads = _oracle_step("s", 2, 160, 256, 6)
+    cfg = O.OracleConfig.named("s")
+    model = sy.build_model("s")
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0), strict=True)
+    model = model.to(dev).train().set_compute_dtype(dt)
+    model.head.use_l1 = True
+    lab, sup = synth_labels(2, 160, 256, cfg.num_classes, num_gt=6, seed=3)
+    out = model(synth_frames(2, 160, 256, seed=2).to(dev), (lab.to(dev), sup.to(dev)))
+    out["total_loss"].backward()
+    want = np.array([float(ref[k]) for k in NAMES]); got = np.array([float(out[k]) for k in NAMES])
+    lerr = np.abs(got - want).max() / np.abs(want).max()
+    worst, wname, med = _per_param_l2(model, rgrads)
+    print("s 160x256 %s: loss rel err %.3e; per-parameter gradient rel L2 error worst %.3e (%s), median %.3e"
+          % (dt, lerr, worst, wname, med))
+    assert lerr < S_TRAIN_TOL[dt][0] and worst < S_TRAIN_TOL[dt][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,ltol", [("fp32", 1e-3), ("bf16", 1e-2)])
 def test_train_step_s_160x256(golden_dir, dt, ltol):
     from streamyolo_amd import _lib
     _lib.use_library(_lib.DEFAULT_PATH)
@@ -187,6 +239,10 @@ def test_pipe_head_training_matches_reference(backend, golden_dir, use_l1):
     assert np.abs(norms - z["grad_norms_" + tag]).max() / np.abs(z["grad_norms_" + tag]).max() < 2e-3
 
 
+# worst per-parameter relative L2 gradient error (each parameter normalised by its own norm); measured on MI355X, bound <= 3x
+L_GRAD_TOL = {"fp32": 2e-3, "bf16": 3e-1}
+
+
 @pytest.mark.gpu
 def test_train_step_l_600x960_full_size_vs_oracle():
     """BASELINE.json's configuration itself (StreamYOLO-l, 600x960; one frame pair so the CPU oracle finishes in
@@ -204,7 +260,8 @@ def test_train_step_l_600x960_full_size_vs_oracle():
     ref = O.forward_train(osd, x, lab, sup, cfg)
     ref["total_loss"].backward()
     want = np.array([float(ref[k]) for k in NAMES])
-    for dt, ltol in (("fp32", 1e-3), ("bf16", 5e-2)):
+    rgrads = {k: v.grad for k, v in osd.items() if v.is_floating_point() and v.requires_grad}
+    for dt, ltol, gtol in (("fp32", 1e-3, L_GRAD_TOL["fp32"]), ("bf16", 3e-2, L_GRAD_TOL["bf16"])):   # bf16 loss measured 1.0e-2
         model = sy.build_model("l")
         model.load_state_dict(sd, strict=True)
         model = model.to(dev).train().set_compute_dtype(dt)
@@ -215,6 +272,9 @@ def test_train_step_l_600x960_full_size_vs_oracle():
         lerr = np.abs(got - want).max() / np.abs(want).max()
         print("l 600x960 %s: loss rel err %.3e" % (dt, lerr))
         assert lerr < ltol
+        worst, wname, med = _per_param_l2(model, rgrads)
+        print("l 600x960 %s: per-parameter gradient rel L2 error worst %.3e (%s), median %.3e" % (dt, worst, wname, med))
+        assert worst < gtol
         if dt == "fp32":
             gn, rn = [], []
             for name, p in model.named_parameters():
@@ -225,3 +285,30 @@ def test_train_step_l_600x960_full_size_vs_oracle():
             assert nerr < 2e-3
         del model, out
         torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_train_step_m_vs_reference_golden(golden_dir):
+    """StreamYOLO-m training step (widths 48..768: Cin / Cout that are not multiples of the 64-byte K slab go through the
+    generic loader, the scatter wgrad and ragged channel tiles) against the reference's own losses, gradients and running
+    statistics; fp32 mode 1e-3 / 2e-3, bf16 speed mode loss bound."""
+    from streamyolo_amd import _lib
+    _lib.use_library(_lib.DEFAULT_PATH)
+    dev = torch.device("cuda:0")
+    for dt, ltol in (("fp32", 1e-3), ("bf16", 3e-2)):
+        z, model, x, targets = _setup("m", "m_train_2x128x192", golden_dir, dev, dt)
+        out = model(x, targets)
+        out["total_loss"].backward()
+        got = np.array([float(out[k]) for k in NAMES])
+        lerr = np.abs(got - z["losses"]).max() / np.abs(z["losses"]).max()
+        print("m train %s: loss rel err %.3e" % (dt, lerr))
+        assert lerr < ltol
+        if dt == "fp32":
+            named = dict(model.named_parameters())
+            worst = max(_rel(named[k[5:]].grad.cpu(), z[k]) for k in z.files if k.startswith("grad:"))
+            norms = np.array([float(named[k].grad.double().norm()) for k in sorted(named)])
+            nerr = np.abs(norms - z["grad_norms"]).max() / np.abs(z["grad_norms"]).max()
+            sd = model.state_dict()
+            serr = max(_rel(sd[k[5:]].float().cpu(), z[k]) for k in z.files if k.startswith("stat:"))
+            print("m train fp32: worst small-grad rel err %.3e, grad-norm rel err %.3e, running-stat rel err %.3e" % (worst, nerr, serr))
+            assert worst < 5e-3 and nerr < 2e-3 and serr < 2e-3

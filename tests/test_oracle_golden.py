@@ -19,18 +19,18 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("name", ["nano", "s", "l"])
+@pytest.mark.parametrize("name", ["nano", "s", "m", "l"])
 def test_param_inventory_matches_reference_keys(name, golden_dir):
     want = {}
     for line in open(os.path.join(golden_dir, "keys_%s.txt" % name)):
         k, shp = line.split()
         want[k] = () if shp == "scalar" else tuple(int(v) for v in shp.split("x"))
     assert O.param_shapes(O.OracleConfig.named(name)) == want
-    assert len(want) == {"nano": 480, "s": 480, "l": 768}[name]
+    assert len(want) == {"nano": 480, "s": 480, "m": 624, "l": 768}[name]
 
 
 @pytest.mark.parametrize("name,tag", [("nano", "nano_eval_2x64x96"), ("nano", "nano_eval_1x152x200"),
-                                      ("s", "s_eval_1x600x960")])
+                                      ("s", "s_eval_1x600x960"), ("m", "m_eval_1x200x320")])
 def test_eval_forward_and_postprocess(name, tag, golden_dir):
     z = np.load(os.path.join(golden_dir, tag + ".npz"))
     B, H, W = [int(v) for v in z["shape"]]
@@ -51,7 +51,8 @@ def test_eval_forward_and_postprocess(name, tag, golden_dir):
         assert np.array_equal(idx.numpy().astype(np.int32), z["keep%d" % i])
 
 
-@pytest.mark.parametrize("name,tag,ngt", [("nano", "nano_train_2x64x96", 6), ("s", "s_train_2x160x256", 6)])
+@pytest.mark.parametrize("name,tag,ngt", [("nano", "nano_train_2x64x96", 6), ("s", "s_train_2x160x256", 6),
+                                          ("m", "m_train_2x128x192", 6)])
 def test_train_loss_grads_and_bn_stats(name, tag, ngt, golden_dir):
     z = np.load(os.path.join(golden_dir, tag + ".npz"))
     B, H, W = [int(v) for v in z["shape"]]

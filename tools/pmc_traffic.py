@@ -61,10 +61,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--commit", default=None, help="tree the counters were taken on (default: tools/.head_commit, written before gpurun)")
     ap.add_argument("bench", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     bench_args = [x for x in a.bench if x != "--"] + ["--steps", str(a.steps), "--warmup", "3", "--no-cpu-baseline"]
-    res = {"bench_args": bench_args, "units": "bytes per step", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950)",
+    commit = a.commit
+    if commit is None:
+        try:
+            commit = open(os.path.join(ROOT, "tools", ".head_commit")).read().strip()
+        except OSError:
+            commit = None
+    res = {"commit": commit, "bench_args": bench_args, "units": "bytes per step", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950)",
            "write_correction": "WRITE_SIZE KiB x 1024 (uncalibrated)", "families": {}}
     with tempfile.TemporaryDirectory(dir="/tmp") as wd:
         for counter, scale, key in (("FETCH_SIZE", 2048.0, "read"), ("WRITE_SIZE", 1024.0, "write")):
