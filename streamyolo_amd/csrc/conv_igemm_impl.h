@@ -60,7 +60,21 @@ struct ConvArgs {
     const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
     unsigned wfrag_extent;
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads
+    // BatchNorm-backward fusion of a data-gradient launch (sy_conv_desc::gs): output channels [c0, c1) are the gradient
+    // of ONE BaseConv's activation; the write-out pass multiplies them by silu'(bn(raw)) and accumulates the two
+    // per-channel reduction sums of that BatchNorm (what sy_bn_silu_bwd_reduce computed in a pass of its own)
+    int gs_count;               // 0, 1 or 2 ranges
+    int gs_seg_M;               // pixels per statistics segment (M / segments)
+    struct Gs {
+        int c0, c1, ldraw, copies;
+        const unsigned char* raw;
+        const float* scale; const float* shift; const float* mean; const float* invstd;
+        float* sums;
+    } gs[2];
 };
+
+// LDS in front of the staged output tile: BN-statistics scratch [WP][CT][2] floats, or the g-space sums [2 seg][2][CT]
+template <int WP, int CT> struct EpiLds { static constexpr int kStatBytes = (WP < 2 ? 2 : WP) * CT * 8; };
 
 constexpr int kRowB = 64;           // DMA ring: bytes of K per LDS row per slab (unpadded: LDS-DMA lands lane-linear)
 constexpr int kPitchRS = 80;        // register-staged: 64 B of K + 16 B pad per LDS row (conflict-free ds_read_b128)
@@ -576,8 +590,8 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
     // [pixel][channel] and the workgroup writes whole pixel rows, 16 bytes per lane, consecutive lanes consecutive
     // addresses (the K loop is over, its LDS is free).
     constexpr int kStagePitch = CT * 2 + 16;                    // bytes per staged pixel row (+16: bank spread)
-    constexpr int kStatBytes = WP * CT * 8;                     // BN-statistics scratch [WP][CT][2] floats (aliases too)
-    constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 8 + kStatBytes <= 48 * 1024);
+    constexpr int kStatBytes = EpiLds<WP, CT>::kStatBytes;      // BN-statistics scratch [WP][CT][2] floats / g-space sums [2][2][CT]
+    constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 12 + kStatBytes <= 48 * 1024);
     // (+= outputs — data gradients of activations with several consumers — are staged too: the write-out pass reads
     //  the old row chunk, adds in fp32 and stores, all coalesced; the staged value was already rounded to 16 bits,
     //  one extra rounding the gradient path tolerates.  Residual adds keep the direct path: single rounding.)
@@ -585,7 +599,13 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
                            ((reinterpret_cast<unsigned long long>(p.y) & 15ull) == 0);
     unsigned char* const stg = smem + kStatBytes;               // [PT][kStagePitch]
     long long* const stg_off = reinterpret_cast<long long*>(smem + kStatBytes + PT * kStagePitch);   // [PT] element offsets
+    int* const stg_lin = reinterpret_cast<int*>(smem + kStatBytes + PT * kStagePitch + PT * 8);      // [PT] n * Ho*Wo + pixel
+    const bool gs_on = kCanStage && stage_out && p.gs_count > 0 && !want_stats;
     if (want_stats || stage_out) __syncthreads();               // every wave is done with the operand tiles
+    if (gs_on) {                                                // g-space sums [2 segments][2 kinds][CT], zeroed before the barrier below
+        float* redg = reinterpret_cast<float*>(smem);
+        for (int i = tid; i < 4 * CT; i += kThreads) redg[i] = 0.0f;
+    }
     // ---- lean path for staged outputs (every training forward / first-write data gradient / eval conv without a
     //      residual): the mode, affine and statistics decisions are taken ONCE here, not per element — the general
     //      loop below re-tests them for each of its 16 x TP values per tile, and at 1x1 layers (4-16 slabs of MFMA
@@ -602,13 +622,16 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
                     for (int u = 0; u < TP; ++u) {
                         const int m = m0 + (wp * TP + u) * 32 + l31;
                         long long off = -1;
+                        int lin = -1;
                         if (m < m_end) {
                             const int n = m / cls_hw;
                             int rem = m - n * cls_hw;
                             if (p.s2_classes) { const int i2 = rem / Wc; rem = (2 * i2 + cls_ph) * p.Wo + 2 * (rem - i2 * Wc) + cls_pw; }
                             off = (long long)n * p.ybs + (long long)rem * p.ldy;
+                            lin = n * p.HoWo + rem;
                         }
                         stg_off[(wp * TP + u) * 32 + l31] = off;
+                        stg_lin[(wp * TP + u) * 32 + l31] = lin;
                     }
                 }
                 sy_static_for<0, TC>([&](auto tc_) {
@@ -688,8 +711,10 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
             const long long roff = (long long)n * p.rbs + (long long)rem * p.ldr;
             int gy = 0, gx = 0;
             if (p.epilogue == SY_EPI_DECODE) { gy = rem / p.Wo; gx = rem - gy * p.Wo; }
-            if (kCanStage && stage_out && t == 0 && wc == 0 && half == 0)
+            if (kCanStage && stage_out && t == 0 && wc == 0 && half == 0) {
                 stg_off[(wp * TP + u) * 32 + l31] = m_ok ? yoff : -1;
+                stg_lin[(wp * TP + u) * 32 + l31] = m_ok ? n * p.HoWo + rem : -1;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cb = c0 + (wc * TC + t) * 32 + q * 8 + half * 4;   // first of 4 channels
@@ -802,12 +827,46 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
     if (want_stats || (kCanStage && stage_out)) __syncthreads();
     if (kCanStage && stage_out) {
         constexpr int CPR = CT / 8;                             // 16-byte chunks per staged pixel row
+        static_assert(kThreads % CPR == 0, "a thread's channel chunk is fixed across its write-out items");
+        // g-space (BatchNorm-backward fusion): this thread's channel chunk belongs to at most one range
+        int gr = -1;
+        float gs0[2][8], gs1[2][8];
+        if (gs_on) {
+            const int co_t = c0 + (tid % CPR) * 8;
+            for (int r = 0; r < p.gs_count; ++r)
+                if (co_t >= p.gs[r].c0 && co_t < p.gs[r].c1) gr = r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gs0[0][j] = 0.0f; gs0[1][j] = 0.0f; gs1[0][j] = 0.0f; gs1[1][j] = 0.0f; }
+        }
         for (int i = tid; i < PT * CPR; i += kThreads) {
             const int px = i / CPR, ck = i - px * CPR;
             const long long off = stg_off[px];
             const int co = c0 + ck * 8;
             if (off < 0 || co >= p.Cout) continue;
             uint4 v = *reinterpret_cast<const uint4*>(stg + px * kStagePitch + ck * 16);
+            if (gs_on && gr >= 0) {
+                // v holds d(loss)/d(activation) of 8 channels of one pixel; the BatchNorm behind that activation needs
+                // g = da * silu'(z) and its sums over the pixels: sum g, sum g * xhat (z = scale*raw + shift)
+                const int lin = stg_lin[px];
+                const int seg = (p.gs_seg_M > 0 && lin >= p.gs_seg_M) ? 1 : 0;
+                const int Cg = p.gs[gr].c1 - p.gs[gr].c0, cc = co - p.gs[gr].c0;
+                const uint4 rv = *reinterpret_cast<const uint4*>(p.gs[gr].raw + ((long long)lin * p.gs[gr].ldraw + cc) * 2);
+                elem er[8], ev[8];
+                __builtin_memcpy(er, &rv, 16);
+                __builtin_memcpy(ev, &v, 16);
+                const float* a_sc = p.gs[gr].scale + seg * Cg + cc; const float* a_sh = p.gs[gr].shift + seg * Cg + cc;
+                const float* a_mu = p.gs[gr].mean + seg * Cg + cc;  const float* a_is = p.gs[gr].invstd + seg * Cg + cc;
+                float g8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float yy = T::to_f32(er[j]);
+                    const float g = T::to_f32(ev[j]) * sy_silu_grad(yy * a_sc[j] + a_sh[j]);
+                    const float gx = g * ((yy - a_mu[j]) * a_is[j]);
+                    if (seg) { gs0[1][j] += g; gs1[1][j] += gx; } else { gs0[0][j] += g; gs1[0][j] += gx; }
+                    g8[j] = g;
+                }
+                v = make_uint4(T::pack2(g8[0], g8[1]), T::pack2(g8[2], g8[3]), T::pack2(g8[4], g8[5]), T::pack2(g8[6], g8[7]));
+            }
             uint4* const dst = reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + off + co);
             if (p.accumulate) {
                 const uint4 o = *dst;
@@ -821,6 +880,33 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
             *dst = v;
+        }
+        if (gs_on) {
+            // fold the threads that share a channel chunk through LDS, then one global atomic per (segment, kind, channel)
+            float* redg = reinterpret_cast<float*>(smem);       // [2 seg][2 kind][CT]
+            if (gr >= 0) {
+                const int cl = (tid % CPR) * 8;
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (gs0[sg][j] != 0.0f) atomicAdd(&redg[(sg * 2 + 0) * CT + cl + j], gs0[sg][j]);
+                        if (gs1[sg][j] != 0.0f) atomicAdd(&redg[(sg * 2 + 1) * CT + cl + j], gs1[sg][j]);
+                    }
+            }
+            __syncthreads();
+            for (int i = tid; i < 4 * CT; i += kThreads) {
+                const float val = redg[i];
+                if (val == 0.0f) continue;
+                const int sg = i / (2 * CT), kind = (i / CT) & 1, cl = i % CT;
+                const int co = c0 + cl;
+                for (int r = 0; r < p.gs_count; ++r) {
+                    if (co < p.gs[r].c0 || co >= p.gs[r].c1) continue;
+                    const int Cg = p.gs[r].c1 - p.gs[r].c0;
+                    const int copy = (int)((unsigned)bid.y % (unsigned)p.gs[r].copies);
+                    atomicAdd(p.gs[r].sums + ((long long)(sg * p.gs[r].copies + copy) * 2 + kind) * Cg + (co - p.gs[r].c0), val);
+                }
+            }
         }
     }
     if (want_stats) {
@@ -851,8 +937,17 @@ int launch_one(const ConvArgs& a, void* stream) {
                               : (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
                                          : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
     // epilogue staging of 16-bit outputs (see the kernel): statistics scratch + [PT][CT*2+16] + [PT] offsets
-    constexpr size_t smem_e = (size_t)WP * CT * 8 + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
-    constexpr size_t smem = (T::kEPC == 8 && smem_e <= 48 * 1024 && smem_e > smem_k) ? smem_e : smem_k;
+    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 12;
+    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= 48 * 1024);
+    constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : smem_k;
+    if (a.gs_count > 0) {
+        // the BatchNorm-backward fusion lives in the staged write-out pass: refuse configurations that do not take it
+        // (the caller falls back to sy_bn_silu_bwd_reduce) instead of silently writing un-multiplied gradients
+        const bool staged = can_stage && !a.y_f32 && a.res == nullptr && (a.Cout & 3) == 0 && (a.ldy & 7) == 0 &&
+                            (reinterpret_cast<unsigned long long>(a.y) & 15ull) == 0 && a.epilogue != SY_EPI_DECODE &&
+                            a.stat_sum == nullptr;
+        if (!staged) return SY_ERR_UNSUPPORTED;
+    }
 #ifndef SY_EMU
     static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
     if (!attr_done) {

@@ -293,6 +293,11 @@ class TrainPlan:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
         self.cache = StagedWeights(self.ops, self.dtype, device)
+        self._plan_gspace()
+        self._gs_producers = {}
+        for op in self.ops:
+            if op.kind == "conv" and op.gspace:
+                self._gs_producers.setdefault(self._vkey(op.y), []).append(op)
         self.loss_ws = None
         self.run_table = None
         self.grads = _GradSpace()
@@ -396,10 +401,10 @@ class TrainPlan:
         u_sum, u_sq, _, (scale, shift, mean, invstd) = a.unit
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
                    wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
-        mom = bn.momentum if bn.momentum is not None else 0.1
-        ops.bn_finalize(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, mom, None, None, scale, shift, mean, invstd,
-                        nseg=2)
-        ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
+        # batch statistics -> affine -> BN + SiLU (+ residual) in ONE launch; running statistics: one batched launch at
+        # the end of the pass (sy_bn_running_update)
+        ops.bn_apply_fused(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, raw2, y2, scale, shift, mean, invstd,
+                           res=None if a.res is None else a.res.pair(), nseg=2)
 
     # ---- launch programs ------------------------------------------------------------------------------------
     # Step 1 runs the Python wrappers directly (kernel variants get tuned).  Step 2 runs them again under
@@ -501,12 +506,10 @@ class TrainPlan:
             ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
             scale, shift, mean, invstd = op.aff
-            mom = bn.momentum if bn.momentum is not None else 0.1
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
-            ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
-                            None, None, scale, shift, mean, invstd)
-            ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
+            ops.bn_apply_fused(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, op.yraw, op.y,
+                               scale, shift, mean, invstd, res=op.res)
         elif k == "resize":
             ops.resize_nearest(op.src, op.dst)
         elif k == "spp":
@@ -556,6 +559,94 @@ class TrainPlan:
     def _backward_sequence(self):
         nf = self.n_frame_ops
         return list(reversed(self.ops[2 * nf:])) + [self.ops[i] for i in reversed(range(nf))]
+
+    # ---- BatchNorm-backward fusion ("g-space") ---------------------------------------------------------------
+    # For a BaseConv output a = silu(bn(raw)) whose only consumers are convolutions, the data-gradient launches of those
+    # consumers store g = da * silu'(z) and accumulate the two BatchNorm reduction sums themselves (sy_conv_desc::gs):
+    # the separate sy_bn_silu_bwd_reduce pass (one read of da and raw per BaseConv, 128 launches per l step) disappears.
+    # Not eligible (they keep the reduce pass): outputs with a residual add or used AS a residual (the shortcut branch
+    # needs the un-multiplied gradient), outputs read by resize / SPP (their backward kernels write plain gradients),
+    # fp32 plans (the fusion lives in the 16-bit staged write-out pass).
+    FUSE_REDUCE = os.environ.get("STREAMYOLO_FUSE_REDUCE", "1") != "0"
+
+    @staticmethod
+    def _vkey(v):
+        return (id(v.root[0]), v.root[1]) if v.root is not None else (id(v.buf), 0)
+
+    @staticmethod
+    def _overlap(a, b):
+        return TrainPlan._vkey(a) == TrainPlan._vkey(b) and a.c_off < b.c_off + b.C and b.c_off < a.c_off + a.C
+
+    def _plan_gspace(self):
+        convs = [op for op in self.ops if op.kind == "conv"]
+        for op in convs:
+            op.gspace, op.gs_out = False, []
+        if not self.FUSE_REDUCE or self.dtype == ops.DT_F32:
+            return
+        inputs = []                                              # (view, kind, consumer op)
+        for op in self.ops:
+            if op.kind == "conv":
+                inputs.append((op.x, "conv" if op.need_dx else "nodx", op))
+                if op.res is not None:
+                    inputs.append((op.res, "res", op))
+            elif op.kind == "pred":
+                inputs += [(op.reg_x, "pred", op), (op.cls_x, "pred", op)]
+            elif op.kind == "resize":
+                inputs.append((op.src, "other", op))
+            elif op.kind == "spp":
+                inputs.append((op.v, "other", op))
+        cand = {}
+        for P in convs:
+            if P.res is not None or P.y.C % 8 or P.y.c_off % 8:
+                continue
+            users = [(v, k, c) for v, k, c in inputs if self._overlap(v, P.y)]
+            if not users or any(k not in ("conv", "pred") for _, k, _ in users):
+                continue
+            # every consumer's input view must contain the whole output range, 16-byte aligned, ld a multiple of 8
+            if all(v.c_off <= P.y.c_off and P.y.c_off + P.y.C <= v.c_off + v.C and v.ld % 8 == 0 and v.c_off % 8 == 0
+                   for v, _, _ in users):
+                cand[id(P)] = (P, users)
+        # a launch carries at most two ranges: demote the producers of any consumer view that would need more
+        changed = True
+        while changed:
+            changed = False
+            per_view = {}
+            for P, users in cand.values():
+                for v, k, c in users:
+                    per_view.setdefault((id(c), id(v)), []).append(P)
+            for lst in per_view.values():
+                if len(lst) > 2:
+                    for P in lst[2:]:
+                        if id(P) in cand:
+                            del cand[id(P)]
+                            changed = True
+        for P, users in cand.values():
+            P.gspace = True
+        # the two frames of a pair share their launches: a layer is fused only if both frames' outputs qualify (the
+        # current frame's PAN outputs are the DFP residual, the support frame's are not)
+        nf = self.n_frame_ops
+        for i in range(nf):
+            a, b2 = self.ops[i], self.ops[nf + i]
+            if a.kind == "conv" and a.gspace != b2.gspace:
+                a.gspace = b2.gspace = False
+        self.n_gspace = sum(1 for op in convs if op.gspace)
+
+    def _gs_for(self, xview, pair):
+        """sy_conv_desc::gs ranges of a data-gradient launch whose output is the gradient of activation view `xview`."""
+        out = []
+        for P in self._gs_producers.get(self._vkey(xview), ()):
+            if not (P.gspace and self._overlap(xview, P.y)):
+                continue
+            c0 = P.y.c_off - xview.c_off
+            if pair:
+                _, _, u_bsum, (scale, shift, mean, invstd) = P.unit
+                raw, sums = P.yraw.pair(), u_bsum
+            else:
+                (scale, shift, mean, invstd), raw, sums = P.aff, P.yraw, P.bsum
+            out.append(dict(c0=c0, c1=c0 + P.y.C, raw=raw, scale=scale, shift=shift, mean=mean, invstd=invstd, sums=sums,
+                            copies=self.BWD_COPIES))
+        assert len(out) <= 2
+        return out or None
 
     def _build_buckets(self):
         last = {}
@@ -636,9 +727,9 @@ class TrainPlan:
         d_ro = View(self.dpad, B, op.reg_x.H, op.reg_x.W, 8, 16, op.a0 * 16, bs=A * 16)
         d_c = View(self.dpad, B, op.reg_x.H, op.reg_x.W, nc, 16, op.a0 * 16 + 8, bs=A * 16)
         g_r, acc_r = G.target(op.reg_x)
-        ops.conv2d(d_ro, w_ro_t, g_r, 1, 1, mode=CONV_DGRAD, accumulate=acc_r)
+        ops.conv2d(d_ro, w_ro_t, g_r, 1, 1, mode=CONV_DGRAD, accumulate=acc_r, gs=self._gs_for(op.reg_x, False))
         g_c, acc_c = G.target(op.cls_x)
-        ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c)
+        ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c, gs=self._gs_for(op.cls_x, False))
         cin = op.reg_x.C
 
         sc = self.pred_scratch
@@ -671,9 +762,11 @@ class TrainPlan:
         dY = G.view(op.y)
         dres, acc = (None, False) if op.res is None else G.target(op.res)    # y = silu(bn(conv)) + res: dres (+)= dY
         scale, shift, mean, invstd = op.aff
-        ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
+        if not op.gspace:                                        # g-space: the consumers' data-gradient launches did it
+            ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
         ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, bn.weight, op.bsum, dyraw,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], dres=dres, dres_accumulate=acc)
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], dres=dres, dres_accumulate=acc,
+                              g_space=op.gspace)
 
     def _wgrad(self, op, x, dyraw):
         w = op.mod.conv.weight
@@ -721,9 +814,12 @@ class TrainPlan:
             dres2 = dra.pair()                                       # written by the BN backward apply pass below
         _, _, u_bsum, (scale, shift, mean, invstd) = a.unit
         raw2 = a.yraw.pair()
-        ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
+        assert a.gspace == b2.gspace
+        if not a.gspace:
+            ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
         ops.bn_silu_bwd_apply(raw2, dY2, scale, shift, mean, invstd, bn.weight, u_bsum, dy2,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2, dres=dres2, dres_accumulate=acca)
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2, dres=dres2, dres_accumulate=acca,
+                              g_space=a.gspace)
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot)
         if a.need_dx:
             dxa, acca = G.target(a.x)
@@ -735,7 +831,8 @@ class TrainPlan:
                 a._tiles["dgrad2"] = t
             ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
                        mode=CONV_DGRAD, accumulate=acca, tile=t,
-                       wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
+                       wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None,
+                       gs=self._gs_for(a.x.pair(), True), gs_segments=2)
 
     def _conv_backward(self, op):
         G = self.grads
@@ -749,14 +846,15 @@ class TrainPlan:
             t = op.tile("dgrad")
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
                        mode=CONV_DGRAD, accumulate=acc, tile=t,
-                       wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None)
+                       wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None,
+                       gs=self._gs_for(op.x, False))
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, x, targets, iters=2, detail=False):
         """Per-op-kind kernel time (ms / step) with HIP events on the launch stream (bench.py roofline).
         detail=True: per (kind, shape) rows [(kind, shape, launches / step, ms / step, flops / step)] instead."""
         evs = []
-        real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply",
+        real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply", "bn_apply_fused",
                                              "bn_silu_bwd_reduce", "bn_silu_bwd_apply", "resize_nearest",
                                              "resize_nearest_bwd", "spp_pool", "spp_pool_bwd", "view_copy", "focus_pack")}
 

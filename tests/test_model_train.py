@@ -313,3 +313,24 @@ def test_train_step_m_vs_reference_golden(golden_dir):
             serr = max(_rel(sd[k[5:]].float().cpu(), z[k]) for k in z.files if k.startswith("stat:"))
             print("m train fp32: worst small-grad rel err %.3e, grad-norm rel err %.3e, running-stat rel err %.3e" % (worst, nerr, serr))
             assert worst < 5e-3 and nerr < 2e-3 and serr < 2e-3
+
+
+def test_gspace_backward_matches_reduce_pass_backward(backend, golden_dir, monkeypatch):
+    """BatchNorm-backward fusion (TrainPlan.FUSE_REDUCE: the consumers' data-gradient launches store g = da * silu'(z)
+    and accumulate the BatchNorm sums, no sy_bn_silu_bwd_reduce pass) against the unfused plan in the 16-bit mode it runs
+    in: same loss (the forward is untouched), every parameter gradient within 16-bit rounding of the unfused one, and
+    most BaseConvs actually take the fused route."""
+    from streamyolo_amd.train_engine import TrainPlan, TrainStep
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(TrainPlan, "FUSE_REDUCE", fuse)
+        z, model, x, targets = _setup("nano", "nano_train_2x64x96", golden_dir, backend, "bf16")
+        st = TrainStep(model, graph=False)
+        out = st.step(x, targets)
+        convs = [op for op in st.plan.ops if op.kind == "conv"]
+        res[fuse] = (float(out["total_loss"]), {n: p.grad.detach().clone().double() for n, p in model.named_parameters()},
+                     sum(1 for op in convs if op.gspace), len(convs))
+    assert res[False][2] == 0 and res[True][2] > 0.6 * res[True][3], (res[True][2], res[True][3])
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    worst = max(float((res[True][1][n] - g).norm() / g.norm().clamp_min(1e-30)) for n, g in res[False][1].items())
+    assert worst < 5e-2, "fused vs unfused BatchNorm backward: worst per-parameter relative L2 difference %.3e" % worst
