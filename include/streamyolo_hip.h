@@ -43,7 +43,9 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
        SY_TILE_RS = 16,   /* add to a tile code: register-staged variant instead of the 4-deep LDS-DMA ring */
        SY_TILE_DMA2 = 32, /* add: 2-deep LDS-DMA ring */
        SY_TILE_DMA3 = 48, /* add: 3-deep LDS-DMA ring */
-       SY_TILE_WR = 80    /* add: register-staged pixels + fragment-packed weights loaded straight into VGPRs */ };
+       SY_TILE_WR = 80,   /* add: register-staged pixels + fragment-packed weights loaded straight into VGPRs */
+       SY_TILE_HALO = 112 /* 112..116: 3x3 stride-1 kernel with the input tile + halo resident in LDS (csrc/conv3x3_halo.h; needs
+                             wfrag): 128 ch x 4 rows x 32 px | 256 x 4 | 128 x 8 | 128 x 2 | 64 x 8 */ };
 
 /* gather modes of sy_conv2d */
 enum {
@@ -250,13 +252,6 @@ SY_API int sy_bn_running_update(const sy_bn_running_entry* entries, int n_entrie
 /* a = silu(scale*y + shift) [+ res], y raw conv output; views as in sy_conv2d. */
 SY_API int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res,
                      int ldr, void* out, int ldo, int64_t pixels, int C, int dtype, int nseg, void* stream);
-/* sy_bn_finalize + sy_bn_silu_apply in one launch: every workgroup folds the statistic replicas itself (same order, so the
- * affine is bit-identical to sy_bn_finalize's and to what sy_bn_running_update derives) and applies it; scale / shift /
- * mean / invstd [nseg][C] are also written out for the backward pass.  Running statistics: sy_bn_running_update. */
-SY_API int sy_bn_apply_fused(const float* sum, const float* sqsum, int copies, double count, const float* gamma,
-                             const float* beta, float eps, const void* y, int ldy, const void* res, int ldr, void* out,
-                             int ldo, int64_t pixels, int C, float* scale, float* shift, float* mean, float* invstd,
-                             int dtype, int nseg, void* stream);
 /* Backward of (BN-train + SiLU): reduce pass then apply pass.
  * reduce: sums[r][0][c] += sum dz, sums[r][1][c] += sum dz*xhat over replica r = workgroup % copies,
  * with dz = da * silu'(scale*y+shift). */

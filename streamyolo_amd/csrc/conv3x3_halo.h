@@ -1,0 +1,223 @@
+// conv3x3_halo.h — 3x3 stride-1 convolution (forward and data gradient) with the input tile + halo resident in LDS.
+//
+// Replaces the same reference code as conv_igemm_impl.h (yolox BaseConv's Conv2d of the Bottleneck / head-tower 3x3 layers —
+// exps/model/darknet.py:118-165 via CSPLayer, dfp_pafpn.py:33-81, tal_head.py:55-104 — and cuDNN backward-data) for the layers
+// that carry 55 % of the step's convolution FLOPs.
+//
+// Why a second kernel: the implicit-GEMM kernel walks K = (tap, channel slab) and re-stages the pixel operand for every tap —
+// nine trips L2 -> LDS per input element, 4-8 MFMAs per wave between barriers.  Here a workgroup owns TH image rows x 32
+// pixels of ONE image and, per 64-byte channel slab, parks the (TH + 2) x 34 halo tile in LDS ONCE; the nine taps are nine
+// shifted windows of that tile:
+//   * pixel operand (MFMA B):  L2 -> LDS by LDS-DMA (buffer_load ... lds, no VGPR round trip, out-of-image pixels arrive as
+//     zeros through the buffer bounds check), two halo buffers, ONE barrier per channel slab = 18 x TC x TP MFMAs per wave
+//     between barriers (72-144 instead of 4-8), global -> LDS traffic 1.3-2.1x the tile instead of 9x;
+//   * a pixel tile of the MFMA = 32 consecutive pixels of one image row, so a lane's fragment address is
+//     (row + tap offset) * 64 B: rows of 64 B land lane-linear from the DMA, physical 16-byte slot = logical chunk ^ ((row >> 2) & 3)
+//     (swizzle applied on the SOURCE side of the DMA and on the read; conflict free for every tap offset: the four 4-row
+//     runs of a ds_read_b128 lane group start 0 / 12 / 20 / 24 rows apart = 0 / 3 / 1 / 2 mod 4 row quads);
+//   * weight operand (MFMA A): fragment-packed weights straight from L2 into VGPRs (the SY_TILE_WR layout of
+//     conv_igemm_impl.h), prefetched two taps ahead through a 3-stage register ring, no LDS, no barrier;
+//   * the data gradient is the same kernel reading tap (kh, kw) at window offset (2 - kh, 2 - kw) with the transposed weights.
+// Epilogue: conv_epilogue of conv_igemm_impl.h through the TilePixels mapper (BN statistics, staged coalesced write-out,
+// g-space BatchNorm-backward fusion all included).
+#pragma once
+#include "conv_igemm_impl.h"
+
+namespace sy_conv {
+
+constexpr int kHaloW = 34;            // 32 pixels + 1 halo pixel on each side
+
+template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 3 : 2)) void conv3x3_halo_kernel(ConvArgs p) {
+    constexpr int kThreads = WC * WP * 64;
+    constexpr int NW = WC * WP;
+    constexpr int EPC = T::kEPC;
+    constexpr int ESZ = 16 / EPC;
+    constexpr int BK = 4 * EPC;                  // channels per 64-byte slab
+    constexpr int CT = WC * TC * 32;
+    constexpr int TH = WP * TP;                  // image rows per tile (one 32-pixel row segment per MFMA pixel tile)
+    constexpr int PT = TH * 32;
+    constexpr int HR = (TH + 2) * kHaloW;        // halo rows (pixels) per slab
+    constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;   // DMA wave-instructions (16 rows each) per wave per slab
+    constexpr int BUF = NW * NI * 16 * 64;       // bytes of one halo buffer (rows past HR: zero filler, never read)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+
+    SY_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = sy_uniform(tid >> 6);
+    const int wc = wave / WP;
+    const int wp = wave % WP;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const sy_block_id bid = sy_xcd_block_id();   // x: channel tile (fastest: the channel tiles of a pixel tile share its halo in L2)
+    const int tiles_w = (p.Wo + 31) >> 5, tiles_h = (p.Ho + TH - 1) / TH;
+    const int tw = bid.y % tiles_w, th_ = (bid.y / tiles_w) % tiles_h, n = bid.y / (tiles_w * tiles_h);
+    const int h0 = th_ * TH, w0 = tw * 32;
+
+    // ---- DMA assignment: instruction j = wave + i * NW fills halo rows [16 j, 16 j + 16); lane -> (row, physical 16-byte slot)
+    const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
+    unsigned voff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = (wave + i * NW) * 16 + (lane >> 2);
+        const int hy = r / kHaloW, hx = r - hy * kHaloW;
+        const int h = h0 - 1 + hy, w = w0 - 1 + hx;
+        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+        const bool ok = r < HR && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W && !(p.ablate & 1);
+        voff[i] = ok ? (unsigned)((((long long)n * p.xbs + ((long long)h * p.W + w) * p.ldx) + chunk * EPC) * ESZ) : 0xFFFFFFFFu;
+    }
+    const sy_lds_base_t lds0 = sy_lds_base(smem);
+    // One DMA piece (16 halo rows) of the next slab.  VMEM loads retire IN ORDER, and the weight-fragment stream below is
+    // consumed two taps after it is issued — so a wait for fragments also waits for every DMA piece issued before them.
+    // The pieces are therefore spread over the first NI taps of a slab, one per tap behind that tap's fragment fetch: each
+    // has ~3 taps of MFMA time to land, none ever stalls a fragment wait by more than that, and all of them are in LDS long
+    // before the slab-end barrier.
+    auto issue_piece = [&](auto i_, int buf, int cslab) {
+        constexpr int I = decltype(i_)::value;
+        const unsigned s_x = (unsigned)(cslab * BK * ESZ);
+        sy_glds16_buf_at(bufx, voff[I] == 0xFFFFFFFFu ? 0xFFFFFFFFu : voff[I] + s_x, lds0,
+                         (unsigned)(buf * BUF + (wave + I * NW) * 1024));
+    };
+
+    // ---- weight fragments: [ct][cslab][tap][g][half][32 rows][EPC], 1 KiB per (ct, cslab, tap, g)
+    const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
+    const int ncs = p.Cin / BK;
+    const int ntile32 = (p.Cout + 31) / 32;
+    unsigned foff[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+        const int ct = bid.x * (CT / 32) + wc * TC + t;
+        foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
+    }
+    uint4 fr[3][TC][2];
+    int f_cs = 0, f_tap = 0;                                  // (channel slab, tap) of the next fragment set to fetch
+    auto fetch = [&](auto st_) {
+        constexpr int S = decltype(st_)::value;
+        const unsigned s_f = (unsigned)((f_cs * 9 + f_tap) * 2048);
+        const bool live = f_cs < ncs;
+#pragma unroll
+        for (int t = 0; t < TC; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                fr[S][t][g] = sy_buffer_load16_s(buff, (live && foff[t] != 0xFFFFFFFFu) ? foff[t] + (unsigned)(g * 1024) : 0xFFFFFFFFu, s_f);
+        if (++f_tap == 9) { f_tap = 0; ++f_cs; }
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int u = 0; u < TP; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    // window origin of this lane's pixel of tile u (halo row index of tap offset (0, 0))
+    int rbase[TP];
+#pragma unroll
+    for (int u = 0; u < TP; ++u) rbase[u] = (wp * TP + u) * kHaloW + l31;
+    const bool fwd = (p.mode == SY_CONV_FWD);
+
+    static_assert(NI <= 9, "one DMA piece per tap");
+    sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, 0, 0); });
+    fetch(sy_int<0>());
+    fetch(sy_int<1>());
+    for (int cs = 0; cs < ncs; ++cs) {
+        sy_wait_vmcnt<0>();                       // this wave's part of slab cs has landed (and its fragment prefetches)
+        sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
+        const bool more = cs + 1 < ncs;
+        const unsigned char* const hb = smem + (cs & 1) * BUF;
+        sy_static_for<0, 9>([&](auto tap_) {
+            constexpr int TAP = decltype(tap_)::value;
+            constexpr int KH = TAP / 3, KW = TAP % 3;
+            fetch(sy_int<(TAP + 2) % 3>());       // two taps ahead (its registers held tap TAP - 1)
+            if constexpr (TAP < NI) {
+                if (more) issue_piece(tap_, (cs + 1) & 1, cs + 1);
+            }
+            const int toff = fwd ? (KH * kHaloW + KW) : ((2 - KH) * kHaloW + (2 - KW));
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint4 b[TP];
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    const int row = rbase[u] + toff;
+                    b[u] = *reinterpret_cast<const uint4*>(hb + row * 64 + (((g * 2 + half) ^ ((row >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), fr[TAP % 3][t][g], b[u], acc[t][u]);
+            }
+        });
+    }
+
+    SY_LATE_ARGS(ConvArgs, p);
+    int e_bx = bid.x, e_n = n, e_h0 = h0, e_w0 = w0, e_by = bid.y;
+    SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_n); SY_LAUNDER_INT(e_h0); SY_LAUNDER_INT(e_w0); SY_LAUNDER_INT(e_by);
+    TilePixels mp;
+    mp.n = e_n; mp.h0 = e_h0; mp.w0 = e_w0; mp.Ho = p_late.Ho; mp.Wo = p_late.Wo; mp.rep = e_by;
+    mp.seg = p_late.seg_M > 0 ? (e_n * p_late.HoWo) / p_late.seg_M : 0;
+    // Output pixels of the tile that lie outside the image still see valid input through their window (the implicit-GEMM
+    // kernel's out-of-range rows read zeros): clear them, the BatchNorm statistics of the epilogue sum every accumulator.
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        int n_, rem_;
+        if (!mp.map((wp * TP + u) * 32 + l31, n_, rem_)) {
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+        }
+    }
+    conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+}
+
+template <typename T, int WC, int WP, int TC, int TP>
+int launch_halo(const ConvArgs& a_in, void* stream) {
+    constexpr int NW = WC * WP, CT = WC * TC * 32, TH = WP * TP, PT = TH * 32;
+    constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
+    ConvArgs a = a_in;
+    a.s2_classes = 0;
+    // 3x3, stride 1, "same" padding, whole channel slabs, 32-bit addressable input, fragment-packed weights
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
+    if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
+    constexpr size_t smem_k = 2 * (size_t)BUF;
+    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 12 + (size_t)32 * CT;
+    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= 48 * 1024);
+    constexpr size_t smem_s = (size_t)WP * CT * 8;            // statistics scratch of the un-staged epilogue
+    constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
+    if (a.gs_count > 0) {
+        const bool staged = can_stage && !a.y_f32 && a.res == nullptr && (a.Cout & 3) == 0 && (a.ldy & 7) == 0 &&
+                            (reinterpret_cast<unsigned long long>(a.y) & 15ull) == 0 && a.epilogue != SY_EPI_DECODE &&
+                            a.stat_sum == nullptr;
+        if (!staged) return SY_ERR_UNSUPPORTED;
+    }
+    const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
+    dim3 grid((a.Cout + CT - 1) / CT, tiles, 1);
+#ifndef SY_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return SY_ERR_LAUNCH;
+        attr_done = true;
+    }
+#endif
+    SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+// tile codes 112..116 of sy_conv_desc::tile (SY_TILE_HALO + k)
+template <typename T>
+int launch_halo_typed(const ConvArgs& a, void* stream) {
+    switch (a.tile) {
+        case 112: return launch_halo<T, 2, 2, 2, 2>(a, stream);     // 128 ch x ( 4 rows x 32 px)
+        case 113: return launch_halo<T, 4, 1, 2, 4>(a, stream);     // 256 ch x ( 4 rows x 32 px)
+        case 114: return launch_halo<T, 2, 2, 2, 4>(a, stream);     // 128 ch x ( 8 rows x 32 px)
+        case 115: return launch_halo<T, 4, 1, 1, 2>(a, stream);     // 128 ch x ( 2 rows x 32 px)
+        case 116: return launch_halo<T, 1, 4, 2, 2>(a, stream);     //  64 ch x ( 8 rows x 32 px)
+        default: return SY_ERR_ARG;
+    }
+}
+
+}  // namespace sy_conv

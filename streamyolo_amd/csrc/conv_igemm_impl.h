@@ -81,8 +81,45 @@ constexpr int kPitchRS = 80;        // register-staged: 64 B of K + 16 B pad per
 
 static __device__ uint4 g_zero16[4] = {};  // DMA generic loader: source of every predicated-off 16-byte chunk
 
-template <typename T, int WC, int WP, int TC, int TP, typename Args>
-__device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int bz, f32x16 (&acc)[TC][TP],
+// Pixel mapping of a workgroup's tile for the epilogue: local pixel lp in [0, PT) -> (image n, pixel index `rem` inside the
+// image) of the OUTPUT tensor; `seg` = statistics segment of the tile, `rep` = tile index used to pick a replica array.
+struct LinearPixels {             // implicit-GEMM kernel: PT consecutive pixels of the flattened (n, ho, wo) range
+    int m0, m_end, cls_hw, Wc, Wo, cls_ph, cls_pw, s2, seg, rep;
+    template <typename Args> __device__ __forceinline__ LinearPixels(const Args& p, int by, int bz, int PT) {
+        cls_ph = 0; cls_pw = 0; Wc = p.Wo; Wo = p.Wo; s2 = p.s2_classes;
+        int Hc = p.Ho, cls_M = p.M;
+        if (p.s2_classes) {
+            cls_ph = bz >> 1; cls_pw = bz & 1;
+            Hc = (p.Ho - cls_ph + 1) >> 1; Wc = (p.Wo - cls_pw + 1) >> 1;
+            cls_M = p.N * Hc * Wc;
+        }
+        cls_hw = Hc * Wc;
+        m_end = p.seg_M > 0 ? (bz + 1) * p.seg_M : cls_M;
+        m0 = (p.s2_classes ? 0 : bz * p.seg_M) + by * PT;
+        seg = bz; rep = by;
+    }
+    __device__ __forceinline__ bool map(int lp, int& n, int& rem) const {
+        const int m = m0 + lp;
+        if (m >= m_end) { n = 0; rem = 0; return false; }
+        n = m / cls_hw;
+        rem = m - n * cls_hw;
+        if (s2) { const int i2 = rem / Wc; rem = (2 * i2 + cls_ph) * Wo + 2 * (rem - i2 * Wc) + cls_pw; }
+        return true;
+    }
+};
+struct TilePixels {               // halo kernel: TH rows of 32 consecutive pixels of one image, origin (h0, w0)
+    int n, h0, w0, Ho, Wo, seg, rep;
+    __device__ __forceinline__ bool map(int lp, int& n_, int& rem) const {
+        const int h = h0 + (lp >> 5), w = w0 + (lp & 31);
+        n_ = n;
+        if (h >= Ho || w >= Wo) { rem = 0; return false; }
+        rem = h * Wo + w;
+        return true;
+    }
+};
+
+template <typename T, int WC, int WP, int TC, int TP, typename Args, typename Map>
+__device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int bx, f32x16 (&acc)[TC][TP],
                                               unsigned char* smem, int tid);
 
 // STG: staging strategy — 1 = register-staged; 2 / 3 / 4 (0 = 4) = LDS-DMA ring of that depth (depth-1 slabs of
@@ -550,13 +587,14 @@ __global__ __launch_bounds__(WC * WP * 64, ((TC * TP <= 4 && !(STG == 6 && TC * 
     SY_LATE_ARGS(ConvArgs, p);
     int e_bx = bid.x, e_by = bid.y, e_bz = bid.z;
     SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_by); SY_LAUNDER_INT(e_bz);
-    conv_epilogue<T, WC, WP, TC, TP>(p_late, e_bx, e_by, e_bz, acc, smem, tid);
+    const LinearPixels mp(p_late, e_by, e_bz, PT);
+    conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
 }
 
 // The epilogue as a separate (inlined) function: its only inputs are the late argument view, the logical tile and
 // the accumulators, so none of the prologue's uniforms can be referenced (and kept alive) by accident.
-template <typename T, int WC, int WP, int TC, int TP, typename Args>
-__device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int bz, f32x16 (&acc)[TC][TP],
+template <typename T, int WC, int WP, int TC, int TP, typename Args, typename Map>
+__device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int bx, f32x16 (&acc)[TC][TP],
                                               unsigned char* smem, int tid) {
     typedef typename T::elem elem;
     constexpr int kThreads = WC * WP * 64;
@@ -571,16 +609,6 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
     const int l31 = lane & 31;
     const int half = lane >> 5;
     const int c0 = bx * CT;
-    int cls_ph = 0, cls_pw = 0, Hc = p.Ho, Wc = p.Wo, cls_M = p.M;
-    if (p.s2_classes) {
-        cls_ph = bz >> 1; cls_pw = bz & 1;
-        Hc = (p.Ho - cls_ph + 1) >> 1; Wc = (p.Wo - cls_pw + 1) >> 1;
-        cls_M = p.N * Hc * Wc;
-    }
-    const int cls_hw = Hc * Wc;
-    const int m_end = p.seg_M > 0 ? (bz + 1) * p.seg_M : cls_M;
-    const int m0 = (p.s2_classes ? 0 : bz * p.seg_M) + by * PT;
-    struct { int x, y, z; } bid = {bx, by, bz};
     const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
                         (p.res == nullptr || (p.ldr & 3) == 0);
     const bool want_stats = (p.stat_sum != nullptr);
@@ -591,7 +619,8 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
     // addresses (the K loop is over, its LDS is free).
     constexpr int kStagePitch = CT * 2 + 16;                    // bytes per staged pixel row (+16: bank spread)
     constexpr int kStatBytes = EpiLds<WP, CT>::kStatBytes;      // BN-statistics scratch [WP][CT][2] floats / g-space sums [2][2][CT]
-    constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 12 + kStatBytes <= 48 * 1024);
+    constexpr int kGsAffBytes = 2 * 4 * CT * 4;                 // g-space: scale | shift | mean | invstd of the tile's channels, 2 segments
+    constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 12 + kStatBytes + kGsAffBytes <= 48 * 1024);
     // (+= outputs — data gradients of activations with several consumers — are staged too: the write-out pass reads
     //  the old row chunk, adds in fp32 and stores, all coalesced; the staged value was already rounded to 16 bits,
     //  one extra rounding the gradient path tolerates.  Residual adds keep the direct path: single rounding.)
@@ -602,9 +631,24 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
     int* const stg_lin = reinterpret_cast<int*>(smem + kStatBytes + PT * kStagePitch + PT * 8);      // [PT] n * Ho*Wo + pixel
     const bool gs_on = kCanStage && stage_out && p.gs_count > 0 && !want_stats;
     if (want_stats || stage_out) __syncthreads();               // every wave is done with the operand tiles
+    float* const gaff = reinterpret_cast<float*>(smem + kStatBytes + PT * kStagePitch + PT * 12);    // [2 seg][4][CT]
     if (gs_on) {                                                // g-space sums [2 segments][2 kinds][CT], zeroed before the barrier below
         float* redg = reinterpret_cast<float*>(smem);
         for (int i = tid; i < 4 * CT; i += kThreads) redg[i] = 0.0f;
+        // ... and the BatchNorm affine of the tile's channels parked in LDS (the write-out pass reads it per item)
+        for (int i = tid; i < 8 * CT; i += kThreads) {
+            const int cl = i % CT, arr = (i / CT) & 3, sg = i / (4 * CT);
+            const int co = c0 + cl;
+            float v = 0.0f;
+            if (sg == 0 || p.gs_seg_M > 0)
+                for (int r = 0; r < p.gs_count; ++r) {
+                    if (co < p.gs[r].c0 || co >= p.gs[r].c1) continue;
+                    const int Cg = p.gs[r].c1 - p.gs[r].c0;
+                    const float* base = arr == 0 ? p.gs[r].scale : arr == 1 ? p.gs[r].shift : arr == 2 ? p.gs[r].mean : p.gs[r].invstd;
+                    v = base[sg * Cg + co - p.gs[r].c0];
+                }
+            gaff[i] = v;
+        }
     }
     // ---- lean path for staged outputs (every training forward / first-write data gradient / eval conv without a
     //      residual): the mode, affine and statistics decisions are taken ONCE here, not per element — the general
@@ -620,13 +664,9 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
                 if (wc == 0 && half == 0) {                         // output element offset of every tile pixel, once
 #pragma unroll
                     for (int u = 0; u < TP; ++u) {
-                        const int m = m0 + (wp * TP + u) * 32 + l31;
                         long long off = -1;
-                        int lin = -1;
-                        if (m < m_end) {
-                            const int n = m / cls_hw;
-                            int rem = m - n * cls_hw;
-                            if (p.s2_classes) { const int i2 = rem / Wc; rem = (2 * i2 + cls_ph) * p.Wo + 2 * (rem - i2 * Wc) + cls_pw; }
+                        int lin = -1, n, rem;
+                        if (mp.map((wp * TP + u) * 32 + l31, n, rem)) {
                             off = (long long)n * p.ybs + (long long)rem * p.ldy;
                             lin = n * p.HoWo + rem;
                         }
@@ -701,12 +741,8 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
         }
 #pragma unroll
         for (int u = 0; u < TP; ++u) {
-            const int m = m0 + (wp * TP + u) * 32 + l31;
-            const bool m_ok = m < m_end;
-            const int mm = m_ok ? m : 0;
-            const int n = mm / cls_hw;
-            int rem = mm - n * cls_hw;
-            if (p.s2_classes) { const int i2 = rem / Wc; rem = (2 * i2 + cls_ph) * p.Wo + 2 * (rem - i2 * Wc) + cls_pw; }
+            int n, rem;
+            const bool m_ok = mp.map((wp * TP + u) * 32 + l31, n, rem);
             const long long yoff = (long long)n * p.ybs + (long long)rem * p.ldy;
             const long long roff = (long long)n * p.rbs + (long long)rem * p.ldr;
             int gy = 0, gx = 0;
@@ -828,45 +864,112 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
     if (kCanStage && stage_out) {
         constexpr int CPR = CT / 8;                             // 16-byte chunks per staged pixel row
         static_assert(kThreads % CPR == 0, "a thread's channel chunk is fixed across its write-out items");
-        // g-space (BatchNorm-backward fusion): this thread's channel chunk belongs to at most one range
-        int gr = -1;
-        float gs0[2][8], gs1[2][8];
         if (gs_on) {
-            const int co_t = c0 + (tid % CPR) * 8;
+            // ---- g-space write-out (BatchNorm-backward fusion).  The staged chunk holds d(loss)/d(activation) of 8 channels
+            //      of one pixel; the BatchNorm behind that activation needs g = da * silu'(z) (z = scale*raw + shift) and,
+            //      per channel, sum g and sum g * xhat over the pixels.  All loads of a thread's items (raw chunk, old
+            //      gradient for +=) are issued first, then the arithmetic runs: one memory round trip per workgroup.
+            constexpr int ITEMS = (PT * CPR + kThreads - 1) / kThreads;
+            const int cl0 = (tid % CPR) * 8;
+            const int co = c0 + cl0;
+            int gr = -1;
             for (int r = 0; r < p.gs_count; ++r)
-                if (co_t >= p.gs[r].c0 && co_t < p.gs[r].c1) gr = r;
+                if (co >= p.gs[r].c0 && co < p.gs[r].c1) gr = r;
+            const unsigned char* const graw = gr >= 0 ? p.gs[gr].raw : nullptr;
+            const int gld = gr >= 0 ? p.gs[gr].ldraw : 0, gcc = gr >= 0 ? co - p.gs[gr].c0 : 0;
+            uint4 rv[ITEMS], ov[ITEMS];
+            long long offs[ITEMS];
+            int segs[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int i = tid + it * kThreads;
+                const int px = i / CPR;
+                long long off = -1;
+                int lin = 0;
+                if (i < PT * CPR && co < p.Cout) { off = stg_off[px]; lin = stg_lin[px]; }
+                offs[it] = off;
+                segs[it] = (p.gs_seg_M > 0 && lin >= p.gs_seg_M) ? 1 : 0;
+                rv[it] = make_uint4(0u, 0u, 0u, 0u);
+                ov[it] = make_uint4(0u, 0u, 0u, 0u);
+                if (off >= 0) {
+                    if (gr >= 0) rv[it] = *reinterpret_cast<const uint4*>(graw + ((long long)lin * gld + gcc) * 2);
+                    if (p.accumulate) ov[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<elem*>(p.y) + off + co);
+                }
+            }
+            float gs0[2][8], gs1[2][8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { gs0[0][j] = 0.0f; gs0[1][j] = 0.0f; gs1[0][j] = 0.0f; gs1[1][j] = 0.0f; }
-        }
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                if (offs[it] < 0) continue;
+                const int px = (tid + it * kThreads) / CPR;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + px * kStagePitch + (tid % CPR) * 16);
+                elem ev[8], er[8], eo[8];
+                __builtin_memcpy(ev, &v, 16);
+                __builtin_memcpy(er, &rv[it], 16);
+                __builtin_memcpy(eo, &ov[it], 16);
+                float g8[8];
+                if (gr >= 0) {
+                    const float* af = gaff + segs[it] * 4 * CT + cl0;
+                    float sc[8], sh[8], mu[8], is[8];
+                    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(af);
+                    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(af + 4);
+                    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(af + CT);
+                    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(af + CT + 4);
+                    *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(af + 2 * CT);
+                    *reinterpret_cast<float4*>(mu + 4) = *reinterpret_cast<const float4*>(af + 2 * CT + 4);
+                    *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(af + 3 * CT);
+                    *reinterpret_cast<float4*>(is + 4) = *reinterpret_cast<const float4*>(af + 3 * CT + 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float yy = T::to_f32(er[j]);
+                        const float g = T::to_f32(ev[j]) * sy_silu_grad_fast(yy * sc[j] + sh[j]);
+                        const float gx = g * ((yy - mu[j]) * is[j]);
+                        if (segs[it]) { gs0[1][j] += g; gs1[1][j] += gx; } else { gs0[0][j] += g; gs1[0][j] += gx; }
+                        g8[j] = g;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g8[j] = T::to_f32(ev[j]);
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g8[j] += T::to_f32(eo[j]);
+                }
+                *reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + offs[it] + co) =
+                    make_uint4(T::pack2(g8[0], g8[1]), T::pack2(g8[2], g8[3]), T::pack2(g8[4], g8[5]), T::pack2(g8[6], g8[7]));
+            }
+            // fold the threads that share a channel chunk through LDS, then one global atomic per (segment, kind, channel)
+            float* redg = reinterpret_cast<float*>(smem);       // [2 seg][2 kind][CT]
+            if (gr >= 0) {
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (gs0[sg][j] != 0.0f) atomicAdd(&redg[(sg * 2 + 0) * CT + cl0 + j], gs0[sg][j]);
+                        if (gs1[sg][j] != 0.0f) atomicAdd(&redg[(sg * 2 + 1) * CT + cl0 + j], gs1[sg][j]);
+                    }
+            }
+            __syncthreads();
+            for (int i = tid; i < 4 * CT; i += kThreads) {
+                const float val = redg[i];
+                if (val == 0.0f) continue;
+                const int sg = i / (2 * CT), kind = (i / CT) & 1, cl = i % CT;
+                const int cch = c0 + cl;
+                for (int r = 0; r < p.gs_count; ++r) {
+                    if (cch < p.gs[r].c0 || cch >= p.gs[r].c1) continue;
+                    const int Cg = p.gs[r].c1 - p.gs[r].c0;
+                    const int copy = (int)((unsigned)mp.rep % (unsigned)p.gs[r].copies);
+                    atomicAdd(p.gs[r].sums + ((long long)(sg * p.gs[r].copies + copy) * 2 + kind) * Cg + (cch - p.gs[r].c0), val);
+                }
+            }
+        } else
         for (int i = tid; i < PT * CPR; i += kThreads) {
             const int px = i / CPR, ck = i - px * CPR;
             const long long off = stg_off[px];
             const int co = c0 + ck * 8;
             if (off < 0 || co >= p.Cout) continue;
             uint4 v = *reinterpret_cast<const uint4*>(stg + px * kStagePitch + ck * 16);
-            if (gs_on && gr >= 0) {
-                // v holds d(loss)/d(activation) of 8 channels of one pixel; the BatchNorm behind that activation needs
-                // g = da * silu'(z) and its sums over the pixels: sum g, sum g * xhat (z = scale*raw + shift)
-                const int lin = stg_lin[px];
-                const int seg = (p.gs_seg_M > 0 && lin >= p.gs_seg_M) ? 1 : 0;
-                const int Cg = p.gs[gr].c1 - p.gs[gr].c0, cc = co - p.gs[gr].c0;
-                const uint4 rv = *reinterpret_cast<const uint4*>(p.gs[gr].raw + ((long long)lin * p.gs[gr].ldraw + cc) * 2);
-                elem er[8], ev[8];
-                __builtin_memcpy(er, &rv, 16);
-                __builtin_memcpy(ev, &v, 16);
-                const float* a_sc = p.gs[gr].scale + seg * Cg + cc; const float* a_sh = p.gs[gr].shift + seg * Cg + cc;
-                const float* a_mu = p.gs[gr].mean + seg * Cg + cc;  const float* a_is = p.gs[gr].invstd + seg * Cg + cc;
-                float g8[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float yy = T::to_f32(er[j]);
-                    const float g = T::to_f32(ev[j]) * sy_silu_grad(yy * a_sc[j] + a_sh[j]);
-                    const float gx = g * ((yy - a_mu[j]) * a_is[j]);
-                    if (seg) { gs0[1][j] += g; gs1[1][j] += gx; } else { gs0[0][j] += g; gs1[0][j] += gx; }
-                    g8[j] = g;
-                }
-                v = make_uint4(T::pack2(g8[0], g8[1]), T::pack2(g8[2], g8[3]), T::pack2(g8[4], g8[5]), T::pack2(g8[6], g8[7]));
-            }
             uint4* const dst = reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + off + co);
             if (p.accumulate) {
                 const uint4 o = *dst;
@@ -881,37 +984,10 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, int bx, int by, int
             }
             *dst = v;
         }
-        if (gs_on) {
-            // fold the threads that share a channel chunk through LDS, then one global atomic per (segment, kind, channel)
-            float* redg = reinterpret_cast<float*>(smem);       // [2 seg][2 kind][CT]
-            if (gr >= 0) {
-                const int cl = (tid % CPR) * 8;
-#pragma unroll
-                for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (gs0[sg][j] != 0.0f) atomicAdd(&redg[(sg * 2 + 0) * CT + cl + j], gs0[sg][j]);
-                        if (gs1[sg][j] != 0.0f) atomicAdd(&redg[(sg * 2 + 1) * CT + cl + j], gs1[sg][j]);
-                    }
-            }
-            __syncthreads();
-            for (int i = tid; i < 4 * CT; i += kThreads) {
-                const float val = redg[i];
-                if (val == 0.0f) continue;
-                const int sg = i / (2 * CT), kind = (i / CT) & 1, cl = i % CT;
-                const int co = c0 + cl;
-                for (int r = 0; r < p.gs_count; ++r) {
-                    if (co < p.gs[r].c0 || co >= p.gs[r].c1) continue;
-                    const int Cg = p.gs[r].c1 - p.gs[r].c0;
-                    const int copy = (int)((unsigned)bid.y % (unsigned)p.gs[r].copies);
-                    atomicAdd(p.gs[r].sums + ((long long)(sg * p.gs[r].copies + copy) * 2 + kind) * Cg + (co - p.gs[r].c0), val);
-                }
-            }
-        }
     }
     if (want_stats) {
         const float* red = reinterpret_cast<const float*>(smem);
-        const int copy = bid.z * p.stat_copies + (int)((unsigned)bid.y % (unsigned)p.stat_copies);
+        const int copy = mp.seg * p.stat_copies + (int)((unsigned)mp.rep % (unsigned)p.stat_copies);
         for (int cl = tid; cl < CT; cl += kThreads) {
             const int co = c0 + cl;
             if (co >= p.Cout) continue;
@@ -937,7 +1013,7 @@ int launch_one(const ConvArgs& a, void* stream) {
                               : (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
                                          : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
     // epilogue staging of 16-bit outputs (see the kernel): statistics scratch + [PT][CT*2+16] + [PT] offsets
-    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 12;
+    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 12 + (size_t)32 * CT;
     constexpr bool can_stage = (T::kEPC == 8 && smem_e <= 48 * 1024);
     constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : smem_k;
     if (a.gs_count > 0) {
@@ -975,8 +1051,11 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
     }
 }
 
+template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 112..116)
+
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
+    if (a.tile >= 112 && a.tile <= 116) return launch_halo_typed<T>(a, stream);
     // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide
     // layers use 256 ch x 256 px (8 waves, 128 accumulator registers per lane).  Layers too small to give
     // every CU a large tile fall back to 128 x 128 (4 waves); narrow layers trade channels for pixels.

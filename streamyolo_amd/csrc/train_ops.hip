@@ -399,68 +399,6 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
     }
 }
 
-// Batch statistics -> affine AND a = silu(scale*y + shift) [+ res] in ONE launch (sy_bn_apply_fused): every workgroup folds
-// the statistic replicas of all C channels itself — in bn_finalize_kernel's order (8 float partial sums over replicas
-// k = rg, rg + 8, ..., then a double sum over rg), so the affine is bit-identical to the separate finalize launch and to
-// what bn_running_update_kernel derives — parks scale / shift in LDS, and workgroup 0 of each segment also writes
-// scale / shift / mean / invstd for the backward pass.  128 finalize launches per l step disappear.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void bn_apply_fused_kernel(const float* sum, const float* sqsum, int copies, double count,
-                                                                const float* gamma, const float* beta, float eps,
-                                                                const typename T::elem* y, int ldy,
-                                                                const typename T::elem* res, int ldr, typename T::elem* out,
-                                                                int ldo, long long pixels, int C, float* scale_out,
-                                                                float* shift_out, float* mean_out, float* invstd_out) {
-    __shared__ float s_aff[2 * 1024];
-    {   // segment blockIdx.y
-        const long long so = (long long)blockIdx.y * copies * C, ao = (long long)blockIdx.y * C, ro = (long long)blockIdx.y * pixels;
-        sum += so; sqsum += so; scale_out += ao; shift_out += ao; mean_out += ao; invstd_out += ao;
-        y += ro * ldy; out += ro * ldo;
-        if (res != nullptr) res += ro * ldr;
-    }
-    for (int c = threadIdx.x; c < C; c += kBlock) {
-        double ds = 0.0, dq = 0.0;
-        for (int rg = 0; rg < 8; ++rg) {
-            float s = 0.0f, q = 0.0f;
-            for (int k = rg; k < copies; k += 8) { s += sum[(long long)k * C + c]; q += sqsum[(long long)k * C + c]; }
-            ds += (double)s; dq += (double)q;
-        }
-        const double mean = ds / count;
-        double var = dq / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        const float sh = beta[c] - (float)mean * sc;
-        s_aff[c] = sc;
-        s_aff[C + c] = sh;
-        if (blockIdx.x == 0) { scale_out[c] = sc; shift_out[c] = sh; mean_out[c] = (float)mean; invstd_out[c] = invstd; }
-    }
-    __syncthreads();
-    const int cpp = C / T::kEPC;
-    const int cc = threadIdx.x % cpp;
-    const int c0 = cc * T::kEPC;
-    const int rows = kBlock / cpp;
-    if ((int)threadIdx.x >= rows * cpp) return;
-    float sc[T::kEPC], sh[T::kEPC];
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) { sc[j] = s_aff[c0 + j]; sh[j] = s_aff[C + c0 + j]; }
-    for (long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp; pix < pixels; pix += (long long)gridDim.x * rows) {
-        Chunk<T> v = Chunk<T>::load(y + pix * ldy + c0);
-        Chunk<T> o;
-        float r[T::kEPC];
-#pragma unroll
-        for (int j = 0; j < T::kEPC; ++j) r[j] = 0.0f;
-        if (res != nullptr) {
-            Chunk<T> rv = Chunk<T>::load(res + pix * ldr + c0);
-#pragma unroll
-            for (int j = 0; j < T::kEPC; ++j) r[j] = T::to_f32(rv.e[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
-        o.store(out + pix * ldo + c0);
-    }
-}
-
 // reduce: sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat.  Thread = (pixel row, channel chunk); register
 // partials, LDS tree over the rows of the workgroup, then ONE atomic per channel per workgroup.
 template <typename T>
@@ -690,24 +628,6 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
-}
-
-extern "C" int sy_bn_apply_fused(const float* sum, const float* sqsum, int copies, double count, const float* gamma,
-                                 const float* beta, float eps, const void* y, int ldy, const void* res, int ldr, void* out,
-                                 int ldo, int64_t pixels, int C, float* scale, float* shift, float* mean, float* invstd,
-                                 int dtype, int nseg, void* stream) {
-    if (sum == nullptr || sqsum == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || out == nullptr ||
-        scale == nullptr || shift == nullptr || mean == nullptr || invstd == nullptr || pixels <= 0 || C <= 0 ||
-        copies <= 0 || count <= 0.0 || nseg < 1)
-        return SY_ERR_ARG;
-    const int e = epc_of(dtype);
-    if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
-    if (!chunk_rows_ok(C, e) || C > 1024) return SY_ERR_UNSUPPORTED;
-    static const int cap_apply = env_cap("SY_BN_APPLY_BLOCKS", 4096);
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_apply_fused_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0,
-                                       stream, sum, sqsum, copies, count, gamma, beta, eps, (const typename T::elem*)y, ldy,
-                                       (const typename T::elem*)res, ldr, (typename T::elem*)out, ldo, (long long)pixels, C,
-                                       scale, shift, mean, invstd));
 }
 
 extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,

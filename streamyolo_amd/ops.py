@@ -319,16 +319,6 @@ def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums, nseg=1):
                                            stream_of(y.buf)), "sy_bn_silu_bwd_reduce")
 
 
-def bn_apply_fused(ssum, ssq, count, gamma, beta, eps, y, out, scale, shift, mean, invstd, res=None, nseg=1):
-    """sy_bn_finalize + sy_bn_silu_apply in one launch (count = elements per channel PER SEGMENT)."""
-    C_ = gamma.numel()
-    check(_lib.lib().sy_bn_apply_fused(ssum.data_ptr(), ssq.data_ptr(), ssum.numel() // (nseg * C_), float(count),
-                                       gamma.data_ptr(), beta.data_ptr(), float(eps), y.ptr(), y.ld,
-                                       None if res is None else res.ptr(), 0 if res is None else res.ld, out.ptr(), out.ld,
-                                       y.pixels // nseg, y.C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                                       invstd.data_ptr(), y.dtype, nseg, stream_of(y.buf)), "sy_bn_apply_fused")
-
-
 def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None, nseg=1,
                       dres=None, dres_accumulate=False, g_space=False):
     """dres: gradient View of the residual input (y = silu(bn(conv)) + res): written (or accumulated) with da in this pass.
@@ -414,6 +404,8 @@ _TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging s
     "c32": [21, 23, 39, 85, 87],
 }
 _tile_cache = {}
+import os as _os
+HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "112,113,114,115,116").split(",") if t]
 
 
 def autotune_enabled(device):
@@ -461,7 +453,10 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     stats = (torch.zeros(32 * Cout, device=device), torch.zeros(32 * Cout, device=device)) if with_stats else None
     from .model.packing import pack_conv_weight_frag
     wf = pack_conv_weight_frag(w, k)
-    cands = _TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide" if Cout < 256 else "wide256"]
+    cands = list(_TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide" if Cout < 256 else "wide256"])
+    if k == 3 and stride == 1 and wf is not None and HALO_TILES:
+        # 3x3 stride-1 layers: the halo-resident kernel (csrc/conv3x3_halo.h), tiles of 64 / 128 / 256 channels
+        cands += [t for t in HALO_TILES if not (t == 113 and Cout < 256) and not (t == 116 and Cout > 64)]
     best, best_t = 0, float("inf")
     for t in cands:
         if t >= TILE_WR and wf is None:

@@ -401,10 +401,12 @@ class TrainPlan:
         u_sum, u_sq, _, (scale, shift, mean, invstd) = a.unit
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
                    wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
-        # batch statistics -> affine -> BN + SiLU (+ residual) in ONE launch; running statistics: one batched launch at
-        # the end of the pass (sy_bn_running_update)
-        ops.bn_apply_fused(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, raw2, y2, scale, shift, mean, invstd,
-                           res=None if a.res is None else a.res.pair(), nseg=2)
+        # (finalize folded into every workgroup of the apply pass was measured at 5.5 ms per l step against 0.8 + 2.25 ms for
+        #  the two launches — 64 x C replica loads per workgroup, profiles/r02/b_* — so the ~5 us finalize launch stays)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        ops.bn_finalize(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, mom, None, None, scale, shift, mean, invstd,
+                        nseg=2)
+        ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
 
     # ---- launch programs ------------------------------------------------------------------------------------
     # Step 1 runs the Python wrappers directly (kernel variants get tuned).  Step 2 runs them again under
@@ -508,8 +510,10 @@ class TrainPlan:
             scale, shift, mean, invstd = op.aff
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
-            ops.bn_apply_fused(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, op.yraw, op.y,
-                               scale, shift, mean, invstd, res=op.res)
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
+                            None, None, scale, shift, mean, invstd)
+            ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
         elif k == "resize":
             ops.resize_nearest(op.src, op.dst)
         elif k == "spp":
@@ -854,7 +858,7 @@ class TrainPlan:
         """Per-op-kind kernel time (ms / step) with HIP events on the launch stream (bench.py roofline).
         detail=True: per (kind, shape) rows [(kind, shape, launches / step, ms / step, flops / step)] instead."""
         evs = []
-        real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply", "bn_apply_fused",
+        real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply",
                                              "bn_silu_bwd_reduce", "bn_silu_bwd_apply", "resize_nearest",
                                              "resize_nearest_bwd", "spp_pool", "spp_pool_bwd", "view_copy", "focus_pack")}
 

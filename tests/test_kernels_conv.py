@@ -172,3 +172,56 @@ def test_wgrad_many_splits_fold(backend):
     dw = torch.zeros(cout, cin, device=backend)
     ops.conv2d_wgrad(xv, dv, dw, 1, 1, workspace=ws, tile=3, target_blocks=4096)
     assert _rel(dw.cpu(), ref) < 1e-4
+
+
+@pytest.mark.parametrize("tile", [112, 113, 114, 115, 116])
+@pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "fwd"), ("bf16", "dgrad"), ("fp32", "dgrad")])
+def test_conv3x3_halo_kernel(backend, tile, dt, mode):
+    """csrc/conv3x3_halo.h (tile codes 112..116): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
+    gradient (first write, accumulate, channel-slice output), on an image whose width and height are ragged against the
+    32-pixel / TH-row tiles, with Cout ragged against the channel tile; against torch and against the implicit-GEMM kernel."""
+    g = torch.Generator().manual_seed(tile + len(mode))
+    N, cin, cout, H, W = 2, 64, 72, 11, 37
+    code = ops.dtype_code(dt)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt).requires_grad_(True)
+    w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, dt)
+    y = F.conv2d(x, w, None, 1, 1)
+    xv = View.alloc(N, H, W, cin + 32, dt, backend, zero=True).slice(32, cin); xv.set_nchw(x.detach().to(backend))
+    if mode == "fwd":
+        wp = pack_conv_weight(w, code).to(backend)
+        wf = pack_conv_weight_frag(wp, 3)
+        yv = View.alloc(N, H, W, cout + 8, dt, backend, zero=True).slice(8, cout)
+        ssum = torch.zeros(2 * 4 * cout, device=backend); ssq = torch.zeros(2 * 4 * cout, device=backend)
+        ops.conv2d(xv, wp, yv, 3, 1, stats=(ssum, ssq), tile=tile, wfrag=wf, segments=2)
+        assert _rel(yv.nchw().cpu(), y.detach()) < TOL[dt]
+        assert float(yv.buf[..., :8].float().abs().max()) == 0.0
+        for s_ in range(2):                                           # one statistics segment per frame
+            ys = y.detach()[s_:s_ + 1]
+            assert _rel(ssq.view(2, 4, cout)[s_].sum(0).cpu(), (ys ** 2).sum((0, 2, 3))) < 1e-3
+            assert float((ssum.view(2, 4, cout)[s_].sum(0).cpu() - ys.sum((0, 2, 3))).abs().max()) < 1e-2 * float(ys.abs().sum((0, 2, 3)).max())
+        # eval-style epilogue: affine + SiLU + residual
+        scale, shift = (torch.rand(cout, generator=g) + 0.5), torch.randn(cout, generator=g) * 0.3
+        res = _q(torch.randn(N, cout, H, W, generator=g), dt)
+        rv = View.alloc(N, H, W, cout, dt, backend); rv.set_nchw(res.to(backend))
+        ops.conv2d(xv, wp, yv, 3, 1, scale.to(backend), shift.to(backend), res=rv, epilogue=ops.EPI_SILU, tile=tile, wfrag=wf)
+        ref = F.silu(y.detach() * scale[None, :, None, None] + shift[None, :, None, None]) + res
+        assert _rel(yv.nchw().cpu(), ref) < TOL[dt]
+    else:
+        dy = _q(torch.randn(y.shape, generator=g), dt)
+        y.backward(dy)
+        dyv = View.alloc(N, H, W, cout + 24, dt, backend, zero=True).slice(24, cout)
+        # the halo kernel walks whole 64-byte channel slabs of its INPUT: pad dy's channels (zero weights) to a slab multiple
+        cpad = -(-cout // (32 if dt != "fp32" else 16)) * (32 if dt != "fp32" else 16)
+        dyp = View.alloc(N, H, W, cpad, dt, backend, zero=True)
+        dyp.slice(0, cout).set_nchw(dy.to(backend))
+        wt = pack_conv_weight(torch.cat([w, w.new_zeros(cpad - cout, cin, 3, 3)], 0), code, transpose=True).to(backend)
+        wf = pack_conv_weight_frag(wt, 3)
+        dxv = View.alloc(N, H, W, cin, dt, backend, zero=True)
+        ops.conv2d(dyp, wt, dxv, 3, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf)
+        assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
+        ops.conv2d(dyp, wt, dxv, 3, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf, accumulate=True)
+        assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]
+        ref = View.alloc(N, H, W, cin, dt, backend, zero=True)
+        ops.conv2d(dyp, wt, ref, 3, 1, mode=ops.CONV_DGRAD, tile=19)  # implicit-GEMM kernel, same operands
+        ops.conv2d(dyp, wt, dxv, 3, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf)
+        assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)

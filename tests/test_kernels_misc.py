@@ -392,33 +392,6 @@ def test_decode_is_invertible(backend):
         assert (inv - raw[..., :5]).abs().max() < 2e-4 * max(1.0, float(raw[..., :5].abs().max()))
 
 
-@pytest.mark.parametrize("dt", ["bf16", "fp32"])
-@pytest.mark.parametrize("nseg", [1, 2])
-def test_bn_apply_fused_is_finalize_then_apply(backend, dt, nseg):
-    """sy_bn_apply_fused (statistics -> affine -> BN + SiLU [+ residual] in one launch) against the two launches it
-    replaces: bit-identical affine / mean / invstd (same replica fold order) and bit-identical activations."""
-    g = torch.Generator().manual_seed(21 + nseg)
-    N, C, H, W, copies = 2 * nseg, 48, 7, 5, 32
-    dev = backend
-    yv = View.alloc(N, H, W, C + 16, dt, dev, zero=True).slice(8, C)
-    yv.set_nchw((torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(dev))
-    rv = View.alloc(N, H, W, C, dt, dev); rv.set_nchw(torch.randn(N, C, H, W, generator=g).to(dev))
-    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
-    ssum = (torch.randn(nseg, copies, C, generator=g) * 3).to(dev).contiguous()
-    ssq = (torch.rand(nseg, copies, C, generator=g) * 40 + 30).to(dev).contiguous()
-    count = (N // nseg) * H * W * 1.0
-    a1 = [torch.empty(nseg * C, device=dev) for _ in range(4)]
-    a2 = [torch.empty(nseg * C, device=dev) for _ in range(4)]
-    o1, o2 = View.alloc(N, H, W, C, dt, dev), View.alloc(N, H, W, C, dt, dev)
-    for res in (None, rv):
-        ops.bn_finalize(ssum.view(-1), ssq.view(-1), count, gamma, beta, 1e-3, 0.03, None, None, *a1, nseg=nseg)
-        ops.bn_silu_apply(yv, a1[0], a1[1], o1, res=res, nseg=nseg)
-        ops.bn_apply_fused(ssum.view(-1), ssq.view(-1), count, gamma, beta, 1e-3, yv, o2, *a2, res=res, nseg=nseg)
-        for u, v in zip(a1, a2):
-            assert torch.equal(u, v)
-        assert torch.equal(o1.buf, o2.buf)
-
-
 @pytest.mark.parametrize("tile", [0, 19, 23, 86, 87, 102, 20, 24])
 @pytest.mark.parametrize("nseg,accumulate,k,stride", [(1, False, 3, 1), (2, True, 1, 1), (2, False, 3, 2)])
 def test_dgrad_gspace_epilogue_replaces_the_reduce_pass(backend, tile, nseg, accumulate, k, stride):

@@ -34,6 +34,7 @@ NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
          22: "rs128x64", 23: "rs64x64", 35: "d2-128x128", 36: "d2-64x256", 38: "d2-128x64", 39: "d2-64x64",
          51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64",
+         112: "halo128x4", 113: "halo256x4", 114: "halo128x8", 115: "halo128x2", 116: "halo64x8",
          99: "w3-128x128", 102: "w3-128x64", 103: "w3-64x64", 24: "rs256x64", 88: "wr256x64", 89: "wr256x128", 83: "wr128x128", 84: "wr64x256", 85: "wr32x256", 86: "wr128x64", 87: "wr64x64"}
 
 
@@ -44,6 +45,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--chain", type=int, default=1, help="launches per timed event pair (amortises the event / launch gap)")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad"], help="dgrad: the data gradient of the layer (3x3 s1 / 1x1 shapes)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     tiles = [int(t) for t in a.tiles.split(",")]
@@ -63,22 +65,31 @@ def main():
         wf = pack_conv_weight_frag(w, k)
         scale = torch.ones(cout, device=dev)
         shift = torch.zeros(cout, device=dev)
+        kw = dict(epilogue=ops.EPI_SILU)
+        if a.mode == "dgrad":
+            if st != 1:
+                continue
+            scale = shift = None
+            kw = dict(mode=ops.CONV_DGRAD)
         flops = 2.0 * cin * cout * k * k * y.pixels
         res = []
         for t in tiles:
-            if ((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256):
+            if t >= 112 and (k != 3 or st != 1 or (t == 113 and cout < 256)):
+                res.append(float("nan"))
+                continue
+            if t < 112 and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
                 res.append(float("nan"))
                 continue
             try:
                 for _ in range(2):
-                    ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t, wfrag=wf)
+                    ops.conv2d(x, w, y, k, st, scale, shift, tile=t, wfrag=wf, **kw)
                 torch.cuda.synchronize()
                 ts = []
                 for _ in range(a.reps):
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
                     for _ in range(a.chain):
-                        ops.conv2d(x, w, y, k, st, scale, shift, epilogue=ops.EPI_SILU, tile=t, wfrag=wf)
+                        ops.conv2d(x, w, y, k, st, scale, shift, tile=t, wfrag=wf, **kw)
                     e.record()
                     torch.cuda.synchronize()
                     ts.append(s.elapsed_time(e) / a.chain)
