@@ -27,8 +27,8 @@ namespace sy_conv {
 
 constexpr int kHaloW = 34;            // 32 pixels + 1 halo pixel on each side
 
-template <typename T, int WC, int WP, int TC, int TP>
-__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 3 : 2)) void conv3x3_halo_kernel(ConvArgs p) {
+template <typename T, int WC, int WP, int TC, int TP, int GS>
+__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_halo_kernel(ConvArgs p) {
     constexpr int kThreads = WC * WP * 64;
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 3 : 2)) void conv3x3_
     const int tiles_w = (p.Wo + 31) >> 5, tiles_h = (p.Ho + TH - 1) / TH;
     const int tw = bid.y % tiles_w, th_ = (bid.y / tiles_w) % tiles_h, n = bid.y / (tiles_w * tiles_h);
     const int h0 = th_ * TH, w0 = tw * 32;
+    if constexpr (GS) gs_fill_affine<CT>(p, smem, bid.x * CT, tid, kThreads);
 
     // ---- DMA assignment: instruction j = wave + i * NW fills halo rows [16 j, 16 j + 16); lane -> (row, physical 16-byte slot)
     const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
@@ -169,11 +170,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 4 ? 3 : 2)) void conv3x3_
                 for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
         }
     }
-    conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+    conv_epilogue<T, WC, WP, TC, TP, GS>(p_late, mp, e_bx, acc, smem, tid);
 }
 
-template <typename T, int WC, int WP, int TC, int TP>
-int launch_halo(const ConvArgs& a_in, void* stream) {
+template <typename T, int WC, int WP, int TC, int TP, int GS>
+int launch_halo_gs(const ConvArgs& a_in, void* stream) {
     constexpr int NW = WC * WP, CT = WC * TC * 32, TH = WP * TP, PT = TH * 32;
     constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
     ConvArgs a = a_in;
@@ -182,11 +183,17 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
     if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
     constexpr size_t smem_k = 2 * (size_t)BUF;
-    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 12 + (size_t)32 * CT;
-    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= 48 * 1024);
+    constexpr size_t stage_b = (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
+    constexpr bool can_stage = (T::kEPC == 8 && (size_t)EpiLds<WP, CT>::kStatBytes + stage_b <= 48 * 1024);
+    constexpr size_t fold_b = (size_t)NW * 64 * 64;
+    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (stage_b > fold_b ? stage_b : fold_b);
     constexpr size_t smem_s = (size_t)WP * CT * 8;            // statistics scratch of the un-staged epilogue
-    constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
+    constexpr size_t smem_base = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
+    size_t smem = smem_base;
+    a.gs_aff_off = (int)smem_base;
     if (a.gs_count > 0) {
+        if (!GS) return SY_ERR_UNSUPPORTED;
+        smem += (size_t)32 * CT;
         const bool staged = can_stage && !a.y_f32 && a.res == nullptr && (a.Cout & 3) == 0 && (a.ldy & 7) == 0 &&
                             (reinterpret_cast<unsigned long long>(a.y) & 15ull) == 0 && a.epilogue != SY_EPI_DECODE &&
                             a.stat_sum == nullptr;
@@ -197,14 +204,23 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP, GS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(smem_base + 32 * CT)) != hipSuccess)
             return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
+    SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP, GS>), grid, dim3(NW * 64), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+template <typename T, int WC, int WP, int TC, int TP>
+int launch_halo(const ConvArgs& a, void* stream) {
+    if (a.gs_count > 0) {
+        if constexpr (T::kEPC == 8) return launch_halo_gs<T, WC, WP, TC, TP, 1>(a, stream);
+        else return SY_ERR_UNSUPPORTED;
+    }
+    return launch_halo_gs<T, WC, WP, TC, TP, 0>(a, stream);
 }
 
 // tile codes 112..116 of sy_conv_desc::tile (SY_TILE_HALO + k)

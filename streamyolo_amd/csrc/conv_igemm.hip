@@ -58,7 +58,7 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
         }
     }
     a.tile = d->tile & 0xff;
-    a.ablate = (d->tile >> 8) & 7;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
+    a.ablate = (d->tile >> 8) & 0xff;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return sy_conv_launch_bf16(a, stream);

@@ -428,12 +428,12 @@ def _time_launches(run, device, launches=4, rounds=2):
     return best
 
 
-def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False):
+def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False, gs=False):
     """Fastest sy_conv2d variant for this problem shape (H, W = INPUT size of the launch), or 0 (the
     library's static heuristic) when tuning is off.  Measured with HIP events on dummy tensors."""
     if not autotune_enabled(device):
         return 0
-    key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats), str(device))
+    key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats), bool(gs), str(device))
     hit = _tile_cache.get(key)
     if hit is not None:
         return hit
@@ -457,6 +457,8 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     if k == 3 and stride == 1 and wf is not None and HALO_TILES:
         # 3x3 stride-1 layers: the halo-resident kernel (csrc/conv3x3_halo.h), tiles of 64 / 128 / 256 channels
         cands += [t for t in HALO_TILES if not (t == 113 and Cout < 256) and not (t == 116 and Cout > 64)]
+    if gs:   # launches carrying sy_conv_desc::gs exist for the register-staged / weights-in-registers / halo variants only
+        cands = [t for t in cands if 16 <= t < 32 or t >= TILE_WR]
     best, best_t = 0, float("inf")
     for t in cands:
         if t >= TILE_WR and wf is None:

@@ -829,14 +829,15 @@ class TrainPlan:
             dxa, acca = G.target(a.x)
             dxb, accb = G.target(b2.x)
             assert acca == accb and dxa.root[0] is dxb.root[0]
+            gs = self._gs_for(a.x.pair(), True)
             t = a._tiles.get("dgrad2")
             if t is None:
-                t = ops.tuned_tile(CONV_DGRAD, dy2.dtype, 2 * N, H, W, C, a.x.C, a.k, a.stride, self.device)
+                t = ops.tuned_tile(CONV_DGRAD, dy2.dtype, 2 * N, H, W, C, a.x.C, a.k, a.stride, self.device, gs=bool(gs))
                 a._tiles["dgrad2"] = t
             ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
                        mode=CONV_DGRAD, accumulate=acca, tile=t,
                        wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None,
-                       gs=self._gs_for(a.x.pair(), True), gs_segments=2)
+                       gs=gs, gs_segments=2)
 
     def _conv_backward(self, op):
         G = self.grads
@@ -847,11 +848,16 @@ class TrainPlan:
         self._on_side(lambda: self._wgrad(op, op.x, dyraw), slot)
         if op.need_dx:
             dx, acc = G.target(op.x)
-            t = op.tile("dgrad")
+            gs = self._gs_for(op.x, False)
+            t = op._tiles.get("dgrad1")
+            if t is None:
+                y = op.y
+                t = ops.tuned_tile(CONV_DGRAD, y.dtype, y.N, y.H, y.W, y.C, op.x.C, op.k, op.stride, self.device, gs=bool(gs))
+                op._tiles["dgrad1"] = t
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
                        mode=CONV_DGRAD, accumulate=acc, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None,
-                       gs=self._gs_for(op.x, False))
+                       gs=gs)
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, x, targets, iters=2, detail=False):

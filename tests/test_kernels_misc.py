@@ -392,8 +392,8 @@ def test_decode_is_invertible(backend):
         assert (inv - raw[..., :5]).abs().max() < 2e-4 * max(1.0, float(raw[..., :5].abs().max()))
 
 
-@pytest.mark.parametrize("tile", [0, 19, 23, 86, 87, 102, 20, 24])
-@pytest.mark.parametrize("nseg,accumulate,k,stride", [(1, False, 3, 1), (2, True, 1, 1), (2, False, 3, 2)])
+@pytest.mark.parametrize("tile", [0, 19, 23, 86, 87, 102, 20, 24, 112, 115])
+@pytest.mark.parametrize("nseg,accumulate,k,stride", [(1, False, 3, 1), (2, True, 1, 1), (2, False, 3, 2), (2, True, 3, 1)])
 def test_dgrad_gspace_epilogue_replaces_the_reduce_pass(backend, tile, nseg, accumulate, k, stride):
     """sy_conv_desc::gs: a data-gradient launch that stores g = da * silu'(bn(raw)) and accumulates the BatchNorm
     backward sums, against the unfused sequence (plain dgrad -> sy_bn_silu_bwd_reduce): same sums, g = da * silu'(z) of
@@ -401,6 +401,8 @@ def test_dgrad_gspace_epilogue_replaces_the_reduce_pass(backend, tile, nseg, acc
     onto an earlier gradient, stride-2 parity classes; and the fused sums + g drive sy_bn_silu_bwd_apply(g_space) to the
     same dy as the unfused pair."""
     from streamyolo_amd.model.packing import pack_conv_weight, pack_conv_weight_frag
+    if tile >= 112 and (k != 3 or stride != 1):
+        pytest.skip("the halo kernel is 3x3 stride 1")
     dt = "bf16"
     g = torch.Generator().manual_seed(tile * 7 + nseg)
     N, cdy, cx = 2 * nseg, 32, 72                                  # dgrad input dy [N,Hy,Wy,cdy] -> output dx [N,H,W,cx]
