@@ -45,28 +45,13 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
        SY_TILE_DMA3 = 48, /* add: 3-deep LDS-DMA ring */
        SY_TILE_WR = 80,   /* add: register-staged pixels + fragment-packed weights loaded straight into VGPRs */
        SY_TILE_HALO = 112 /* 112..116: 3x3 stride-1 kernel with the input tile + halo resident in LDS (csrc/conv3x3_halo.h; needs
-                             wfrag): 128 ch x 4 rows x 32 px | 256 x 4 | 128 x 8 | 128 x 2 | 64 x 8 */ };
+                             wfrag): 128 ch x 4 rows x 32 px (2x2 waves) | 128 x 4 (4x1 waves) | 128 x 2 (8 waves) | 128 x 2 | 64 x 8 */ };
 
 /* gather modes of sy_conv2d */
 enum {
     SY_CONV_FWD = 0,        /* out(ho,wo) <- in(ho*s - p + kh, wo*s - p + kw)                  */
     SY_CONV_DGRAD = 1       /* out(h,w)  <- in((h + p - kh)/s, (w + p - kw)/s) when divisible  */
 };
-
-/* BatchNorm-backward fusion of a data-gradient launch (sy_conv_desc::gs).  Output channels [c0, c1) of the launch are
- * d(loss)/d(activation) of ONE BaseConv call, a = silu(scale*raw + shift).  Instead of storing da and reading it back
- * in a reduction pass, the launch stores g = da * silu'(scale*raw + shift) ("g-space": several launches may
- * accumulate into one gradient, the map is linear) and adds its part of  sums[0][c] = sum_pixels g,
- * sums[1][c] = sum_pixels g * xhat  into replica (pixel tile % copies) — exactly what sy_bn_silu_bwd_reduce produces.
- * raw: that BaseConv's raw convolution output, dense [N, Ho, Wo] pixels with pixel stride ldraw, first channel c0.
- * scale / shift / mean / invstd: [segments][c1-c0]; sums: [segments][copies][2][c1-c0]. */
-typedef struct sy_conv_gs {
-    int32_t c0, c1;
-    int32_t ldraw, copies;
-    const void* raw;
-    const float* scale; const float* shift; const float* mean; const float* invstd;
-    float* sums;
-} sy_conv_gs;
 
 typedef struct sy_conv_desc {
     /* tensors */
@@ -98,9 +83,6 @@ typedef struct sy_conv_desc {
     int64_t x_bytes, w_bytes;           /* bytes addressable from x / w (buffer bounds of the fast gather; 0 = unknown) */
     const void* wfrag;                  /* optional: weights re-packed in MFMA-fragment order (SY_TILE_WR variants) */
     int64_t wfrag_bytes;
-    int32_t gs_count;                   /* 0-2 sy_conv_gs ranges (16-bit outputs without residual; SY_ERR_UNSUPPORTED otherwise) */
-    int32_t gs_segments;                /* statistics segments of the gs arrays (frame pairs: 2), N % segments == 0 */
-    sy_conv_gs gs[2];
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.
@@ -261,13 +243,12 @@ SY_API int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldd
 /* apply: dy = gamma*invstd*(dz - S0/M - xhat*S1/M) with S = sums folded over its `copies` replicas
  * ([copies][2][C]); optionally dgamma += S1, dbeta += S0.  dres (optional): the gradient view of the residual input of
  * y = silu(bn(conv)) + res (Bottleneck shortcut, DFP add): dres = da, or dres += da when dres_accumulate — the same
- * pass that already reads da (replaces a separate sy_view_copy).  g_space = 1: `da` already holds g = da * silu'(z)
- * and `sums` were accumulated by the data-gradient launches that wrote it (sy_conv_desc::gs): no reduce pass ran. */
+ * pass that already reads da (replaces a separate sy_view_copy). */
 SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                 const float* shift, const float* mean, const float* invstd,
                                 const float* gamma, const float* sums, int copies, void* dy, int lddy,
                                 int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
-                                int dres_accumulate, int g_space, int dtype, int nseg, void* stream);
+                                int dres_accumulate, int dtype, int nseg, void* stream);
 
 /* SimOTA assignment + Trend-Aware loss, forward and gradient, for a whole batch, no host sync.
  * raw [B, A, 5+nc] fp32 raw head logits (reg4, obj, cls); labels/support [B, max_labels, 5] fp32 rows

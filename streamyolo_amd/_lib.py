@@ -25,13 +25,6 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-class ConvGs(C.Structure):
-    """sy_conv_gs (include/streamyolo_hip.h): one BatchNorm-backward fusion range of a data-gradient launch."""
-    _fields_ = [("c0", C.c_int32), ("c1", C.c_int32), ("ldraw", C.c_int32), ("copies", C.c_int32), ("raw", C.c_void_p),
-                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-                ("sums", C.c_void_p)]
-
-
 class ConvDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
@@ -43,7 +36,6 @@ class ConvDesc(C.Structure):
         ("xbs", C.c_int64), ("ybs", C.c_int64), ("rbs", C.c_int64),
         ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
         ("accumulate", C.c_int32), ("dec_stride", C.c_float), ("stat_copies", C.c_int32), ("stat_segments", C.c_int32), ("tile", C.c_int32), ("x_bytes", C.c_int64), ("w_bytes", C.c_int64), ("wfrag", C.c_void_p), ("wfrag_bytes", C.c_int64),
-        ("gs_count", C.c_int32), ("gs_segments", C.c_int32), ("gs", ConvGs * 2),
     ]
 
 
@@ -110,7 +102,7 @@ SIGNATURES = {
     "sy_bn_finalize": (_I, [_P, _P, _I, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
     "sy_bn_silu_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
-    "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),

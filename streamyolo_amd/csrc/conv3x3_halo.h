@@ -18,8 +18,7 @@
 //   * weight operand (MFMA A): fragment-packed weights straight from L2 into VGPRs (the SY_TILE_WR layout of
 //     conv_igemm_impl.h), prefetched two taps ahead through a 3-stage register ring, no LDS, no barrier;
 //   * the data gradient is the same kernel reading tap (kh, kw) at window offset (2 - kh, 2 - kw) with the transposed weights.
-// Epilogue: conv_epilogue of conv_igemm_impl.h through the TilePixels mapper (BN statistics, staged coalesced write-out,
-// g-space BatchNorm-backward fusion all included).
+// Epilogue: conv_epilogue of conv_igemm_impl.h through the TilePixels mapper (BN statistics, staged coalesced write-out).
 #pragma once
 #include "conv_igemm_impl.h"
 
@@ -27,7 +26,7 @@ namespace sy_conv {
 
 constexpr int kHaloW = 34;            // 32 pixels + 1 halo pixel on each side
 
-template <typename T, int WC, int WP, int TC, int TP, int GS>
+template <typename T, int WC, int WP, int TC, int TP>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_halo_kernel(ConvArgs p) {
     constexpr int kThreads = WC * WP * 64;
     constexpr int NW = WC * WP;
@@ -54,7 +53,6 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
     const int tiles_w = (p.Wo + 31) >> 5, tiles_h = (p.Ho + TH - 1) / TH;
     const int tw = bid.y % tiles_w, th_ = (bid.y / tiles_w) % tiles_h, n = bid.y / (tiles_w * tiles_h);
     const int h0 = th_ * TH, w0 = tw * 32;
-    if constexpr (GS) gs_fill_affine<CT>(p, smem, bid.x * CT, tid, kThreads);
 
     // ---- DMA assignment: instruction j = wave + i * NW fills halo rows [16 j, 16 j + 16); lane -> (row, physical 16-byte slot)
     const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
@@ -128,28 +126,34 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
         sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
         const bool more = cs + 1 < ncs;
         const unsigned char* const hb = smem + (cs & 1) * BUF;
-        sy_static_for<0, 9>([&](auto tap_) {
-            constexpr int TAP = decltype(tap_)::value;
-            constexpr int KH = TAP / 3, KW = TAP % 3;
-            fetch(sy_int<(TAP + 2) % 3>());       // two taps ahead (its registers held tap TAP - 1)
-            if constexpr (TAP < NI) {
-                if (more) issue_piece(tap_, (cs + 1) & 1, cs + 1);
-            }
-            const int toff = fwd ? (KH * kHaloW + KW) : ((2 - KH) * kHaloW + (2 - KW));
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                uint4 b[TP];
-#pragma unroll
-                for (int u = 0; u < TP; ++u) {
-                    const int row = rbase[u] + toff;
-                    b[u] = *reinterpret_cast<const uint4*>(hb + row * 64 + (((g * 2 + half) ^ ((row >> 2) & 3)) << 4));
+        // taps: kh is a RUNTIME loop (three trips), kw unrolled — the fragment ring position (tap % 3 == kw) stays a compile-time
+        // index, the code is a third of the fully unrolled form and the register allocator no longer hoists nine taps of
+        // address arithmetic and LDS reads (the 64-register tile spilled, tools/regs_census.sh)
+        for (int kh = 0; kh < 3; ++kh) {
+            sy_static_for<0, 3>([&](auto kw_) {
+                constexpr int KW = decltype(kw_)::value;
+                fetch(sy_int<(KW + 2) % 3>());    // two taps ahead (its registers held the previous tap)
+                if (more) {                       // DMA piece number (3 kh + kw) of the next slab
+                    if constexpr (KW < NI) { if (kh == 0) issue_piece(sy_int<KW>(), (cs + 1) & 1, cs + 1); }
+                    if constexpr (3 + KW < NI) { if (kh == 1) issue_piece(sy_int<3 + KW>(), (cs + 1) & 1, cs + 1); }
+                    if constexpr (6 + KW < NI) { if (kh == 2) issue_piece(sy_int<6 + KW>(), (cs + 1) & 1, cs + 1); }
                 }
+                const int toff = fwd ? (kh * kHaloW + KW) : ((2 - kh) * kHaloW + (2 - KW));
 #pragma unroll
-                for (int t = 0; t < TC; ++t)
+                for (int g = 0; g < 2; ++g) {
+                    uint4 b[TP];
 #pragma unroll
-                    for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), fr[TAP % 3][t][g], b[u], acc[t][u]);
-            }
-        });
+                    for (int u = 0; u < TP; ++u) {
+                        const int row = rbase[u] + toff;
+                        b[u] = *reinterpret_cast<const uint4*>(hb + row * 64 + (((g * 2 + half) ^ ((row >> 2) & 3)) << 4));
+                    }
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+#pragma unroll
+                        for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), fr[KW][t][g], b[u], acc[t][u]);
+                }
+            });
+        }
     }
 
     SY_LATE_ARGS(ConvArgs, p);
@@ -170,11 +174,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
                 for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
         }
     }
-    conv_epilogue<T, WC, WP, TC, TP, GS>(p_late, mp, e_bx, acc, smem, tid);
+    conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int GS>
-int launch_halo_gs(const ConvArgs& a_in, void* stream) {
+template <typename T, int WC, int WP, int TC, int TP>
+int launch_halo(const ConvArgs& a_in, void* stream) {
     constexpr int NW = WC * WP, CT = WC * TC * 32, TH = WP * TP, PT = TH * 32;
     constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
     ConvArgs a = a_in;
@@ -183,44 +187,23 @@ int launch_halo_gs(const ConvArgs& a_in, void* stream) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
     if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
     constexpr size_t smem_k = 2 * (size_t)BUF;
-    constexpr size_t stage_b = (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
-    constexpr bool can_stage = (T::kEPC == 8 && (size_t)EpiLds<WP, CT>::kStatBytes + stage_b <= 48 * 1024);
-    constexpr size_t fold_b = (size_t)NW * 64 * 64;
-    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (stage_b > fold_b ? stage_b : fold_b);
+    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
+    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= 48 * 1024);
     constexpr size_t smem_s = (size_t)WP * CT * 8;            // statistics scratch of the un-staged epilogue
-    constexpr size_t smem_base = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
-    size_t smem = smem_base;
-    a.gs_aff_off = (int)smem_base;
-    if (a.gs_count > 0) {
-        if (!GS) return SY_ERR_UNSUPPORTED;
-        smem += (size_t)32 * CT;
-        const bool staged = can_stage && !a.y_f32 && a.res == nullptr && (a.Cout & 3) == 0 && (a.ldy & 7) == 0 &&
-                            (reinterpret_cast<unsigned long long>(a.y) & 15ull) == 0 && a.epilogue != SY_EPI_DECODE &&
-                            a.stat_sum == nullptr;
-        if (!staged) return SY_ERR_UNSUPPORTED;
-    }
+    constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
     const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
     dim3 grid((a.Cout + CT - 1) / CT, tiles, 1);
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP, GS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(smem_base + 32 * CT)) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP, GS>), grid, dim3(NW * 64), smem, stream, a);
+    SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
-}
-
-template <typename T, int WC, int WP, int TC, int TP>
-int launch_halo(const ConvArgs& a, void* stream) {
-    if (a.gs_count > 0) {
-        if constexpr (T::kEPC == 8) return launch_halo_gs<T, WC, WP, TC, TP, 1>(a, stream);
-        else return SY_ERR_UNSUPPORTED;
-    }
-    return launch_halo_gs<T, WC, WP, TC, TP, 0>(a, stream);
 }
 
 // tile codes 112..116 of sy_conv_desc::tile (SY_TILE_HALO + k)
@@ -228,8 +211,8 @@ template <typename T>
 int launch_halo_typed(const ConvArgs& a, void* stream) {
     switch (a.tile) {
         case 112: return launch_halo<T, 2, 2, 2, 2>(a, stream);     // 128 ch x ( 4 rows x 32 px)
-        case 113: return launch_halo<T, 4, 1, 2, 4>(a, stream);     // 256 ch x ( 4 rows x 32 px)
-        case 114: return launch_halo<T, 2, 2, 2, 4>(a, stream);     // 128 ch x ( 8 rows x 32 px)
+        case 113: return launch_halo<T, 4, 1, 1, 4>(a, stream);     // 128 ch x ( 4 rows x 32 px), 4 waves x (32 ch x 128 px)
+        case 114: return launch_halo<T, 4, 2, 1, 1>(a, stream);     // 128 ch x ( 2 rows x 32 px), 8 waves x (32 ch x 32 px)
         case 115: return launch_halo<T, 4, 1, 1, 2>(a, stream);     // 128 ch x ( 2 rows x 32 px)
         case 116: return launch_halo<T, 1, 4, 2, 2>(a, stream);     //  64 ch x ( 8 rows x 32 px)
         default: return SY_ERR_ARG;

@@ -39,26 +39,8 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.w_extent = (d->w_bytes > 0 && d->w_bytes < 0xFFFFFFF0LL) ? (unsigned)d->w_bytes : 0u;
     a.wfrag = (const unsigned char*)d->wfrag;
     a.wfrag_extent = (d->wfrag != nullptr && d->wfrag_bytes > 0 && d->wfrag_bytes < 0xFFFFFFF0LL) ? (unsigned)d->wfrag_bytes : 0u;
-    a.gs_count = 0; a.gs_seg_M = 0;
-    if (d->gs_count > 0) {
-        if (d->gs_count > 2 || d->mode == SY_CONV_FWD || d->dtype == SY_DT_F32 || d->y_f32 || d->res != nullptr) return SY_ERR_UNSUPPORTED;
-        const int nseg = d->gs_segments > 1 ? d->gs_segments : 1;
-        if (nseg > 2 || d->N % nseg != 0) return SY_ERR_ARG;
-        a.gs_count = d->gs_count;
-        a.gs_seg_M = nseg > 1 ? (d->N / nseg) * d->Ho * d->Wo : 0;
-        for (int r = 0; r < d->gs_count; ++r) {
-            const sy_conv_gs& g = d->gs[r];
-            if (g.raw == nullptr || g.scale == nullptr || g.shift == nullptr || g.mean == nullptr || g.invstd == nullptr ||
-                g.sums == nullptr || g.copies < 1 || g.c0 < 0 || g.c1 > d->Cout || g.c0 >= g.c1 || (g.c0 & 7) || (g.c1 & 7) ||
-                (g.ldraw & 7) || (reinterpret_cast<unsigned long long>(g.raw) & 15ull))
-                return SY_ERR_ARG;
-            a.gs[r].c0 = g.c0; a.gs[r].c1 = g.c1; a.gs[r].ldraw = g.ldraw; a.gs[r].copies = g.copies;
-            a.gs[r].raw = (const unsigned char*)g.raw; a.gs[r].scale = g.scale; a.gs[r].shift = g.shift;
-            a.gs[r].mean = g.mean; a.gs[r].invstd = g.invstd; a.gs[r].sums = g.sums;
-        }
-    }
     a.tile = d->tile & 0xff;
-    a.ablate = (d->tile >> 8) & 0xff;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
+    a.ablate = (d->tile >> 8) & 7;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return sy_conv_launch_bf16(a, stream);

@@ -60,43 +60,10 @@ struct ConvArgs {
     const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
     unsigned wfrag_extent;
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads
-    // BatchNorm-backward fusion of a data-gradient launch (sy_conv_desc::gs): output channels [c0, c1) are the gradient
-    // of ONE BaseConv's activation; the write-out pass multiplies them by silu'(bn(raw)) and accumulates the two
-    // per-channel reduction sums of that BatchNorm (what sy_bn_silu_bwd_reduce computed in a pass of its own)
-    int gs_count;               // 0, 1 or 2 ranges
-    int gs_seg_M;               // pixels per statistics segment (M / segments)
-    int gs_aff_off;             // byte offset in dynamic LDS of the tile's BatchNorm affine [2 seg][4][CT] (set by the launcher, past everything else)
-    struct Gs {
-        int c0, c1, ldraw, copies;
-        const unsigned char* raw;
-        const float* scale; const float* shift; const float* mean; const float* invstd;
-        float* sums;
-    } gs[2];
 };
 
-// g-space: park scale | shift | mean | invstd of the workgroup's CT channels (both segments) in LDS at kernel start — the loads
-// hide behind the K loop; the write-out pass of the epilogue reads them per item.
-template <int CT, typename Args>
-__device__ __forceinline__ void gs_fill_affine(const Args& p, unsigned char* smem, int c0, int tid, int nthreads) {
-    if (p.gs_count <= 0) return;
-    float* gaff = reinterpret_cast<float*>(smem + p.gs_aff_off);
-    for (int i = tid; i < 8 * CT; i += nthreads) {
-        const int cl = i % CT, arr = (i / CT) & 3, sg = i / (4 * CT);
-        const int co = c0 + cl;
-        float v = 0.0f;
-        if (sg == 0 || p.gs_seg_M > 0)
-            for (int r = 0; r < p.gs_count; ++r) {
-                if (co < p.gs[r].c0 || co >= p.gs[r].c1) continue;
-                const int Cg = p.gs[r].c1 - p.gs[r].c0;
-                const float* base = arr == 0 ? p.gs[r].scale : arr == 1 ? p.gs[r].shift : arr == 2 ? p.gs[r].mean : p.gs[r].invstd;
-                v = base[sg * Cg + co - p.gs[r].c0];
-            }
-        gaff[i] = v;
-    }
-}
-
-// LDS in front of the staged output tile: BN-statistics scratch [WP][CT][2] floats, or the g-space sums [2 seg][2][CT]
-template <int WP, int CT> struct EpiLds { static constexpr int kStatBytes = (WP < 2 ? 2 : WP) * CT * 8; };
+// LDS in front of the staged output tile: BN-statistics scratch [WP][CT][2] floats
+template <int WP, int CT> struct EpiLds { static constexpr int kStatBytes = WP * CT * 8; };
 
 constexpr int kRowB = 64;           // DMA ring: bytes of K per LDS row per slab (unpadded: LDS-DMA lands lane-linear)
 constexpr int kPitchRS = 80;        // register-staged: 64 B of K + 16 B pad per LDS row (conflict-free ds_read_b128)
@@ -140,17 +107,14 @@ struct TilePixels {               // halo kernel: TH rows of 32 consecutive pixe
     }
 };
 
-template <typename T, int WC, int WP, int TC, int TP, int GS, typename Args, typename Map>
+template <typename T, int WC, int WP, int TC, int TP, typename Args, typename Map>
 __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int bx, f32x16 (&acc)[TC][TP],
                                               unsigned char* smem, int tid);
 
 // STG: staging strategy — 1 = register-staged; 2 / 3 / 4 (0 = 4) = LDS-DMA ring of that depth (depth-1 slabs of
 // loads in flight while one feeds the MFMAs; a shallow ring costs less LDS, so more workgroups share a CU).
-// GS = 1: the instantiation that carries the g-space write-out (sy_conv_desc::gs).  A separate instantiation because its
-// batched loads and sums cost registers: compiled into the common kernel they pushed the 128x64 tile from 94 to 128 VGPRs
-// (one wave per SIMD less) and the 128x128 tile into scratch for EVERY launch, forward ones included (tools/regs_census.sh).
-template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST, int GS>
-__global__ __launch_bounds__(WC * WP * 64, GS ? (TC * TP <= 2 ? 3 : 2) : ((TC * TP <= 4 && !(STG == 6 && TC * TP == 4)) ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
+template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
+__global__ __launch_bounds__(WC * WP * 64, ((TC * TP <= 4 && !(STG == 6 && TC * TP == 4)) ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
     typedef typename T::elem elem;
     constexpr int RS = (STG == 1 || STG == 5 || STG == 6) ? 1 : 0;
     constexpr int WR = (STG == 5 || STG == 6) ? 1 : 0;   // weights: fragment-packed, global -> VGPR, never in LDS
@@ -180,7 +144,6 @@ __global__ __launch_bounds__(WC * WP * 64, GS ? (TC * TP <= 2 ? 3 : 2) : ((TC * 
     const int wp = wave % WP;
     const sy_block_id bid = sy_xcd_block_id();   // logical tile of this workgroup (XCD-contiguous order)
     const int c0 = bid.x * CT;
-    if constexpr (GS) gs_fill_affine<CT>(p, smem, c0, tid, kThreads);
     // statistics segments (training forward of a frame pair): segment z owns pixels [z * seg_M, (z + 1) * seg_M)
     // Stride-2 data gradient: an output pixel (ho, wo) only receives the taps with kh = ho + pad, kw = wo + pad (mod 2)
     // — a 3x3 kernel has 1, 2, 2 or 4 of them, never 9.  gridDim.z enumerates the four parity classes; a workgroup
@@ -614,12 +577,12 @@ __global__ __launch_bounds__(WC * WP * 64, GS ? (TC * TP <= 2 ? 3 : 2) : ((TC * 
     int e_bx = bid.x, e_by = bid.y, e_bz = bid.z;
     SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_by); SY_LAUNDER_INT(e_bz);
     const LinearPixels mp(p_late, e_by, e_bz, PT);
-    conv_epilogue<T, WC, WP, TC, TP, GS>(p_late, mp, e_bx, acc, smem, tid);
+    conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
 }
 
 // The epilogue as a separate (inlined) function: its only inputs are the late argument view, the logical tile and
 // the accumulators, so none of the prologue's uniforms can be referenced (and kept alive) by accident.
-template <typename T, int WC, int WP, int TC, int TP, int GS, typename Args, typename Map>
+template <typename T, int WC, int WP, int TC, int TP, typename Args, typename Map>
 __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int bx, f32x16 (&acc)[TC][TP],
                                               unsigned char* smem, int tid) {
     typedef typename T::elem elem;
@@ -644,7 +607,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
     // [pixel][channel] and the workgroup writes whole pixel rows, 16 bytes per lane, consecutive lanes consecutive
     // addresses (the K loop is over, its LDS is free).
     constexpr int kStagePitch = CT * 2 + 16;                    // bytes per staged pixel row (+16: bank spread)
-    constexpr int kStatBytes = EpiLds<WP, CT>::kStatBytes;      // BN-statistics scratch [WP][CT][2] floats / g-space sums [2][2][CT]
+    constexpr int kStatBytes = EpiLds<WP, CT>::kStatBytes;      // BN-statistics scratch [WP][CT][2] floats (aliases too)
     constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 8 + kStatBytes <= 48 * 1024);
     // (+= outputs — data gradients of activations with several consumers — are staged too: the write-out pass reads
     //  the old row chunk, adds in fp32 and stores, all coalesced; the staged value was already rounded to 16 bits,
@@ -653,8 +616,6 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                            ((reinterpret_cast<unsigned long long>(p.y) & 15ull) == 0);
     unsigned char* const stg = smem + kStatBytes;               // [PT][kStagePitch]
     long long* const stg_off = reinterpret_cast<long long*>(smem + kStatBytes + PT * kStagePitch);   // [PT] element offsets
-    constexpr bool kGs = (GS != 0) && kCanStage;
-    const bool gs_on = kGs && stage_out && p.gs_count > 0 && !want_stats;
     if (want_stats || stage_out) __syncthreads();               // every wave is done with the operand tiles
     // ---- lean path for staged outputs (every training forward / first-write data gradient / eval conv without a
     //      residual): the mode, affine and statistics decisions are taken ONCE here, not per element — the general
@@ -860,129 +821,9 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             }
         }
     });
-    // ---- g-space (BatchNorm-backward fusion, sy_conv_desc::gs): the write-out pass below turns the staged chunk (d(loss)/
-    //      d(activation) of 8 channels of one pixel) into g = da * silu'(z), z = scale*raw + shift, and accumulates
-    //      per channel sum g and sum g * xhat.  A thread's channel chunk is fixed across its items; ALL its loads (raw
-    //      chunks, old gradients for +=) are issued here — after the accumulators were parked in LDS (they are dead now:
-    //      holding both sets of registers spilled the 64- and 128-register tiles), before the barrier — as one batch, so the
-    //      workgroup pays one memory round trip; the affine of the tile's channels waits in LDS since kernel start.
-    constexpr int CPRg = CT / 8;
-    constexpr int ITEMS = kGs ? (PT * CPRg + kThreads - 1) / kThreads : 1;
-    const int g_cl0 = (tid % CPRg) * 8;
-    const int g_co = c0 + g_cl0;
-    int gr = -1;
-    uint4 rv[ITEMS], ov[ITEMS];
-    long long offs[ITEMS];
-    int segs[ITEMS];
-    if constexpr (kGs) if (gs_on) {
-        for (int r = 0; r < p.gs_count; ++r)
-            if (g_co >= p.gs[r].c0 && g_co < p.gs[r].c1) gr = r;
-        const unsigned char* const graw = gr >= 0 ? p.gs[gr].raw : nullptr;
-        const int gld = gr >= 0 ? p.gs[gr].ldraw : 0, gcc = gr >= 0 ? g_co - p.gs[gr].c0 : 0;
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const int i = tid + it * kThreads;
-            int n_, rem_;
-            long long off = -1;
-            int lin = 0;
-            if (i < PT * CPRg && g_co < p.Cout && mp.map(i / CPRg, n_, rem_)) {
-                off = (long long)n_ * p.ybs + (long long)rem_ * p.ldy;
-                lin = n_ * p.HoWo + rem_;
-            }
-            offs[it] = off;
-            segs[it] = (p.gs_seg_M > 0 && lin >= p.gs_seg_M) ? 1 : 0;
-            rv[it] = make_uint4(0u, 0u, 0u, 0u);
-            ov[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (off >= 0) {
-                if (gr >= 0 && !(p.ablate & 32)) rv[it] = *reinterpret_cast<const uint4*>(graw + ((long long)lin * gld + gcc) * 2);
-                if (p.accumulate) ov[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<elem*>(p.y) + off + g_co);
-            }
-        }
-    }
     if (want_stats || (kCanStage && stage_out)) __syncthreads();
     if (kCanStage && stage_out) {
         constexpr int CPR = CT / 8;                             // 16-byte chunks per staged pixel row
-        static_assert(kThreads % CPR == 0, "a thread's channel chunk is fixed across its write-out items");
-        if (kGs && gs_on) {
-            const float* const gaff = reinterpret_cast<const float*>(smem + p.gs_aff_off);    // [2 seg][4][CT]
-            float gs0[2][8], gs1[2][8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { gs0[0][j] = 0.0f; gs0[1][j] = 0.0f; gs1[0][j] = 0.0f; gs1[1][j] = 0.0f; }
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                if (offs[it] < 0) continue;
-                const int px = (tid + it * kThreads) / CPR;
-                const uint4 v = *reinterpret_cast<const uint4*>(stg + px * kStagePitch + (tid % CPR) * 16);
-                elem ev[8], er[8], eo[8];
-                __builtin_memcpy(ev, &v, 16);
-                __builtin_memcpy(er, &rv[it], 16);
-                __builtin_memcpy(eo, &ov[it], 16);
-                float g8[8];
-                if (gr >= 0 && !(p.ablate & 32)) {
-                    const float* af = gaff + segs[it] * 4 * CT + g_cl0;
-                    float sc[8], sh[8], mu[8], is[8];
-                    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(af);
-                    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(af + 4);
-                    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(af + CT);
-                    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(af + CT + 4);
-                    *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(af + 2 * CT);
-                    *reinterpret_cast<float4*>(mu + 4) = *reinterpret_cast<const float4*>(af + 2 * CT + 4);
-                    *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(af + 3 * CT);
-                    *reinterpret_cast<float4*>(is + 4) = *reinterpret_cast<const float4*>(af + 3 * CT + 4);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float yy = T::to_f32(er[j]);
-                        const float g = T::to_f32(ev[j]) * sy_silu_grad_fast(yy * sc[j] + sh[j]);
-                        const float gx = g * ((yy - mu[j]) * is[j]);
-                        if (segs[it]) { gs0[1][j] += g; gs1[1][j] += gx; } else { gs0[0][j] += g; gs1[0][j] += gx; }
-                        g8[j] = g;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) g8[j] = T::to_f32(ev[j]);
-                }
-                if (p.accumulate) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) g8[j] += T::to_f32(eo[j]);
-                }
-                *reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + offs[it] + g_co) =
-                    make_uint4(T::pack2(g8[0], g8[1]), T::pack2(g8[2], g8[3]), T::pack2(g8[4], g8[5]), T::pack2(g8[6], g8[7]));
-            }
-            // Fold the kThreads / CPR threads that share a channel chunk: plain LDS stores into [row][kind][CT] (the staged tile
-            // is dead once everybody has passed the barrier), then thread (kind, channel) sums its column and issues ONE
-            // global atomic.  (LDS float atomics for this fold cost 23-40 us per workgroup — profiles/r02/c_gs_probe.txt.)
-            constexpr int R = kThreads / CPR;
-            float* const fold = reinterpret_cast<float*>(stg);  // [R][2][CT] floats = kThreads * 64 bytes
-            const int nseg = (p.gs_seg_M > 0) ? 2 : 1;
-            for (int sg = 0; sg < nseg && !(p.ablate & 16); ++sg) {
-                __syncthreads();
-                {
-                    float* dst = fold + ((tid / CPR) * 2) * CT + g_cl0;
-                    float a0[8], a1[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { a0[j] = sg ? gs0[1][j] : gs0[0][j]; a1[j] = sg ? gs1[1][j] : gs1[0][j]; }
-                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(a0);
-                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(a0 + 4);
-                    *reinterpret_cast<float4*>(dst + CT) = *reinterpret_cast<const float4*>(a1);
-                    *reinterpret_cast<float4*>(dst + CT + 4) = *reinterpret_cast<const float4*>(a1 + 4);
-                }
-                __syncthreads();
-                for (int i = tid; i < 2 * CT; i += kThreads) {
-                    float val = 0.0f;
-#pragma unroll 4
-                    for (int rr = 0; rr < R; ++rr) val += fold[rr * 2 * CT + i];
-                    if (val == 0.0f || (p.ablate & 8)) continue;
-                    const int kind = i / CT, cl = i % CT;
-                    const int cch = c0 + cl;
-                    for (int r = 0; r < p.gs_count; ++r) {
-                        if (cch < p.gs[r].c0 || cch >= p.gs[r].c1) continue;
-                        const int Cg = p.gs[r].c1 - p.gs[r].c0;
-                        const int copy = (int)((unsigned)mp.rep % (unsigned)p.gs[r].copies);
-                        atomicAdd(p.gs[r].sums + ((long long)(sg * p.gs[r].copies + copy) * 2 + kind) * Cg + (cch - p.gs[r].c0), val);
-                    }
-                }
-            }
-        } else
         for (int i = tid; i < PT * CPR; i += kThreads) {
             const int px = i / CPR, ck = i - px * CPR;
             const long long off = stg_off[px];
@@ -1019,9 +860,8 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
     }
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST, int GS = 0>
-int launch_one(const ConvArgs& a_in, void* stream) {
-    ConvArgs a = a_in;
+template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
+int launch_one(const ConvArgs& a, void* stream) {
     constexpr int RS = (STG == 1 || STG == 5 || STG == 6) ? 1 : 0;
     constexpr int kStages = RS ? 1 : (STG == 0 ? 4 : STG);
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
@@ -1033,34 +873,18 @@ int launch_one(const ConvArgs& a_in, void* stream) {
                               : (STG == 5) ? (size_t)(PT * kPitchRS > WP * CT * 8 ? PT * kPitchRS : WP * CT * 8)
                                          : (RS ? (size_t)(CT + PT) * kPitchRS : (size_t)kStages * (CT + PT) * kRowB);
     // epilogue staging of 16-bit outputs (see the kernel): statistics scratch + [PT][CT*2+16] + [PT] offsets
-    // + the g-space fold [threads / CPR][2][CT] floats = threads * 64 bytes, which aliases the staged tile
-    constexpr size_t stage_b = (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
-    constexpr bool can_stage = (T::kEPC == 8 && (size_t)EpiLds<WP, CT>::kStatBytes + stage_b <= 48 * 1024);
-    constexpr size_t fold_b = (size_t)WC * WP * 64 * 64;
-    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (stage_b > fold_b ? stage_b : fold_b);
-    constexpr size_t smem_base = (can_stage && smem_e > smem_k) ? smem_e : smem_k;
-    size_t smem = smem_base;
-    a.gs_aff_off = (int)smem_base;
-    if (a.gs_count > 0) {
-        if (!GS) return SY_ERR_UNSUPPORTED;
-        smem += (size_t)32 * CT;                                // BatchNorm affine of the tile's channels, parked for the whole kernel
-        // the BatchNorm-backward fusion lives in the staged write-out pass: refuse configurations that do not take it
-        // (the caller falls back to sy_bn_silu_bwd_reduce) instead of silently writing un-multiplied gradients
-        const bool staged = can_stage && !a.y_f32 && a.res == nullptr && (a.Cout & 3) == 0 && (a.ldy & 7) == 0 &&
-                            (reinterpret_cast<unsigned long long>(a.y) & 15ull) == 0 && a.epilogue != SY_EPI_DECODE &&
-                            a.stat_sum == nullptr;
-        if (!staged) return SY_ERR_UNSUPPORTED;
-    }
+    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
+    constexpr size_t smem = (T::kEPC == 8 && smem_e <= 48 * 1024 && smem_e > smem_k) ? smem_e : smem_k;
 #ifndef SY_EMU
     static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST, GS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem_base + 32 * CT)) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST, GS>), grid, dim3(WC * WP * 64), smem, stream, a);
+    SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST>), grid, dim3(WC * WP * 64), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
@@ -1070,18 +894,6 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
     ConvArgs a = a_in;
     const bool fast = (a.Cin % (4 * T::kEPC) == 0) && a.x_extent != 0 && a.w_extent != 0 && a.KH * a.KW <= 32;
     a.s2_classes = (fast && a.mode != SY_CONV_FWD && a.stride == 2 && a.KH >= 2 && a.KW >= 2 && !(a_in.ablate & 4)) ? 1 : 0;
-    // g-space launches (sy_conv_desc::gs) exist for the 16-bit register-staged variants (STG 1 / 5 / 6) only
-    constexpr bool gs_cfg = (T::kEPC == 8) && (STG == 1 || STG == 5 || STG == 6);
-    if (a.gs_count > 0) {
-        if constexpr (gs_cfg) {
-            if constexpr (STG == 5 || STG == 6) {
-                if (fast && a.wfrag != nullptr && a.wfrag_extent != 0) return launch_one<T, WC, WP, TC, TP, STG, 1, 1>(a, stream);
-            }
-            return fast ? launch_one<T, WC, WP, TC, TP, 1, 1, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, 1, 0, 1>(a, stream);
-        } else {
-            return SY_ERR_UNSUPPORTED;
-        }
-    }
     if constexpr (STG == 5 || STG == 6) {   // fragment-packed weights exist only for the FAST traversal; else plain register staging
         if (fast && a.wfrag != nullptr && a.wfrag_extent != 0) return launch_one<T, WC, WP, TC, TP, STG, 1>(a, stream);
         return fast ? launch_one<T, WC, WP, TC, TP, 1, 1>(a, stream) : launch_one<T, WC, WP, TC, TP, 1, 0>(a, stream);

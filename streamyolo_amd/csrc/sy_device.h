@@ -304,17 +304,6 @@ __device__ __forceinline__ float sy_silu(float z) { return z * sy_sigmoid(z); }
 // d silu(z)/dz = s * (1 + z * (1 - s))
 __device__ __forceinline__ float sy_silu_grad(float z) { float s = sy_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
 
-// the same derivative on the hardware reciprocal (v_rcp_f32, ~1 ulp): epilogues whose results are rounded to 16 bits anyway
-#ifdef SY_EMU
-static inline float sy_rcp_fast(float x) { return 1.0f / x; }
-#else
-__device__ __forceinline__ float sy_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
-#endif
-__device__ __forceinline__ float sy_silu_grad_fast(float z) {
-    const float s = sy_rcp_fast(1.0f + sy_exp(-z));
-    return s * (1.0f + z * (1.0f - s));
-}
-
 // compile-time for: f(std::integral_constant<int, I>) for I in [B, E)
 template <int I> struct sy_int { static constexpr int value = I; };
 template <int B, int E, typename F> __device__ __forceinline__ void sy_static_for(F&& f) {

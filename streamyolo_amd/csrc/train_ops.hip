@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
                                                                    typename T::elem* dy, int lddy, long long pixels,
                                                                    int C, int copies, float* dgamma, float* dbeta,
                                                                    long long seg_sum_stride, typename T::elem* dres,
-                                                                   int lddres, int dres_acc, int g_space) {
+                                                                   int lddres, int dres_acc) {
     // fold the replicas of the two reduction sums once per workgroup, cooperatively, through LDS
     __shared__ float s_fold[2 * 1024];
     {   // segment blockIdx.y
@@ -506,8 +506,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) {
             const float yy = T::to_f32(yv.e[j]);
-            // g_space: the data-gradient launches already stored g = da * silu'(z) (sy_conv_desc::gs)
-            const float dz = g_space ? T::to_f32(gv.e[j]) : T::to_f32(gv.e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
+            const float dz = T::to_f32(gv.e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
             o.e[j] = T::from_f32(gi[j] * (dz - m0[j] - (yy - mu[j]) * is[j] * m1[j]));
         }
         o.store(dy + pix * lddy + c0);
@@ -540,9 +539,9 @@ inline int env_cap(const char* name, int dflt) {          // tuning knob (tools/
     return (v != nullptr && atoi(v) > 0) ? atoi(v) : dflt;
 }
 
-inline int row_grid(long long pixels, int C, int e, int cap) {
+inline int row_grid(long long pixels, int C, int e, int cap, int min_rows_per_thread = 1) {
     const int rows = kBlock / (C / e);
-    long long b = (pixels + rows - 1) / rows;
+    long long b = (pixels + (long long)rows * min_rows_per_thread - 1) / ((long long)rows * min_rows_per_thread);
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
@@ -625,7 +624,8 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
     if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
     static const int cap_apply = env_cap("SY_BN_APPLY_BLOCKS", 4096);
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0, stream,
+    static const int min_rows = env_cap("SY_BN_MIN_ROWS", 1);          // pixel rows per thread at least (small tensors: fewer, longer-lived workgroups)
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg, min_rows), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
 }
@@ -638,7 +638,12 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
     static const int cap_reduce = env_cap("SY_BN_REDUCE_BLOCKS", 1024);
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, cap_reduce / nseg), nseg), dim3(kBlock), 0, stream,
+    // every workgroup ends with 2 C global atomics: a budget of atomics per launch bounds the grid of the wide layers
+    // (512 workgroups x 1024 atomics for C = 512 was the whole kernel time of the 19 x 30 layers)
+    static const int atom_budget = env_cap("SY_BN_REDUCE_ATOMICS", 1 << 30);
+    int cap_r = cap_reduce;
+    if ((long long)cap_r * 2 * C > atom_budget) cap_r = atom_budget / (2 * C) < 32 ? 32 : atom_budget / (2 * C);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, cap_r / nseg > 0 ? cap_r / nseg : 1), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, sums, (long long)pixels, C, copies));
 }
@@ -646,11 +651,10 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
 extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                     const float* shift, const float* mean, const float* invstd, const float* gamma,
                                     const float* sums, int copies, void* dy, int lddy, int64_t pixels, int C,
-                                    float* dgamma, float* dbeta, void* dres, int lddres, int dres_accumulate, int g_space,
-                                    int dtype, int nseg, void* stream) {
+                                    float* dgamma, float* dbeta, void* dres, int lddres, int dres_accumulate, int dtype,
+                                    int nseg, void* stream) {
     if (y == nullptr || da == nullptr || sums == nullptr || dy == nullptr || pixels <= 0 || C <= 0 || copies <= 0 || nseg < 1)
         return SY_ERR_ARG;
-    if (g_space && dres != nullptr) return SY_ERR_ARG;     // a residual branch needs the un-multiplied gradient
     const long long seg_sum_stride = (long long)copies * 2 * C;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
     const int e = epc_of(dtype);
@@ -663,9 +667,9 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
         copies = 1;
     }
     static const int cap_bapply = env_cap("SY_BN_BAPPLY_BLOCKS", 2048);
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg), nseg), dim3(kBlock), 0, stream,
+    static const int min_rows_b = env_cap("SY_BN_MIN_ROWS", 1);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg, min_rows_b), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
-                                       dgamma, dbeta, seg_sum_stride, (typename T::elem*)dres, lddres, dres_accumulate,
-                                       g_space));
+                                       dgamma, dbeta, seg_sum_stride, (typename T::elem*)dres, lddres, dres_accumulate));
 }

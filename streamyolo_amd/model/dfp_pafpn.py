@@ -41,8 +41,12 @@ class DFPPAFPN(nn.Module):
 
     def forward(self, input, buffer=None, mode="off_pipe"):
         if self.training:
-            raise RuntimeError("training runs through YOLOX.forward (one fused forward+backward plan); "
-                               "DFPPAFPN.forward alone is an inference entry point")
+            # stand-alone training-mode call (the first half of the reference's YOLOX.forward, yolox.py:32): batch statistics,
+            # running-statistics updates and an autograd node whose backward runs the HIP backward plan of the backbone.
+            # YOLOX.forward itself uses the single fused forward + loss + backward plan instead (train_engine.train_forward).
+            assert mode == "off_pipe", "on_pipe is an inference mode (dfp_pafpn.py:177-228 runs it under eval)"
+            from ..train_engine import backbone_train_forward
+            return backbone_train_forward(self, input)
         if mode == "off_pipe":
             if input.size()[1] == 3:
                 input = torch.cat([input, input], dim=1)

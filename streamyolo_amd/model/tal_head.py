@@ -50,10 +50,13 @@ class TALHead(nn.Module):
             conv.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
 
     def forward(self, xin, labels=None, imgs=None):
-        """Inference entry point on already-fused FPN features (NCHW tensors).  Training runs through
-        YOLOX.forward, which owns the fused forward+backward plan."""
+        """On already-fused FPN features (NCHW tensors).  eval: decoded predictions; training (`labels` = the (targets,
+        support targets) pair, tal_head.py:152-209): the reference's loss 6-tuple through a head-only forward + loss +
+        backward plan (YOLOX.forward itself runs the single fused plan of the whole model)."""
         if self.training:
-            raise RuntimeError("TALHead training is driven by YOLOX.forward (single fwd+bwd plan)")
+            assert labels is not None
+            from ..train_engine import head_train_forward
+            return head_train_forward(self, xin, labels)
         x0 = xin[0]
         B = x0.shape[0]
         s0 = self.strides[0]

@@ -118,11 +118,9 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None, segments=1, gs=None, gs_segments=1):
+           cout=None, tile=0, wfrag=None, segments=1):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
-    y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc]).
-    gs: up to two BatchNorm-backward fusion ranges (data-gradient launches), each a dict with c0, c1 (output channels),
-    raw (View of the BaseConv's raw output), scale / shift / mean / invstd ([gs_segments][C] tensors), sums, copies."""
+    y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
     d.x, d.w = x.ptr(), w.data_ptr()
     d.scale, d.shift = _p(scale), _p(shift)
@@ -153,16 +151,6 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.w_bytes = w.numel() * w.element_size()
     if wfrag is not None:
         d.wfrag, d.wfrag_bytes = wfrag.data_ptr(), wfrag.numel() * wfrag.element_size()
-    if gs:
-        d.gs_count, d.gs_segments = len(gs), gs_segments
-        for r, g in enumerate(gs):
-            e = d.gs[r]
-            raw = g["raw"]
-            assert raw.bs == raw.H * raw.W * raw.ld and raw.pixels == y.pixels       # dense pixel rows, same pixel grid
-            e.c0, e.c1, e.ldraw, e.copies = g["c0"], g["c1"], raw.ld, g["copies"]
-            e.raw = raw.ptr()
-            e.scale, e.shift, e.mean, e.invstd = (g[k].data_ptr() for k in ("scale", "shift", "mean", "invstd"))
-            e.sums = g["sums"].data_ptr()
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
@@ -320,16 +308,15 @@ def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums, nseg=1):
 
 
 def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None, nseg=1,
-                      dres=None, dres_accumulate=False, g_space=False):
-    """dres: gradient View of the residual input (y = silu(bn(conv)) + res): written (or accumulated) with da in this pass.
-    g_space: `da` holds g = da * silu'(z) and `sums` were filled by the data-gradient launches (conv2d(..., gs=...))."""
+                      dres=None, dres_accumulate=False):
+    """dres: gradient View of the residual input (y = silu(bn(conv)) + res): written (or accumulated) with da in this pass."""
     assert dres is None or (dres.C == y.C and dres.pixels == y.pixels)
     check(_lib.lib().sy_bn_silu_bwd_apply(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
                                           sums.numel() // (2 * y.C * nseg), dy.ptr(), dy.ld, y.pixels // nseg, y.C,
                                           _p(dgamma), _p(dbeta), None if dres is None else dres.ptr(),
-                                          0 if dres is None else dres.ld, 1 if dres_accumulate else 0,
-                                          1 if g_space else 0, y.dtype, nseg, stream_of(y.buf)), "sy_bn_silu_bwd_apply")
+                                          0 if dres is None else dres.ld, 1 if dres_accumulate else 0, y.dtype, nseg,
+                                          stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 
 class PostprocessWorkspace:
@@ -428,12 +415,12 @@ def _time_launches(run, device, launches=4, rounds=2):
     return best
 
 
-def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False, gs=False):
+def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False):
     """Fastest sy_conv2d variant for this problem shape (H, W = INPUT size of the launch), or 0 (the
     library's static heuristic) when tuning is off.  Measured with HIP events on dummy tensors."""
     if not autotune_enabled(device):
         return 0
-    key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats), bool(gs), str(device))
+    key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats), str(device))
     hit = _tile_cache.get(key)
     if hit is not None:
         return hit
@@ -456,9 +443,7 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     cands = list(_TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide" if Cout < 256 else "wide256"])
     if k == 3 and stride == 1 and wf is not None and HALO_TILES:
         # 3x3 stride-1 layers: the halo-resident kernel (csrc/conv3x3_halo.h), tiles of 64 / 128 / 256 channels
-        cands += [t for t in HALO_TILES if not (t == 113 and Cout < 256) and not (t == 116 and Cout > 64)]
-    if gs:   # launches carrying sy_conv_desc::gs exist for the register-staged / weights-in-registers / halo variants only
-        cands = [t for t in cands if 16 <= t < 32 or t >= TILE_WR]
+        cands += [t for t in HALO_TILES if not (t == 116 and Cout > 64)]
     best, best_t = 0, float("inf")
     for t in cands:
         if t >= TILE_WR and wf is None:

@@ -214,30 +214,42 @@ class TrainPlan:
     STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
     TAPE_ON_CPU = True           # the SIMT-emulator test runs replay launch tapes too (same code path as the GPU)
 
-    def __init__(self, model, B, H, W, dtype, device):
+    def __init__(self, model, B, H, W, dtype, device, parts="full", feat_shapes=None):
+        """parts: "full" = YOLOX (backbone + head, the fused forward + loss + backward plan); "backbone" = a DFPPAFPN alone
+        (frames -> fused FPN features, gradients of the features in); "head" = a TALHead alone on given fused features
+        (`feat_shapes` = [(C, H, W)] per level) — the stand-alone training-mode entry points of the sub-modules, which the
+        reference's YOLOX.forward composes (exps/model/yolox.py:32-38)."""
         self.model, self.B, self.H, self.W, self.device = model, B, H, W, device
+        self.parts = parts
         self.dtype = ops.dtype_code(dtype)
         self.tdtype = ops.TORCH_DTYPE[self.dtype]
-        pafpn, head = model.backbone, model.head
+        pafpn = model.backbone if parts == "full" else (model if parts == "backbone" else None)
+        head = model.head if parts == "full" else (model if parts == "head" else None)
         self.head = head
         self.cache = None                    # StagedWeights, built below once the plan's ops exist
         b = _PairBuilder(self.dtype, device)
-        self.f0_cur, cur = build_frame_net(b, pafpn, B, H, W)          # current frame  (dfp_pafpn.py:120-140)
-        self.n_frame_ops = len(b.ops)
-        b.replay = 0
-        self.f0_sup, sup = build_frame_net(b, pafpn, B, H, W)          # support frame  (:145-165), same weights
-        assert len(b.ops) == 2 * self.n_frame_ops and b.replay == len(b.fulls)
-        b.paired = False
-        fused = build_fuse_net(b, pafpn, cur, sup)                      # (:168-170)
+        if pafpn is not None:
+            self.f0_cur, cur = build_frame_net(b, pafpn, B, H, W)          # current frame  (dfp_pafpn.py:120-140)
+            self.n_frame_ops = len(b.ops)
+            b.replay = 0
+            self.f0_sup, sup = build_frame_net(b, pafpn, B, H, W)          # support frame  (:145-165), same weights
+            assert len(b.ops) == 2 * self.n_frame_ops and b.replay == len(b.fulls)
+            b.paired = False
+            fused = build_fuse_net(b, pafpn, cur, sup)                      # (:168-170)
+        else:
+            self.n_frame_ops = 0
+            b.paired = False
+            fused = tuple(b.buf(B, h, w, c) for c, h, w in feat_shapes)
+        self.fused = fused
         self.n_head_start = len(b.ops)
-        self.preds, self.A = build_head_net(b, head, fused)
+        self.preds, self.A = (build_head_net(b, head, fused) if head is not None else ([], 0))
         lvl = 0
         for op in b.ops[self.n_head_start:]:                             # per-level towers end with their PredOp
             op.level = lvl
             lvl += 1 if op.kind == "pred" else 0
         self.hw = [(f.H, f.W) for f in fused]
         self.ops = b.ops
-        self.nc = head.num_classes
+        self.nc = head.num_classes if head is not None else 0
         nch = 5 + self.nc
         self.raw = torch.empty((B, self.A, nch), dtype=torch.float32, device=device)
         self.dpad = torch.zeros((B, self.A, 16), dtype=self.tdtype, device=device)
@@ -293,11 +305,6 @@ class TrainPlan:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
         self.cache = StagedWeights(self.ops, self.dtype, device)
-        self._plan_gspace()
-        self._gs_producers = {}
-        for op in self.ops:
-            if op.kind == "conv" and op.gspace:
-                self._gs_producers.setdefault(self._vkey(op.y), []).append(op)
         self.loss_ws = None
         self.run_table = None
         self.grads = _GradSpace()
@@ -317,12 +324,15 @@ class TrainPlan:
         self.on_bucket = None                 # TrainStep: callable(k, main_stream, side_stream) -> starts the bucket's all-reduce
         self.bn_mods = [op.mod.bn for op in convs]
         self.stem_scratch = None
-        self.pred_scratch = torch.zeros((2, 8, int(256 * head.width)), dtype=torch.float32, device=device)
+        self.pred_scratch = torch.zeros((2, 8, int(256 * head.width)), dtype=torch.float32, device=device) \
+            if head is not None else None
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, x):
-        """x [B,6,H,W] float on device -> raw [B, A, 5+nc] fp32 (plan-owned)."""
-        x = x.float().contiguous()
+        """x [B,6,H,W] float on device -> raw [B, A, 5+nc] fp32 (plan-owned).  parts == "backbone": returns the fused
+        feature views instead; parts == "head": x = the three fused feature tensors."""
+        if self.parts != "head":
+            x = x.float().contiguous()
         sig = tuple(p.data_ptr() for p in self.params)
         if sig != self._param_sig or not self.cache.valid():     # a parameter was re-allocated (.to(), load with assign)
             self._param_sig = sig
@@ -331,7 +341,11 @@ class TrainPlan:
                 self.cache = StagedWeights(self.ops, self.dtype, self.device)
         self.cache.refresh()                                     # this step's weights -> MFMA operand layouts
         self.stat_arena.zero_()
-        if isinstance(x, FramePairsU8):                          # uint8 HWC frames: mirror / letterbox / resize / pack in one launch
+        if self.parts == "head":                                 # x = the three fused FPN features (NCHW-shaped tensors)
+            for v, t in zip(self.fused, x):
+                assert tuple(t.shape) == (v.N, v.C, v.H, v.W)
+                v.set_nchw(t.detach())
+        elif isinstance(x, FramePairsU8):                        # uint8 HWC frames: mirror / letterbox / resize / pack in one launch
             x.pack_focus(self.f0_cur, self.f0_sup)
         else:
             ops.focus_pack(x, 0, self.f0_cur)
@@ -352,7 +366,7 @@ class TrainPlan:
         if counts:
             ts, cs = zip(*counts.values())
             torch._foreach_add_(list(ts), list(cs))
-        return self.raw
+        return self.raw if self.head is not None else self.fused
 
     def _forward_ops(self):
         """The op loop in launch order.  The per-frame network runs ONCE over both frames (2B images per launch, one
@@ -401,8 +415,6 @@ class TrainPlan:
         u_sum, u_sq, _, (scale, shift, mean, invstd) = a.unit
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
                    wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
-        # (finalize folded into every workgroup of the apply pass was measured at 5.5 ms per l step against 0.8 + 2.25 ms for
-        #  the two launches — 64 x C replica loads per workgroup, profiles/r02/b_* — so the ~5 us finalize launch stays)
         mom = bn.momentum if bn.momentum is not None else 0.1
         ops.bn_finalize(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, mom, None, None, scale, shift, mean, invstd,
                         nseg=2)
@@ -508,9 +520,9 @@ class TrainPlan:
             ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
             scale, shift, mean, invstd = op.aff
+            mom = bn.momentum if bn.momentum is not None else 0.1
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
-            mom = bn.momentum if bn.momentum is not None else 0.1
             ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
                             None, None, scale, shift, mean, invstd)
             ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
@@ -541,17 +553,24 @@ class TrainPlan:
         return out, d_raw
 
     # ------------------------------------------------------------------------------------------------
-    def backward(self, d_raw):
-        """d_raw [B, A, 5+nc] fp32 -> parameter gradients accumulated into self.arena (zeroed here)."""
+    def backward(self, d_raw, d_fused=None):
+        """d_raw [B, A, 5+nc] fp32 -> parameter gradients accumulated into self.arena (zeroed here).
+        parts == "backbone": d_raw is None and d_fused = gradients of the three fused features (NCHW-shaped tensors);
+        parts == "head": afterwards self.fused_grads() holds the gradients of the fused inputs."""
         self.arena.zero_()
         self.bwd_arena.zero_()
         nc = self.nc
-        # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels
-        self.dpad[..., 0:5] = d_raw[..., 0:5]
-        self.dpad[..., 8:8 + nc] = d_raw[..., 5:]
-        self._run("bwd", lambda: self._backward_ops(d_raw), key=d_raw.data_ptr())
+        if self.head is not None:
+            # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels
+            self.dpad[..., 0:5] = d_raw[..., 0:5]
+            self.dpad[..., 8:8 + nc] = d_raw[..., 5:]
+        self._seed = d_fused
+        self._run("bwd", lambda: self._backward_ops(d_raw), key=None if d_raw is None else d_raw.data_ptr())
         self.tuned = True                                            # kernels are tuned after the first full step
         return self.arena
+
+    def fused_grads(self):
+        return tuple(self.grads.view(f).nchw() for f in self.fused)
 
     # ---- gradient buckets (data-parallel overlap) -----------------------------------------------------------
     # The arena is in parameter order = forward order, the backward walk runs it back to front, so contiguous
@@ -563,94 +582,6 @@ class TrainPlan:
     def _backward_sequence(self):
         nf = self.n_frame_ops
         return list(reversed(self.ops[2 * nf:])) + [self.ops[i] for i in reversed(range(nf))]
-
-    # ---- BatchNorm-backward fusion ("g-space") ---------------------------------------------------------------
-    # For a BaseConv output a = silu(bn(raw)) whose only consumers are convolutions, the data-gradient launches of those
-    # consumers store g = da * silu'(z) and accumulate the two BatchNorm reduction sums themselves (sy_conv_desc::gs):
-    # the separate sy_bn_silu_bwd_reduce pass (one read of da and raw per BaseConv, 128 launches per l step) disappears.
-    # Not eligible (they keep the reduce pass): outputs with a residual add or used AS a residual (the shortcut branch
-    # needs the un-multiplied gradient), outputs read by resize / SPP (their backward kernels write plain gradients),
-    # fp32 plans (the fusion lives in the 16-bit staged write-out pass).
-    FUSE_REDUCE = os.environ.get("STREAMYOLO_FUSE_REDUCE", "1") != "0"
-
-    @staticmethod
-    def _vkey(v):
-        return (id(v.root[0]), v.root[1]) if v.root is not None else (id(v.buf), 0)
-
-    @staticmethod
-    def _overlap(a, b):
-        return TrainPlan._vkey(a) == TrainPlan._vkey(b) and a.c_off < b.c_off + b.C and b.c_off < a.c_off + a.C
-
-    def _plan_gspace(self):
-        convs = [op for op in self.ops if op.kind == "conv"]
-        for op in convs:
-            op.gspace, op.gs_out = False, []
-        if not self.FUSE_REDUCE or self.dtype == ops.DT_F32:
-            return
-        inputs = []                                              # (view, kind, consumer op)
-        for op in self.ops:
-            if op.kind == "conv":
-                inputs.append((op.x, "conv" if op.need_dx else "nodx", op))
-                if op.res is not None:
-                    inputs.append((op.res, "res", op))
-            elif op.kind == "pred":
-                inputs += [(op.reg_x, "pred", op), (op.cls_x, "pred", op)]
-            elif op.kind == "resize":
-                inputs.append((op.src, "other", op))
-            elif op.kind == "spp":
-                inputs.append((op.v, "other", op))
-        cand = {}
-        for P in convs:
-            if P.res is not None or P.y.C % 8 or P.y.c_off % 8:
-                continue
-            users = [(v, k, c) for v, k, c in inputs if self._overlap(v, P.y)]
-            if not users or any(k not in ("conv", "pred") for _, k, _ in users):
-                continue
-            # every consumer's input view must contain the whole output range, 16-byte aligned, ld a multiple of 8
-            if all(v.c_off <= P.y.c_off and P.y.c_off + P.y.C <= v.c_off + v.C and v.ld % 8 == 0 and v.c_off % 8 == 0
-                   for v, _, _ in users):
-                cand[id(P)] = (P, users)
-        # a launch carries at most two ranges: demote the producers of any consumer view that would need more
-        changed = True
-        while changed:
-            changed = False
-            per_view = {}
-            for P, users in cand.values():
-                for v, k, c in users:
-                    per_view.setdefault((id(c), id(v)), []).append(P)
-            for lst in per_view.values():
-                if len(lst) > 2:
-                    for P in lst[2:]:
-                        if id(P) in cand:
-                            del cand[id(P)]
-                            changed = True
-        for P, users in cand.values():
-            P.gspace = True
-        # the two frames of a pair share their launches: a layer is fused only if both frames' outputs qualify (the
-        # current frame's PAN outputs are the DFP residual, the support frame's are not)
-        nf = self.n_frame_ops
-        for i in range(nf):
-            a, b2 = self.ops[i], self.ops[nf + i]
-            if a.kind == "conv" and a.gspace != b2.gspace:
-                a.gspace = b2.gspace = False
-        self.n_gspace = sum(1 for op in convs if op.gspace)
-
-    def _gs_for(self, xview, pair):
-        """sy_conv_desc::gs ranges of a data-gradient launch whose output is the gradient of activation view `xview`."""
-        out = []
-        for P in self._gs_producers.get(self._vkey(xview), ()):
-            if not (P.gspace and self._overlap(xview, P.y)):
-                continue
-            c0 = P.y.c_off - xview.c_off
-            if pair:
-                _, _, u_bsum, (scale, shift, mean, invstd) = P.unit
-                raw, sums = P.yraw.pair(), u_bsum
-            else:
-                (scale, shift, mean, invstd), raw, sums = P.aff, P.yraw, P.bsum
-            out.append(dict(c0=c0, c1=c0 + P.y.C, raw=raw, scale=scale, shift=shift, mean=mean, invstd=invstd, sums=sums,
-                            copies=self.BWD_COPIES))
-        assert len(out) <= 2
-        return out or None
 
     def _build_buckets(self):
         last = {}
@@ -685,6 +616,11 @@ class TrainPlan:
         G.reset()
         self.ring_i = 0
         nf = self.n_frame_ops
+        if self.head is None:                                    # backbone alone: the feature gradients come from the caller
+            for f, g in zip(self.fused, self._seed):
+                gv, acc = G.target(f)
+                assert not acc
+                self._py(lambda gv=gv, g=g: gv.set_nchw(g))
         self._bucket_marks(-1)                                   # ranges no kernel writes (unused parameters)
         for pos, a in enumerate(self._backward_sequence()):      # head, DFP fusion, then the per-frame network
             if pos < len(self.ops) - 2 * nf:
@@ -731,9 +667,9 @@ class TrainPlan:
         d_ro = View(self.dpad, B, op.reg_x.H, op.reg_x.W, 8, 16, op.a0 * 16, bs=A * 16)
         d_c = View(self.dpad, B, op.reg_x.H, op.reg_x.W, nc, 16, op.a0 * 16 + 8, bs=A * 16)
         g_r, acc_r = G.target(op.reg_x)
-        ops.conv2d(d_ro, w_ro_t, g_r, 1, 1, mode=CONV_DGRAD, accumulate=acc_r, gs=self._gs_for(op.reg_x, False))
+        ops.conv2d(d_ro, w_ro_t, g_r, 1, 1, mode=CONV_DGRAD, accumulate=acc_r)
         g_c, acc_c = G.target(op.cls_x)
-        ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c, gs=self._gs_for(op.cls_x, False))
+        ops.conv2d(d_c, w_c_t, g_c, 1, 1, mode=CONV_DGRAD, accumulate=acc_c)
         cin = op.reg_x.C
 
         sc = self.pred_scratch
@@ -766,11 +702,9 @@ class TrainPlan:
         dY = G.view(op.y)
         dres, acc = (None, False) if op.res is None else G.target(op.res)    # y = silu(bn(conv)) + res: dres (+)= dY
         scale, shift, mean, invstd = op.aff
-        if not op.gspace:                                        # g-space: the consumers' data-gradient launches did it
-            ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
+        ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
         ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, bn.weight, op.bsum, dyraw,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], dres=dres, dres_accumulate=acc,
-                              g_space=op.gspace)
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], dres=dres, dres_accumulate=acc)
 
     def _wgrad(self, op, x, dyraw):
         w = op.mod.conv.weight
@@ -818,26 +752,21 @@ class TrainPlan:
             dres2 = dra.pair()                                       # written by the BN backward apply pass below
         _, _, u_bsum, (scale, shift, mean, invstd) = a.unit
         raw2 = a.yraw.pair()
-        assert a.gspace == b2.gspace
-        if not a.gspace:
-            ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
+        ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
         ops.bn_silu_bwd_apply(raw2, dY2, scale, shift, mean, invstd, bn.weight, u_bsum, dy2,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2, dres=dres2, dres_accumulate=acca,
-                              g_space=a.gspace)
+                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2, dres=dres2, dres_accumulate=acca)
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot)
         if a.need_dx:
             dxa, acca = G.target(a.x)
             dxb, accb = G.target(b2.x)
             assert acca == accb and dxa.root[0] is dxb.root[0]
-            gs = self._gs_for(a.x.pair(), True)
             t = a._tiles.get("dgrad2")
             if t is None:
-                t = ops.tuned_tile(CONV_DGRAD, dy2.dtype, 2 * N, H, W, C, a.x.C, a.k, a.stride, self.device, gs=bool(gs))
+                t = ops.tuned_tile(CONV_DGRAD, dy2.dtype, 2 * N, H, W, C, a.x.C, a.k, a.stride, self.device)
                 a._tiles["dgrad2"] = t
             ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
                        mode=CONV_DGRAD, accumulate=acca, tile=t,
-                       wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None,
-                       gs=gs, gs_segments=2)
+                       wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
 
     def _conv_backward(self, op):
         G = self.grads
@@ -848,16 +777,10 @@ class TrainPlan:
         self._on_side(lambda: self._wgrad(op, op.x, dyraw), slot)
         if op.need_dx:
             dx, acc = G.target(op.x)
-            gs = self._gs_for(op.x, False)
-            t = op._tiles.get("dgrad1")
-            if t is None:
-                y = op.y
-                t = ops.tuned_tile(CONV_DGRAD, y.dtype, y.N, y.H, y.W, y.C, op.x.C, op.k, op.stride, self.device, gs=bool(gs))
-                op._tiles["dgrad1"] = t
+            t = op.tile("dgrad")
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
                        mode=CONV_DGRAD, accumulate=acc, tile=t,
-                       wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None,
-                       gs=gs)
+                       wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None)
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, x, targets, iters=2, detail=False):
@@ -955,6 +878,89 @@ class _PlanFunction(torch.autograd.Function):
             outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
             o += p.numel()
         return (None, None, None, None) + tuple(outs)
+
+
+class _BackboneFunction(torch.autograd.Function):
+    """DFPPAFPN.forward in training mode: frames -> the three fused FPN features, batch statistics (two BatchNorm calls per
+    shared module, current frame first) and running-statistics updates as in the reference (dfp_pafpn.py:109-175); backward
+    takes the feature gradients through the HIP backward plan."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.plan = plan
+        fused = plan.forward(x)
+        return tuple(f.buf.clone().permute(0, 3, 1, 2) for f in fused)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        plan = ctx.plan
+        arena = plan.backward(None, d_fused=[g.float() for g in gouts]).clone()
+        outs, o = [], 0
+        for p in plan.params:
+            outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
+            o += p.numel()
+        return (None, None) + tuple(outs)
+
+
+class _HeadFunction(torch.autograd.Function):
+    """TALHead.forward(xin, labels, imgs) in training mode: towers + predictions + SimOTA / Trend-Aware loss on given fused
+    features; backward returns the gradients of the three features and of the head's parameters."""
+
+    @staticmethod
+    def forward(ctx, plan, labels, support, f0, f1, f2, *params):
+        ctx.plan = plan
+        plan.forward((f0, f1, f2))
+        out, d_raw = plan.loss(labels, support)
+        ctx.d_raw = d_raw
+        stats = torch.stack([out[k] for k in ("iou_loss", "l1_loss", "conf_loss", "cls_loss", "num_fg")]).clone()
+        ctx.mark_non_differentiable(stats)
+        return out["total_loss"].clone(), stats
+
+    @staticmethod
+    def backward(ctx, g_total, _g_stats):
+        plan = ctx.plan
+        arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
+        gf = tuple(g.to(plan.tdtype) for g in plan.fused_grads())
+        outs, o = [], 0
+        for p in plan.params:
+            outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
+            o += p.numel()
+        return (None, None, None) + gf + tuple(outs)
+
+
+def backbone_train_forward(pafpn, x):
+    """DFPPAFPN.forward(input, mode='off_pipe') with self.training (what YOLOX.forward calls first, yolox.py:32)."""
+    if x.size()[1] == 3:
+        x = torch.cat([x, x], dim=1)
+    assert x.size()[1] == 6
+    dt = compute_dtype_for(pafpn, x)
+    B, _, H, W = x.shape
+    key = ("train-backbone", B, H, W, dt, str(x.device))
+    plan = pafpn._plans.plans.get(key)
+    if plan is None:
+        plan = pafpn._plans.plans[key] = TrainPlan(pafpn, B, H, W, dt, x.device, parts="backbone")
+    return _BackboneFunction.apply(plan, x, *plan.params)
+
+
+def head_train_forward(head, xin, labels):
+    """TALHead.forward(xin, labels, imgs) with self.training: the reference's 6-tuple (loss, 5 * iou, conf, cls, l1, num_fg /
+    num_gt) in ITS order (tal_head.py:463-470; YOLOX.forward unpacks it at yolox.py:36-38)."""
+    x0 = xin[0]
+    dt = compute_dtype_for(head, x0)
+    shapes = tuple((int(t.shape[1]), int(t.shape[2]), int(t.shape[3])) for t in xin)
+    key = ("train-head", int(x0.shape[0]), shapes, dt, str(x0.device))
+    plan = head._plans.plans.get(key)
+    if plan is None:
+        plan = head._plans.plans[key] = TrainPlan(head, int(x0.shape[0]), 0, 0, dt, x0.device, parts="head", feat_shapes=shapes)
+    lab, sup = split_targets_head(head, labels)
+    total, stats = _HeadFunction.apply(plan, lab, sup, xin[0], xin[1], xin[2], *plan.params)
+    return total, stats[0], stats[2], stats[3], stats[1], stats[4]
+
+
+def split_targets_head(head, targets):
+    if getattr(head, "single_labels", False) and torch.is_tensor(targets):
+        return targets, targets
+    return targets
 
 
 def split_targets(model, targets):

@@ -390,91 +390,3 @@ def test_decode_is_invertible(backend):
         grid = torch.stack([gx, gy], -1).reshape(1, H * W, 2).float()
         inv = torch.cat([dec[..., 0:2] / stride - grid, (dec[..., 2:4] / stride).log(), torch.logit(dec[..., 4:5])], -1)
         assert (inv - raw[..., :5]).abs().max() < 2e-4 * max(1.0, float(raw[..., :5].abs().max()))
-
-
-@pytest.mark.parametrize("tile", [0, 19, 23, 86, 87, 102, 20, 24, 112, 115])
-@pytest.mark.parametrize("nseg,accumulate,k,stride", [(1, False, 3, 1), (2, True, 1, 1), (2, False, 3, 2), (2, True, 3, 1)])
-def test_dgrad_gspace_epilogue_replaces_the_reduce_pass(backend, tile, nseg, accumulate, k, stride):
-    """sy_conv_desc::gs: a data-gradient launch that stores g = da * silu'(bn(raw)) and accumulates the BatchNorm
-    backward sums, against the unfused sequence (plain dgrad -> sy_bn_silu_bwd_reduce): same sums, g = da * silu'(z) of
-    the stored da up to one 16-bit rounding, two ranges with different producers, frame-pair segments, accumulation
-    onto an earlier gradient, stride-2 parity classes; and the fused sums + g drive sy_bn_silu_bwd_apply(g_space) to the
-    same dy as the unfused pair."""
-    from streamyolo_amd.model.packing import pack_conv_weight, pack_conv_weight_frag
-    if tile >= 112 and (k != 3 or stride != 1):
-        pytest.skip("the halo kernel is 3x3 stride 1")
-    dt = "bf16"
-    g = torch.Generator().manual_seed(tile * 7 + nseg)
-    N, cdy, cx = 2 * nseg, 32, 72                                  # dgrad input dy [N,Hy,Wy,cdy] -> output dx [N,H,W,cx]
-    Hy, Wy = 9, 11
-    H, W = (Hy, Wy) if stride == 1 else (2 * Hy - 1, 2 * Wy)       # forward conv: x [H,W] -> y [Hy,Wy]
-    assert ops.conv_out_size(H, k, stride) == Hy and ops.conv_out_size(W, k, stride) == Wy
-    dev = backend
-    code = ops.dtype_code(dt)
-    dy = View.alloc(N, Hy, Wy, cdy, dt, dev); dy.set_nchw(torch.randn(N, cdy, Hy, Wy, generator=g).to(dev))
-    w = torch.randn(cdy, cx, k, k, generator=g) / (cdy * k * k) ** 0.5      # forward weight [Cout=cdy][Cin=cx]
-    wt = pack_conv_weight(w, code, transpose=True).to(dev)
-    wf = pack_conv_weight_frag(wt, k)
-    # the dgrad output covers two producers: channels [0, 40) of producer A, [40, 72) of producer B (each BN'd)
-    ranges = [(0, 40), (40, 72)]
-    copies = 2
-    prods = []
-    for c0, c1 in ranges:
-        C = c1 - c0
-        raw = View.alloc(N, H, W, C, dt, dev); raw.set_nchw((torch.randn(N, C, H, W, generator=g) * 1.5).to(dev))
-        aff = [(torch.rand(nseg * C, generator=g) + 0.5).to(dev), (torch.randn(nseg * C, generator=g) * 0.3).to(dev),
-               (torch.randn(nseg * C, generator=g) * 0.2).to(dev), (torch.rand(nseg * C, generator=g) + 0.5).to(dev)]
-        prods.append((raw, aff))
-    base = View.alloc(N, H, W, cx + 8, dt, dev, zero=True)
-    base.buf.copy_((torch.randn(base.buf.shape, generator=g) * 0.5).to(dev))
-    # ---- unfused: dgrad (+= earlier gradient) into da, then the reduce pass per producer
-    da = View(base.buf.clone(), N, H, W, cx, cx + 8, 8)
-    ops.conv2d(dy, wt, da, k, stride, mode=ops.CONV_DGRAD, accumulate=accumulate, tile=tile, wfrag=wf if tile >= 80 else None)
-    early = View(base.buf.clone(), N, H, W, cx, cx + 8, 8)
-    sums_ref = []
-    for (c0, c1), (raw, aff) in zip(ranges, prods):
-        s = torch.zeros(nseg * copies * 2 * (c1 - c0), device=dev)
-        # this launch's contribution only: the earlier gradient's sums were added by whoever wrote it
-        contrib = View.alloc(N, H, W, c1 - c0, dt, dev)
-        d_new = da.slice(c0, c1 - c0).nchw() - (early.slice(c0, c1 - c0).nchw() if accumulate else 0.0)
-        contrib.set_nchw(d_new)
-        ops.bn_silu_bwd_reduce(raw, contrib, *aff, s, nseg=nseg)
-        sums_ref.append(s.view(nseg, copies, 2, c1 - c0).sum(1))
-    # ---- fused
-    gs = [dict(c0=c0, c1=c1, raw=raw, scale=aff[0], shift=aff[1], mean=aff[2], invstd=aff[3],
-               sums=torch.zeros(nseg * copies * 2 * (c1 - c0), device=dev), copies=copies)
-          for (c0, c1), (raw, aff) in zip(ranges, prods)]
-    gv = View(base.buf.clone(), N, H, W, cx, cx + 8, 8)
-    ops.conv2d(dy, wt, gv, k, stride, mode=ops.CONV_DGRAD, accumulate=accumulate, tile=tile, wfrag=wf if tile >= 80 else None,
-               gs=gs, gs_segments=nseg)
-    assert torch.equal(gv.buf[..., :8], base.buf[..., :8])                   # neighbouring channels untouched
-    for r, ((c0, c1), (raw, aff)) in enumerate(zip(ranges, prods)):
-        C = c1 - c0
-        got = gs[r]["sums"].view(nseg, copies, 2, C).sum(1)
-        scale = float(sums_ref[r].abs().max())
-        assert float((got - sums_ref[r]).abs().max()) < 2e-2 * scale, (r, float((got - sums_ref[r]).abs().max()), scale)
-        # g = (this launch's da) * silu'(z) [+ earlier gradient]
-        y = raw.nchw().float()
-        sc, sh = aff[0].view(nseg, C), aff[1].view(nseg, C)
-        seg = torch.arange(N, device=dev) // (N // nseg)
-        z = y * sc[seg][:, :, None, None] + sh[seg][:, :, None, None]
-        sg = torch.sigmoid(z)
-        dnew = da.slice(c0, C).nchw() - (early.slice(c0, C).nchw() if accumulate else 0.0)
-        want = dnew * (sg * (1 + z * (1 - sg))) + (early.slice(c0, C).nchw() if accumulate else 0.0)
-        gg = gv.slice(c0, C).nchw()
-        assert float((gg - want).abs().max()) < 3e-2 * float(want.abs().max()), r
-    # ---- and the apply pass consumes g-space input: same dy as the unfused reduce + apply (first-write case)
-    if not accumulate:
-        (c0, c1), (raw, aff) = ranges[0], prods[0]
-        C = c1 - c0
-        gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
-        s_unf = torch.zeros(nseg * copies * 2 * C, device=dev)
-        da0 = View.alloc(N, H, W, C, dt, dev); da0.set_nchw(da.slice(c0, C).nchw())
-        ops.bn_silu_bwd_reduce(raw, da0, *aff, s_unf, nseg=nseg)
-        dy_a, dy_b = View.alloc(N, H, W, C, dt, dev), View.alloc(N, H, W, C, dt, dev)
-        dg_a, db_a, dg_b, db_b = (torch.zeros(C, device=dev) for _ in range(4))
-        ops.bn_silu_bwd_apply(raw, da0, *aff, gamma, s_unf, dy_a, dg_a, db_a, nseg=nseg)
-        g0 = View.alloc(N, H, W, C, dt, dev); g0.set_nchw(gv.slice(c0, C).nchw())
-        ops.bn_silu_bwd_apply(raw, g0, *aff, gamma, gs[0]["sums"], dy_b, dg_b, db_b, nseg=nseg, g_space=True)
-        assert _rel(dy_b.nchw(), dy_a.nchw()) < 3e-2
-        assert _rel(dg_b, dg_a) < 2e-2 and _rel(db_b, db_a) < 2e-2
