@@ -539,9 +539,9 @@ inline int env_cap(const char* name, int dflt) {          // tuning knob (tools/
     return (v != nullptr && atoi(v) > 0) ? atoi(v) : dflt;
 }
 
-inline int row_grid(long long pixels, int C, int e, int cap, int min_rows_per_thread = 1) {
+inline int row_grid(long long pixels, int C, int e, int cap) {
     const int rows = kBlock / (C / e);
-    long long b = (pixels + (long long)rows * min_rows_per_thread - 1) / ((long long)rows * min_rows_per_thread);
+    long long b = (pixels + rows - 1) / rows;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
@@ -624,8 +624,7 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
     if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
     static const int cap_apply = env_cap("SY_BN_APPLY_BLOCKS", 4096);
-    static const int min_rows = env_cap("SY_BN_MIN_ROWS", 1);          // pixel rows per thread at least (small tensors: fewer, longer-lived workgroups)
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg, min_rows), nseg), dim3(kBlock), 0, stream,
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
 }
@@ -638,12 +637,8 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
     static const int cap_reduce = env_cap("SY_BN_REDUCE_BLOCKS", 1024);
-    // every workgroup ends with 2 C global atomics: a budget of atomics per launch bounds the grid of the wide layers
-    // (512 workgroups x 1024 atomics for C = 512 was the whole kernel time of the 19 x 30 layers)
-    static const int atom_budget = env_cap("SY_BN_REDUCE_ATOMICS", 1 << 30);
-    int cap_r = cap_reduce;
-    if ((long long)cap_r * 2 * C > atom_budget) cap_r = atom_budget / (2 * C) < 32 ? 32 : atom_budget / (2 * C);
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, cap_r / nseg > 0 ? cap_r / nseg : 1), nseg), dim3(kBlock), 0, stream,
+    // (fewer workgroups = fewer of the 2 C closing atomics each was tried: 5.7 instead of 3.3 ms per l step at a 64 K atomic budget)
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, cap_reduce / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, sums, (long long)pixels, C, copies));
 }
@@ -667,8 +662,7 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
         copies = 1;
     }
     static const int cap_bapply = env_cap("SY_BN_BAPPLY_BLOCKS", 2048);
-    static const int min_rows_b = env_cap("SY_BN_MIN_ROWS", 1);
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg, min_rows_b), nseg), dim3(kBlock), 0, stream,
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
                                        dgamma, dbeta, seg_sum_stride, (typename T::elem*)dres, lddres, dres_accumulate));
