@@ -431,6 +431,152 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
     wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
 }
 
+// ---- 3x3 stride-1 "all taps" variant (16-bit types) ------------------------------------------------------------
+// The transpose-read kernel above treats every (tap, ci) row tile as its own GEMM tile: a 3x3 layer re-stages the x operand
+// nine times (once per tap) and the dy operand Cin * 9 / 128 times.  Here a workgroup owns 32 input channels x ALL NINE taps
+// (288 k-rows) x 128 output channels; a slab = 32 consecutive pixels of ONE image row, and the x operand of the slab is the
+// 3 x 34 halo window around them, parked ONCE in LDS (row-major [pixel][16 channels] subtiles, LDS-DMA): the nine taps are
+// nine pixel offsets ((kh * 34 + kw) * 32 bytes) of the same ds_read_b64_tr_b16 gather.  Per slab: 14.5 KB staged for 72
+// MFMAs instead of 16 KB for 32.  Wave w owns output channels [32 w, 32 w + 32) and all nine taps: 9 accumulator tiles.
+constexpr int kHaloPix = 3 * 34;                  // halo pixels of a slab (3 rows x (32 + 2))
+constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (102 used) x 16 channels + bank padding
+
+template <typename T, int STG>
+__global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
+    constexpr int CT = 128, CIT = 32;
+    constexpr int SB = CT / 16;                   // dy subtiles per slab
+    constexpr int STAGE = 2 * kXSub + SB * kSubPitch;
+    static_assert(T::kEPC == 8, "16-bit elements");
+    SY_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = sy_uniform(tid >> 6);
+    const sy_block_id bid = sy_xcd_block_id();
+    const int ci0 = bid.x * CIT;
+    const int c0 = bid.y * CT;
+    const int wsegs = (p.Wo + 31) >> 5;
+    const int slabs_total = p.N * p.Ho * wsegs;
+    const int slab0 = bid.z * p.slabs_per_split;
+    int nslab = p.slabs_per_split;
+    if (slab0 + nslab > slabs_total) nslab = slabs_total - slab0;
+    if (nslab <= 0) return;
+
+    // ---- DMA assignment per slab: wave w issues x instructions {w, w + 4} (subtile j >> 2, 32-pixel quarter j & 3 of the
+    //      flattened 3 x 34 window) and dy subtiles {w, w + 4}; lane -> (pixel lane >> 1, 16-byte channel half lane & 1)
+    const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
+    const sy_buffer bufdy = sy_make_buffer(p.dy, p.dy_extent);
+    const sy_lds_base_t lds0 = sy_lds_base(smem);
+    const int half8 = (lane & 1) * 8;
+    int x_hy[2], x_hx[2], x_c[2];
+    bool x_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wv + 4 * i;
+        const int pp = (j & 3) * 32 + (lane >> 1);             // flattened halo pixel
+        x_ok[i] = pp < kHaloPix;
+        x_hy[i] = pp / 34;
+        x_hx[i] = pp - x_hy[i] * 34;
+        x_c[i] = ci0 + (j >> 2) * 16 + half8;
+    }
+    int cur_n, cur_h, cur_ws;                                   // slab cursor of the NEXT slab to issue
+    {
+        const int per_img = p.Ho * wsegs;
+        cur_n = slab0 / per_img;
+        const int rem = slab0 - cur_n * per_img;
+        cur_h = rem / wsegs;
+        cur_ws = rem - cur_h * wsegs;
+    }
+    int issued = 0, stage_w = 0;
+    auto issue_slab = [&]() {
+        const unsigned stage = (unsigned)(stage_w * STAGE);
+        const int w0 = cur_ws * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wv + 4 * i;
+            const int hi = cur_h - 1 + x_hy[i], wi = w0 - 1 + x_hx[i];
+            const bool ok = x_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int off = cur_n * (int)p.xbs + (hi * p.W + wi) * p.ldx + x_c[i];
+            sy_glds16_buf_at(bufx, ok ? (unsigned)(off * 2) : 0xFFFFFFFFu, lds0,
+                             stage + (unsigned)((j >> 2) * kXSub + (j & 3) * 1024));
+        }
+        const int wo = w0 + (lane >> 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wv + 4 * i;
+            const int co = c0 + j * 16 + half8;
+            const bool ok = wo < p.Wo && co < p.Cout;
+            const int off = cur_n * (int)p.dybs + (cur_h * p.Wo + wo) * p.lddy + co;
+            sy_glds16_buf_at(bufdy, ok ? (unsigned)(off * 2) : 0xFFFFFFFFu, lds0, stage + (unsigned)(2 * kXSub + j * kSubPitch));
+        }
+        if (++cur_ws == wsegs) { cur_ws = 0; if (++cur_h == p.Ho) { cur_h = 0; ++cur_n; } }
+        ++issued;
+        stage_w = (stage_w + 1 == STG) ? 0 : stage_w + 1;
+    };
+    auto wait_slab = [&](int ahead) {             // at most `ahead` later slabs of this wave's loads still in flight
+        if (ahead >= 3) sy_wait_vmcnt<12>();
+        else if (ahead == 2) sy_wait_vmcnt<8>();
+        else if (ahead == 1) sy_wait_vmcnt<4>();
+        else sy_wait_vmcnt<0>();
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // fragment gather (see conv_wgrad_tr_kernel): lane (g = lane >> 5, parity = (lane >> 4) & 1, i = lane & 15) addresses pixel
+    // row 8 g + (i >> 2) (+ 4 for the second half of its 8 k-values), channel quad i & 3 of subtile `parity`
+    const int x_lane = ((lane >> 4) & 1) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+    const int y_lane = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+
+    for (int j = 0; j < STG - 1 && j < nslab; ++j) issue_slab();
+    int stage_r = 0;
+    for (int s = 0; s < nslab; ++s) {
+        wait_slab(issued - s - 1);
+        sy_barrier();                             // slab s complete for every wave; everyone is past slab s - 1
+        if (issued < nslab) issue_slab();
+        const unsigned char* const xb = smem + stage_r * STAGE + x_lane;
+        const unsigned char* const yb = smem + stage_r * STAGE + 2 * kXSub + (wv * 2) * kSubPitch + y_lane;
+        stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint2 blo = sy_lds_read_tr16(yb + ks * 512), bhi = sy_lds_read_tr16(yb + ks * 512 + 128);
+            const uint4 b = make_uint4(blo.x, blo.y, bhi.x, bhi.y);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const unsigned char* ptr = xb + ((t / 3) * 34 + (t % 3)) * 32 + ks * 512;
+                const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
+                acc[t] = sy_mfma_group(T(), make_uint4(lo.x, lo.y, hi.x, hi.y), b, acc[t]);
+            }
+        }
+    }
+
+    // ---- epilogue: D[row = (tap, ci)][col = co]; partial slab of this split, or += into dW (one split)
+    const int l31 = lane & 31, half = lane >> 5;
+    const int co = c0 + wv * 32 + l31;
+    if (co >= p.Cout) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = ci0 + q * 8 + half * 4;
+            const int kb = t * p.Cin + ci;
+            const float v0 = acc[t][q * 4 + 0], v1 = acc[t][q * 4 + 1], v2 = acc[t][q * 4 + 2], v3 = acc[t][q * 4 + 3];
+            if (p.splits > 1) {
+                *reinterpret_cast<float4*>(p.part + ((long long)bid.z * p.Cout + co) * p.K + kb) = make_float4(v0, v1, v2, v3);
+            } else if (p.oihw) {
+                float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
+                row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
+            } else {
+                float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co * p.K + kb);
+                float4 o = *dst;
+                o.x += v0; o.y += v1; o.z += v2; o.w += v3;
+                *dst = o;
+            }
+        }
+}
+
 // dW (+)= sum over splits of the partial slabs; also applies the packed -> OIHW layout change.
 // A workgroup = (256 / ZL) consecutive elements x ZL split lanes: many-split folds of small weight tensors are
 // latency bound, so the split loop is spread over ZL threads per element and combined through LDS.
@@ -533,8 +679,59 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
+template <typename T, int STG>
+int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
+    if constexpr (T::kEPC != 8) {
+        return SY_ERR_UNSUPPORTED;
+    } else {
+        if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W || a.Cin % 32 != 0 ||
+            a.Cout % 16 != 0 || a.x_extent == 0 || a.dy_extent == 0)
+            return SY_ERR_UNSUPPORTED;
+        const int gx = a.Cin / 32, gy = (a.Cout + 127) / 128;
+        const int slabs_total = a.N * a.Ho * ((a.Wo + 31) / 32);
+        const int target = a.target_blocks > 0 ? a.target_blocks : 512;
+        int splits = (target + gx * gy - 1) / (gx * gy);
+        const int max_splits = (slabs_total + 7) / 8;
+        if (splits > max_splits) splits = max_splits;
+        const long long slab_bytes = (long long)a.Cout * a.K * 4;
+        if (a.part == nullptr) splits = 1;
+        else if ((long long)splits * slab_bytes > ws_bytes) splits = (int)(ws_bytes / slab_bytes);
+        if (splits < 1) splits = 1;
+        a.slabs_per_split = (slabs_total + splits - 1) / splits;
+        splits = (slabs_total + a.slabs_per_split - 1) / a.slabs_per_split;
+        a.splits = splits;
+        constexpr size_t smem = (size_t)STG * (2 * kXSub + 8 * kSubPitch);
+#ifndef SY_EMU
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)conv_wgrad9_kernel<T, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                return SY_ERR_LAUNCH;
+            attr_done = true;
+        }
+#endif
+        SY_LAUNCH((conv_wgrad9_kernel<T, STG>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
+        if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
+        if (splits > 1) {
+            const long long work = (long long)a.Cout * a.K;
+            auto grid_for = [&](int e) { long long b = (work + e - 1) / e; return (int)(b > 4096 ? 4096 : b); };
+            if (splits >= 64)
+                SY_LAUNCH(wgrad_fold_kernel<16>, dim3(grid_for(16)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
+                          a.Cin, 9, splits, a.oihw);
+            else if (splits >= 16)
+                SY_LAUNCH(wgrad_fold_kernel<4>, dim3(grid_for(64)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
+                          a.Cin, 9, splits, a.oihw);
+            else
+                SY_LAUNCH(wgrad_fold_kernel<1>, dim3(grid_for(256)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
+                          a.Cin, 9, splits, a.oihw);
+        }
+        return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+    }
+}
+
 template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
+    if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
+    if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128
         case 2: return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);   // 128 x  64

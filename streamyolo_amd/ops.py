@@ -468,7 +468,8 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
 
 # tile codes 1-6: scatter-transposed staging; +16 / +32: LDS-DMA ring (3 / 4 slabs) + ds_read_b64_tr_b16 fragments
 _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 1024), (33, 1024), (18, 512), (18, 1024),
-                     (20, 1024), (22, 1024), (21, 1024)]
+                     (20, 1024), (22, 1024), (21, 1024),
+                     (49, 512), (49, 1024), (65, 512), (65, 1024)]     # 3x3 stride 1: all nine taps per workgroup (conv_wgrad9_kernel)
 _wgrad_cache = {}
 
 
@@ -486,9 +487,12 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
     dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
     best, best_t = (0, 0), float("inf")
     for (t, tb) in _WGRAD_CANDIDATES:
-        if (t & 15) in (1, 5, 6) and Cout < 128:
+        if t in (49, 65):
+            if k != 3 or stride != 1 or Cin % 32 or Cout % 16:
+                continue
+        elif (t & 15) in (1, 5, 6) and Cout < 128:
             continue
-        if (t & 15) == 2 and Cout < 64:
+        elif (t & 15) == 2 and Cout < 64:
             continue
         try:
             def run():

@@ -225,3 +225,35 @@ def test_conv3x3_halo_kernel(backend, tile, dt, mode):
         ops.conv2d(dyp, wt, ref, 3, 1, mode=ops.CONV_DGRAD, tile=19)  # implicit-GEMM kernel, same operands
         ops.conv2d(dyp, wt, dxv, 3, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf)
         assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("tile", [49, 65])
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 144, 7, 37), (1, 32, 48, 5, 70)])
+def test_wgrad_all_taps_kernel(backend, tile, N, cin, cout, H, W):
+    """conv_wgrad9_kernel (tile codes 49 / 65): 3x3 stride-1 weight gradient with all nine taps per workgroup and the x halo
+    window resident in LDS — ragged 32-pixel row segments, ragged Cout tile, one split and many splits (+ fold), packed and
+    OIHW layouts, against torch and against the per-tap transpose-read kernel."""
+    dt = "bf16"
+    g = torch.Generator().manual_seed(tile + cin)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, dt).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1)
+    dy = _q(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(cout, -1)
+    xv = View.alloc(N, H, W, cin + 16, dt, backend, zero=True).slice(16, cin); xv.set_nchw(x.to(backend))
+    dyv = View.alloc(N, H, W, cout, dt, backend); dyv.set_nchw(dy.to(backend))
+    ws = torch.empty(1 << 24, dtype=torch.uint8, device=backend)
+    for tb in (1, 8, 4096):
+        dw = torch.zeros(cout, 9 * cin, device=backend)
+        ops.conv2d_wgrad(xv, dyv, dw, 3, 1, workspace=ws, tile=tile, target_blocks=tb)
+        assert _rel(dw.cpu(), ref) < TOL[dt], "splits target %d" % tb
+    dw2 = torch.zeros(cout, cin, 3, 3, device=backend)
+    ops.conv2d_wgrad(xv, dyv, dw2, 3, 1, oihw=True, workspace=ws, tile=tile, target_blocks=16)
+    ops.conv2d_wgrad(xv, dyv, dw2, 3, 1, oihw=True, workspace=None, tile=tile)             # one split: += in place
+    assert _rel(dw2.cpu(), 2 * w.grad) < TOL[dt]
+    dw3 = torch.zeros(cout, 9 * cin, device=backend)
+    ops.conv2d_wgrad(xv, dyv, dw3, 3, 1, workspace=ws, tile=17, target_blocks=8)
+    dw4 = torch.zeros(cout, 9 * cin, device=backend)
+    ops.conv2d_wgrad(xv, dyv, dw4, 3, 1, workspace=ws, tile=tile, target_blocks=8)
+    assert _rel(dw4.cpu(), dw3.cpu()) < 1e-4
