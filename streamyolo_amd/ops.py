@@ -469,7 +469,10 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
 # tile codes 1-6: scatter-transposed staging; +16 / +32: LDS-DMA ring (3 / 4 slabs) + ds_read_b64_tr_b16 fragments
 _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 1024), (33, 1024), (18, 512), (18, 1024),
                      (20, 1024), (22, 1024), (21, 1024),
-                     (49, 512), (49, 1024), (65, 512), (65, 1024)]     # 3x3 stride 1: all nine taps per workgroup (conv_wgrad9_kernel)
+                     (17, 256), (33, 256), (18, 256),
+                     # 3x3 stride 1: all nine taps per workgroup (conv_wgrad9_kernel); few splits: the split-K slabs + fold are a
+                     # third of its time at 1024 workgroups (profiles/r02/f_wgrad_probe.txt)
+                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512)]
 _wgrad_cache = {}
 
 
