@@ -116,11 +116,13 @@ SY_API int sy_focus_pack(const float* in, int N, int Ctot, int c0, int H, int W,
 /* Device-side input pipeline: uint8 HWC frames -> model input in ONE launch.
  * cur / sup: [B, Hs, Ws, 3] uint8 (BGR as cv2.imread delivers them; sup = NULL for a single on_pipe frame),
  * image_stride / row_stride in bytes.  Steps, in the reference's order:
- *   decimate (1 | 2): the load-time cv2.resize (exps/dataset/tal_flip_one_future_argoversedataset.py:179-187,
- *       streamyolo_det.py:177) for the two ratios that need no cv2 tables: copy, or exact 2x = (a+b+c+d+2)>>2;
+ *   decimate (1 | 2 | 0): the load-time cv2.resize (exps/dataset/tal_flip_one_future_argoversedataset.py:179-187,
+ *       streamyolo_det.py:177): 1 = copy, 2 = exact 2x = (a+b+c+d+2)>>2 (OpenCV's INTER_AREA fast path), 0 = any other
+ *       camera size: r = min(H/Hs, W/Ws), OpenCV's fixed-point INTER_LINEAR to (int(Ws r), int(Hs r)) (`preproc`,
+ *       exps/data/data_augment_flip.py:151-167); restated from OpenCV's source, unpinned against a cv2 binary;
  *   mirror[b] != 0: `_mirror`'s image[:, ::-1], the same flag for both frames of a pair
  *       (exps/data/data_augment_flip.py:140-148, DoubleTrainTransform :219-222);
- *   letterbox onto an H x W canvas filled with 114, image at the top-left (`preproc` :151-167; r must be 1);
+ *   letterbox onto an H x W canvas filled with 114, image at the top-left (`preproc` :151-167);
  *   bilinear resize of the canvas to Ho x Wo when they differ (Exp.preprocess's F.interpolate(mode="bilinear",
  *       align_corners=False), cfgs/l_s50_onex_dfp_tal_filp.py:161-172);
  *   layout SY_FRAMES_NCHW: out_cur = fp32 [B, 3 or 6, Ho, Wo] (current channels first — np.concatenate((img,

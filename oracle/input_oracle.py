@@ -22,6 +22,48 @@ def load_time_resize(img, decimate):
     return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
 
 
+def cv2_resize_linear_u8(img, dsize):
+    """cv2.resize(img, dsize=(w, h), interpolation=cv2.INTER_LINEAR) for uint8 HWC images, restated from OpenCV's
+    modules/imgproc/src/resize.cpp (8-bit fixed-point path; INTER_RESIZE_COEF_BITS = 11):
+        scale = 1. / ((double)dst / src);  fx = (float)((dx + 0.5) * scale - 0.5);  sx = floor(fx);  fx -= sx
+        sx < 0 -> (fx, sx) = (0, 0);  sx >= src - 1 -> (fx, sx) = (0, src - 1)
+        alpha = saturate_cast<short>({1 - fx, fx} * 2048)                    (cvRound: round half to even)
+        horizontal:  D = S[sx] * alpha0 + S[sx + 1] * alpha1                 (int32)
+        vertical:    dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+    (both scale factors exactly 2 take the INTER_AREA fast path instead: load_time_resize(img, 2)).
+    PARITY UNPINNED: no OpenCV binary exists in the build container."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    sh, sw = img.shape[:2]
+    if sh == 2 * dh and sw == 2 * dw:
+        return load_time_resize(img, 2)
+
+    def taps(dn, sn):
+        scale = 1.0 / (float(dn) / float(sn))
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo, hi = s < 0, s >= sn - 1
+        f = np.where(lo | hi, np.float32(0), f)
+        s = np.where(lo, 0, np.where(hi, sn - 1, s))
+        a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, np.minimum(s + 1, sn - 1), a0, a1
+    x0, x1, ax0, ax1 = taps(dw, sw)
+    y0, y1, ay0, ay1 = taps(dh, sh)
+    src = img.astype(np.int64)
+    hor = src[:, x0] * ax0[None, :, None] + src[:, x1] * ax1[None, :, None]           # [sh, dw, 3], scaled by 2^11
+    S0, S1 = hor[y0], hor[y1]
+    out = (((ay0[:, None, None] * (S0 >> 4)) >> 16) + ((ay1[:, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def load_time_resize_general(img, input_size):
+    """`preproc`'s own resize for an arbitrary camera size (data_augment_flip.py:151-160):
+    r = min(H / h, W / w); cv2.resize(img, (int(w * r), int(h * r)), INTER_LINEAR)."""
+    r = min(input_size[0] / img.shape[0], input_size[1] / img.shape[1])
+    return cv2_resize_linear_u8(img, (int(img.shape[1] * r), int(img.shape[0] * r)))
+
+
 def mirror_image(img, mirror):
     """`_mirror`, image part: image[:, ::-1] (exps/data/data_augment_flip.py:140-148)."""
     return img[:, ::-1] if mirror else img
@@ -41,9 +83,10 @@ def pair_tensor(cur, sup, input_size, decimate=1, mirror=None):
     (exps/data/tal_flip_mosaicdetection.py:257) of the two `preproc` outputs, one mirror flag per pair
     (DoubleTrainTransform, data_augment_flip.py:213-222).  cur / sup: uint8 [B, Hs, Ws, 3] arrays (sup may be None)."""
     out = []
+    rs = (lambda im: load_time_resize_general(im, input_size)) if decimate == 0 else (lambda im: load_time_resize(im, decimate))
     for b in range(cur.shape[0]):
         m = bool(mirror[b]) if mirror is not None else False
-        planes = [preproc(mirror_image(load_time_resize(f[b], decimate), m), input_size)
+        planes = [preproc(mirror_image(rs(f[b]), m), input_size)
                   for f in ((cur, sup) if sup is not None else (cur,))]
         out.append(np.concatenate(planes, axis=0))
     return torch.from_numpy(np.stack(out))

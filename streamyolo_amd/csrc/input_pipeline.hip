@@ -12,10 +12,16 @@
 // either to the reference's fp32 NCHW tensor (drop-in) or straight to the Focus-packed NHWC16 operand of the stem
 // convolution (space-to-depth order TL, BL, TR, BR — trap T4).  HBM-bound: 3 B read, <= 4 B written per pixel/channel.
 //
-// cv2.resize parity: only the two cases that need no cv2 arithmetic tables are implemented — same size (copy) and the
-// exact 2x decimation (cv::resize turns INTER_LINEAR into the INTER_AREA fast path when both scale factors are
-// exactly 2: (a + b + c + d + 2) >> 2), which is Argoverse's 1200x1920 -> 600x960.  Any other ratio returns
-// SY_ERR_UNSUPPORTED: cv2 is not available where this was built, so its general fixed-point bilinear cannot be pinned.
+// cv2.resize parity (OpenCV is not available where this was built: all three cases are restated from OpenCV's published
+// resize.cpp, PARITY UNPINNED against a cv2 binary — oracle/input_oracle.py states the same arithmetic in numpy):
+//   decimate 1   same size: copy;
+//   decimate 2   exact 2x: cv::resize turns INTER_LINEAR into the INTER_AREA fast path when both scale factors are exactly
+//                2, (a + b + c + d + 2) >> 2 — Argoverse's 1200x1920 -> 600x960;
+//   decimate 0   any other camera size: `preproc`'s r = min(H / h, W / w), cv2.resize(img, (int(w r), int(h r)),
+//                INTER_LINEAR) (data_augment_flip.py:151-167) = OpenCV's fixed-point bilinear for 8-bit images: source
+//                coordinate fx = (float)((dx + 0.5) * scale - 0.5), taps sx = floor(fx), sx + 1 (clamped at the borders with
+//                the fraction zeroed), coefficients saturate_cast<short>(frac * 2048) (round half to even), horizontal pass
+//                in int32, vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
 #include "sy_pointwise.h"
 
 namespace {
@@ -24,15 +30,41 @@ struct FrameSrc {               // uint8 HWC frames of one batch: current and (o
     const unsigned char* img[2];
     long long image_stride;     // bytes between images
     int row_stride;             // bytes between rows
-    int hs, ws;                 // size AFTER the optional decimation
-    int dec;                    // 1 or 2
+    int hs, ws;                 // size AFTER the load-time resize (decimation or general ratio)
+    int dec;                    // 1 or 2; 0 = general-ratio fixed-point bilinear from a src_h x src_w frame
+    int src_h, src_w;
+    double scale_y, scale_x;    // dec == 0: source / destination size ratios (OpenCV: 1. / ((double)dst / src))
     const unsigned char* mirror;    // [B] flags or nullptr
+    // OpenCV's INTER_LINEAR tap set of one destination coordinate (resize.cpp, 8-bit fixed-point path)
+    struct Tap { int s0, s1; int a0, a1; };
+    static __device__ __forceinline__ Tap tap(int d, double scale, int ssize) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { f = 0.0f; s = 0; }
+        if (s >= ssize - 1) { f = 0.0f; s = ssize - 1; }
+        Tap t;
+        t.s0 = s;
+        t.s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+        t.a0 = (int)rintf((1.0f - f) * 2048.0f);            // saturate_cast<short>(float) = cvRound (round half to even)
+        t.a1 = (int)rintf(f * 2048.0f);
+        return t;
+    }
     // value of channel c at (y, x) of the letterboxed H x W canvas of image n, frame f
     __device__ __forceinline__ float at(int n, int f, int c, int y, int x) const {
         if (y >= hs || x >= ws) return 114.0f;
         if (mirror != nullptr && mirror[n]) x = ws - 1 - x;
         const unsigned char* p = img[f] + n * image_stride;
         if (dec == 1) return (float)p[(long long)y * row_stride + x * 3 + c];
+        if (dec == 0) {
+            const Tap ty = tap(y, scale_y, src_h), tx = tap(x, scale_x, src_w);
+            const unsigned char* r0 = p + (long long)ty.s0 * row_stride + c;
+            const unsigned char* r1 = p + (long long)ty.s1 * row_stride + c;
+            const int S0 = (int)r0[tx.s0 * 3] * tx.a0 + (int)r0[tx.s1 * 3] * tx.a1;      // horizontal pass, scaled by 2^11
+            const int S1 = (int)r1[tx.s0 * 3] * tx.a0 + (int)r1[tx.s1 * 3] * tx.a1;
+            const int v = (((ty.a0 * (S0 >> 4)) >> 16) + ((ty.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            return (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
         const unsigned char* r0 = p + (long long)(2 * y) * row_stride + (2 * x) * 3 + c;
         const unsigned char* r1 = r0 + row_stride;
         return (float)(((int)r0[0] + (int)r0[3] + (int)r1[0] + (int)r1[3] + 2) >> 2);
@@ -128,14 +160,26 @@ extern "C" int sy_frames_u8_pack(const uint8_t* cur, const uint8_t* sup, int B, 
                                  int layout, void* out_cur, void* out_sup, int dtype, void* stream) {
     if (cur == nullptr || out_cur == nullptr || B <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0)
         return SY_ERR_ARG;
-    if (decimate != 1 && decimate != 2) return SY_ERR_UNSUPPORTED;
+    if (decimate < 0 || decimate > 2) return SY_ERR_UNSUPPORTED;
     if (decimate == 2 && ((Hs & 1) || (Ws & 1))) return SY_ERR_UNSUPPORTED;
     if (row_stride < Ws * 3 || image_stride < (int64_t)row_stride * Hs) return SY_ERR_ARG;
-    const int hs = Hs / decimate, ws = Ws / decimate;
-    // preproc's ratio r = min(H / h, W / w) must be exactly 1 after the decimation (see the header)
-    if (hs > H || ws > W || (hs != H && ws != W)) return SY_ERR_UNSUPPORTED;
-    const int F = sup != nullptr ? 2 : 1;
+    int hs, ws;
     FrameSrc src;
+    src.src_h = Hs; src.src_w = Ws; src.scale_y = 1.0; src.scale_x = 1.0;
+    if (decimate == 0) {
+        // preproc: r = min(H / h, W / w); resized to (int(w * r), int(h * r)) — the same double arithmetic as the Python code
+        const double r = ((double)H / Hs < (double)W / Ws) ? (double)H / Hs : (double)W / Ws;
+        hs = (int)(Hs * r); ws = (int)(Ws * r);
+        if (hs < 1 || ws < 1 || hs > H || ws > W) return SY_ERR_UNSUPPORTED;
+        src.scale_y = 1.0 / ((double)hs / Hs); src.scale_x = 1.0 / ((double)ws / Ws);
+        if (hs == Hs && ws == Ws) decimate = 1;                          // r == 1: cv::resize copies
+        else if (2 * hs == Hs && 2 * ws == Ws) decimate = 2;             // both factors exactly 2: OpenCV's INTER_AREA fast path
+    } else {
+        hs = Hs / decimate; ws = Ws / decimate;
+        // preproc's ratio r = min(H / h, W / w) must be exactly 1 after the decimation (see the header)
+        if (hs > H || ws > W || (hs != H && ws != W)) return SY_ERR_UNSUPPORTED;
+    }
+    const int F = sup != nullptr ? 2 : 1;
     src.img[0] = cur; src.img[1] = sup; src.image_stride = image_stride; src.row_stride = row_stride;
     src.hs = hs; src.ws = ws; src.dec = decimate; src.mirror = mirror;
     if (layout == SY_FRAMES_NCHW) {

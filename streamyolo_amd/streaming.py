@@ -43,18 +43,18 @@ class StreamingDetector:
     buffer being reset at every sequence start (:150).
 
     Frames are the raw uint8 HWC arrays `cv2.imread` returns.  With in_scale = 0.5 the reference's cv2.resize is the
-    exact 2x decimation, done on the device together with the Focus packing (sy_frames_u8_pack); other scales would
-    need cv2's interpolation tables and are refused (streamyolo_amd/data.py)."""
+    exact 2x decimation, with any other in_scale OpenCV's fixed-point bilinear resize — both done on the device together
+    with the Focus packing (sy_frames_u8_pack, csrc/input_pipeline.hip)."""
 
     def __init__(self, model, frame_hw, in_scale=0.5, num_classes=8, conf_thre=0.01, nms_thresh=0.65, dtype="fp16",
                  device="cuda"):
-        if in_scale not in (0.5, 1.0):
-            raise NotImplementedError("in_scale %r: only 1.0 and the exact 0.5 decimation are pinned" % (in_scale,))
         self.model = model.to(device).eval().set_compute_dtype(dtype)
         self.device = torch.device(device)
-        self.in_scale, self.decimate = in_scale, int(round(1.0 / in_scale))
+        self.in_scale = in_scale
+        self.decimate = {1.0: 1, 0.5: 2}.get(float(in_scale), 0)          # 0: general-ratio bilinear (streamyolo_det.py:177)
         self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
-        self.canvas = (int(self.frame_hw[0] * in_scale), int(self.frame_hw[1] * in_scale))
+        # cv2.resize(frame, dsize=None, fx=in_scale, fy=in_scale): dsize = round(src * scale); the plan needs even sizes
+        self.canvas = (int(round(self.frame_hw[0] * in_scale)), int(round(self.frame_hw[1] * in_scale)))
         self.num_classes, self.conf_thre, self.nms_thresh = num_classes, conf_thre, nms_thresh
         self._slot = torch.empty((1,) + self.frame_hw + (3,), dtype=torch.uint8, device=self.device)
         self._in = FramePairsU8(self._slot, None, self.canvas, self.decimate)

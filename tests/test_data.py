@@ -163,3 +163,38 @@ def test_device_prefetcher_hands_over_uint8_batches():
         assert tgt[0].is_cuda and float(tgt[0][0, 0, 0]) == float(i) and float(tgt[1][0, 0, 0]) == float(i + 1)
     inp, tgt = pf.next()
     assert inp is None and tgt is None
+
+
+def test_cv2_linear_restatement_properties():
+    """oracle.input_oracle.cv2_resize_linear_u8 (OpenCV's fixed-point INTER_LINEAR, restated — no cv2 binary here): the
+    properties any correct restatement has — same size is the identity, constants stay constant, results stay inside the
+    source range, a horizontal ramp stays monotone, exact 2x takes the INTER_AREA fast path, and the tap weights of every
+    output pixel sum to 2048."""
+    g = np.random.default_rng(3)
+    img = g.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(IO.cv2_resize_linear_u8(img, (53, 37)), img)
+    const = np.full((30, 44, 3), 171, dtype=np.uint8)
+    assert np.all(IO.cv2_resize_linear_u8(const, (33, 21)) == 171)
+    for dsize in ((40, 25), (80, 60), (17, 9)):
+        out = IO.cv2_resize_linear_u8(img, dsize)
+        assert out.shape == (dsize[1], dsize[0], 3) and out.min() >= img.min() and out.max() <= img.max()
+    ramp = np.repeat(np.linspace(0, 255, 64).astype(np.uint8)[None, :, None], 20, 0).repeat(3, 2)
+    up = IO.cv2_resize_linear_u8(ramp, (150, 31)).astype(np.int32)
+    assert np.all(np.diff(up[:, :, 0], axis=1) >= 0)
+    big = g.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    assert np.array_equal(IO.cv2_resize_linear_u8(big, (20, 12)), IO.load_time_resize(big, 2))
+
+
+@pytest.mark.parametrize("hs,ws,canvas", [(45, 80, (40, 64)), (27, 64, (40, 64)), (50, 41, (40, 64)), (80, 128, (40, 64)),
+                                          (40, 64, (40, 64))])
+def test_general_ratio_letterbox_matches_the_oracle_bit_exact(backend, hs, ws, canvas):
+    """decimate=0: a camera size that is neither the canvas nor twice it — `preproc`'s r = min(H / h, W / w) followed by
+    OpenCV's fixed-point bilinear resize, mirror, letterbox on 114 — the device kernel against the numpy restatement,
+    integer arithmetic on both sides: every pixel equal, for shrinking, enlarging, exact-2x and same-size cameras."""
+    g = torch.Generator().manual_seed(hs * 131 + ws)
+    cur = torch.randint(0, 256, (2, hs, ws, 3), generator=g, dtype=torch.uint8)
+    sup = torch.randint(0, 256, (2, hs, ws, 3), generator=g, dtype=torch.uint8)
+    mirror = torch.tensor([1, 0], dtype=torch.uint8)
+    want = IO.pair_tensor(cur.numpy(), sup.numpy(), canvas, decimate=0, mirror=mirror.numpy())
+    got = FramePairsU8(cur.to(backend), sup.to(backend), canvas, decimate=0, mirror=mirror.to(backend)).to_nchw()
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)

@@ -41,6 +41,16 @@ def main():
     for kind, shape, calls, ms, fl in rows[:70]:
         print("%-20s %-36s %6.1f %9.4f %6.2f %9.1f" % (kind, shape, calls, ms, 100 * ms / tot, fl / ms / 1e9 if ms else 0))
     print("TOTAL %.3f ms" % tot)
+    # which kernel variant the per-shape autotuner picked (tile codes: include/streamyolo_hip.h; wgrad: (tile, split-K workgroups))
+    from collections import Counter
+    picks = Counter()
+    for op in st.plan.ops:
+        if op.kind == "conv":
+            for k, t in op._tiles.items():
+                picks[("N%d %dx%d %d->%d k%d s%d" % (op.y.N, op.y.H, op.y.W, op.x.C, op.y.C, op.k, op.stride), k, str(t))] += 1
+    print("tuned variants (shape, launch kind, code): launches")
+    for (shape, k, t), n in sorted(picks.items()):
+        print("  %-34s %-12s %-12s x%d" % (shape, k, t, n))
 
 
 if __name__ == "__main__":
