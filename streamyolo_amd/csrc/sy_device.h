@@ -228,6 +228,15 @@ __device__ __forceinline__ void sy_glds16_buf_at(const sy_buffer& b, unsigned vo
 }
 #endif
 
+// Wave-level ordering point for wave-PRIVATE LDS hand-offs (one lane writes, another lane of the same wave reads): the
+// hardware executes a wave's LDS instructions in order, so nothing is needed beyond keeping the compiler from reordering;
+// the host emulator runs lanes as fibers and needs a real rendezvous of the wave.
+#ifdef SY_EMU
+static inline void sy_wave_fence() { (void)__shfl(0, 0); }
+#else
+__device__ __forceinline__ void sy_wave_fence() { __builtin_amdgcn_wave_barrier(); }
+#endif
+
 // wave-uniform value hint (lets hipcc keep per-wave constants in SGPRs and branch on them with SALU)
 #ifdef SY_EMU
 static inline int sy_uniform(int v) { return v; }

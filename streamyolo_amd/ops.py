@@ -393,6 +393,7 @@ _TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging s
 _tile_cache = {}
 import os as _os
 HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "112,113,114,115,116").split(",") if t]
+STREAM_1X1 = _os.environ.get("STREAMYOLO_STREAM_1X1", "1") != "0"
 
 
 def autotune_enabled(device):
@@ -444,6 +445,9 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     if k == 3 and stride == 1 and wf is not None and HALO_TILES:
         # 3x3 stride-1 layers: the halo-resident kernel (csrc/conv3x3_halo.h), tiles of 64 / 128 / 256 channels
         cands += [t for t in HALO_TILES if not (t == 116 and Cout > 64)]
+    if (k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256) and code != DT_F32 and STREAM_1X1
+            and (with_stats or mode == CONV_DGRAD)):
+        cands.append(120)                      # weight-stationary pixel stream (csrc/conv1x1_stream.h): raw outputs only
     best, best_t = 0, float("inf")
     for t in cands:
         if t >= TILE_WR and wf is None:
@@ -452,9 +456,10 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
         def run():
             if with_stats:
                 conv2d(x, w, y, k, stride, stats=stats, mode=mode, tile=t, wfrag=wf)
-            else:
-                conv2d(x, w, y, k, stride, scale, shift, epilogue=EPI_SILU if mode == CONV_FWD else EPI_LINEAR,
-                       mode=mode, tile=t, wfrag=wf)
+            elif mode == CONV_FWD:
+                conv2d(x, w, y, k, stride, scale, shift, epilogue=EPI_SILU, mode=mode, tile=t, wfrag=wf)
+            else:                                # data gradient as the backward pass launches it: raw output, no affine
+                conv2d(x, w, y, k, stride, epilogue=EPI_LINEAR, mode=mode, tile=t, wfrag=wf)
         try:
             run()
             dt = _time_launches(run, device)

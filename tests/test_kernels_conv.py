@@ -257,3 +257,43 @@ def test_wgrad_all_taps_kernel(backend, tile, N, cin, cout, H, W):
     dw4 = torch.zeros(cout, 9 * cin, device=backend)
     ops.conv2d_wgrad(xv, dyv, dw4, 3, 1, workspace=ws, tile=tile, target_blocks=8)
     assert _rel(dw4.cpu(), dw3.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W", [(64, 72, 2, 7, 9), (128, 160, 4, 5, 13), (256, 128, 2, 9, 11), (128, 64, 2, 16, 33)])
+def test_conv1x1_stream_kernel(backend, cin, cout, N, H, W):
+    """csrc/conv1x1_stream.h (tile code 120): 1x1 stride-1 training forward (raw output + per-frame BatchNorm statistics)
+    and data gradient (first write and accumulate, channel-slice output), ragged pixel and channel tiles, several tiles per
+    workgroup; against torch and against the implicit-GEMM kernel."""
+    dt = "bf16"
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt).requires_grad_(True)
+    w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    y = F.conv2d(x, w)
+    xv = View.alloc(N, H, W, cin + 8, dt, backend, zero=True).slice(8, cin); xv.set_nchw(x.detach().to(backend))
+    wp = pack_conv_weight(w, code).to(backend)
+    wf = pack_conv_weight_frag(wp, 1)
+    yv = View.alloc(N, H, W, cout + 16, dt, backend, zero=True).slice(16, cout)
+    ssum = torch.zeros(2 * 4 * cout, device=backend); ssq = torch.zeros(2 * 4 * cout, device=backend)
+    ops.conv2d(xv, wp, yv, 1, 1, stats=(ssum, ssq), tile=120, wfrag=wf, segments=2)
+    assert _rel(yv.nchw().cpu(), y.detach()) < TOL[dt]
+    assert float(yv.buf[..., :16].float().abs().max()) == 0.0
+    for s_ in range(2):
+        ys = y.detach()[s_ * (N // 2):(s_ + 1) * (N // 2)]
+        assert _rel(ssq.view(2, 4, cout)[s_].sum(0).cpu(), (ys ** 2).sum((0, 2, 3))) < 1e-3
+        assert float((ssum.view(2, 4, cout)[s_].sum(0).cpu() - ys.sum((0, 2, 3))).abs().max()) < 1e-2 * float(ys.abs().sum((0, 2, 3)).max())
+    ref = View.alloc(N, H, W, cout, dt, backend)
+    ops.conv2d(xv, wp, ref, 1, 1, stats=(torch.zeros_like(ssum), torch.zeros_like(ssq)), tile=19, segments=2)
+    assert _rel(yv.nchw().cpu(), ref.nchw().cpu()) < 1e-2
+    # data gradient: dy [N,H,W,cout_pad] x W^T -> dx, then += ; the stream kernel needs dy's channel count in {64..512}
+    if cout in (64, 128, 256):
+        dy = _q(torch.randn(y.shape, generator=g), dt)
+        y.backward(dy)
+        dyv = View.alloc(N, H, W, cout, dt, backend); dyv.set_nchw(dy.to(backend))
+        wt = pack_conv_weight(w, code, transpose=True).to(backend)
+        wft = pack_conv_weight_frag(wt, 1)
+        dxv = View.alloc(N, H, W, cin, dt, backend, zero=True)
+        ops.conv2d(dyv, wt, dxv, 1, 1, mode=ops.CONV_DGRAD, tile=120, wfrag=wft)
+        assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
+        ops.conv2d(dyv, wt, dxv, 1, 1, mode=ops.CONV_DGRAD, tile=120, wfrag=wft, accumulate=True)
+        assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]

@@ -34,7 +34,7 @@ NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
          22: "rs128x64", 23: "rs64x64", 35: "d2-128x128", 36: "d2-64x256", 38: "d2-128x64", 39: "d2-64x64",
          51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64",
-         112: "halo128x4", 113: "halo128x4w", 114: "halo128x2-8w", 115: "halo128x2", 116: "halo64x8",
+         120: "stream1x1", 112: "halo128x4", 113: "halo128x4w", 114: "halo128x2-8w", 115: "halo128x2", 116: "halo64x8",
          99: "w3-128x128", 102: "w3-128x64", 103: "w3-64x64", 24: "rs256x64", 88: "wr256x64", 89: "wr256x128", 83: "wr128x128", 84: "wr64x256", 85: "wr32x256", 86: "wr128x64", 87: "wr64x64"}
 
 
@@ -74,7 +74,10 @@ def main():
         flops = 2.0 * cin * cout * k * k * y.pixels
         res = []
         for t in tiles:
-            if t >= 112 and (k != 3 or st != 1):
+            if t == 120 and (k != 1 or st != 1 or cin not in (64, 128, 256) or a.mode != "dgrad"):
+                res.append(float("nan"))
+                continue
+            if 112 <= t < 120 and (k != 3 or st != 1):
                 res.append(float("nan"))
                 continue
             if t < 112 and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
