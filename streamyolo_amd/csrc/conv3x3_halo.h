@@ -177,7 +177,162 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
 }
 
+// ---- second generation: the same tile, software-pipelined inside the wave ---------------------------------------------
+// The ISA of the kernel above shows why its waves sit at ~35 % MFMA issue: every pair of MFMAs waits on the ds_read_b128
+// issued right in front of it (lgkmcnt(0), ~120 cycles), the weight fragments arrive two taps = 4 MFMAs = 128 cycles after
+// they were requested from L2 (~500+ cycles), and the slab-top `vmcnt(0)` drains the fragment prefetch every 36 MFMAs.
+// Here, per wave:
+//   * weight fragments: ALL nine taps of a slab live in registers (72 x TC VGPRs); the slot of tap t is refilled with tap t
+//     of the NEXT slab right after its MFMAs — every fragment has a whole slab (18 x TC x TP MFMAs) to arrive;
+//   * pixel fragments: a 3-deep register ring over the 18 (tap, k-half) steps of a slab, read two steps ahead of the MFMAs
+//     from LDS addresses precomputed once per kernel (one v_add per read for the halo-buffer parity);
+//   * the slab-top wait is COUNTED: only the slab's DMA pieces (issued behind taps 0 .. NI-1 of the previous slab) must
+//     have landed — the (9 - NI) x 2 TC fragment loads issued after the last piece stay in flight across the barrier;
+//   * no branches in the slab body: the DMA pieces of the slab after the last one are issued out of range (zeros into the
+//     idle buffer, drained before the epilogue reuses the LDS).
 template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_halo2_kernel(ConvArgs p) {
+    constexpr int NW = WC * WP;
+    constexpr int EPC = T::kEPC;
+    constexpr int ESZ = 16 / EPC;
+    constexpr int BK = 4 * EPC;
+    constexpr int CT = WC * TC * 32;
+    constexpr int TH = WP * TP;
+    constexpr int HR = (TH + 2) * kHaloW;
+    constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;
+    constexpr int BUF = NW * NI * 16 * 64;
+    constexpr int BD = 3;                        // pixel-fragment ring: two (tap, k-half) steps of reads in flight
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NI <= 9, "one DMA piece per tap");
+
+    SY_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = sy_uniform(tid >> 6);
+    const int wc = wave / WP;
+    const int wp = wave % WP;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const sy_block_id bid = sy_xcd_block_id();
+    const int tiles_w = (p.Wo + 31) >> 5, tiles_h = (p.Ho + TH - 1) / TH;
+    const int tw = bid.y % tiles_w, th_ = (bid.y / tiles_w) % tiles_h, n = bid.y / (tiles_w * tiles_h);
+    const int h0 = th_ * TH, w0 = tw * 32;
+
+    const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
+    unsigned voff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = (wave + i * NW) * 16 + (lane >> 2);
+        const int hy = r / kHaloW, hx = r - hy * kHaloW;
+        const int h = h0 - 1 + hy, w = w0 - 1 + hx;
+        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+        const bool ok = r < HR && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W && !(p.ablate & 1);
+        voff[i] = ok ? (unsigned)((((long long)n * p.xbs + ((long long)h * p.W + w) * p.ldx) + chunk * EPC) * ESZ) : 0xFFFFFFFFu;
+    }
+    const sy_lds_base_t lds0 = sy_lds_base(smem);
+    const int ncs = p.Cin / BK;
+    auto issue_piece = [&](auto i_, int cslab) {           // piece I of slab `cslab` (out of range past the last slab)
+        constexpr int I = decltype(i_)::value;
+        const unsigned s_x = (unsigned)(cslab * BK * ESZ);
+        const bool dead = voff[I] == 0xFFFFFFFFu || cslab >= ncs;
+        sy_glds16_buf_at(bufx, dead ? 0xFFFFFFFFu : voff[I] + s_x, lds0, (unsigned)((cslab & 1) * BUF + (wave + I * NW) * 1024));
+    };
+
+    const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
+    const int ntile32 = (p.Cout + 31) / 32;
+    unsigned foff[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+        const int ct = bid.x * (CT / 32) + wc * TC + t;
+        foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
+    }
+    uint4 fr[9][TC][2];
+    auto fetch = [&](auto tap_, int cslab) {               // fragments of tap TAP of slab `cslab` into their slot
+        constexpr int TAP = decltype(tap_)::value;
+        const unsigned s_f = (unsigned)((cslab * 9 + TAP) * 2048);
+        const bool live = cslab < ncs;
+#pragma unroll
+        for (int t = 0; t < TC; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                fr[TAP][t][g] = sy_buffer_load16_s(buff, (live && foff[t] != 0xFFFFFFFFu) ? foff[t] + (unsigned)(g * 1024) : 0xFFFFFFFFu, s_f);
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int u = 0; u < TP; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    // LDS byte offset of this lane's fragment row for (tap, pixel tile), k-half 0 (k-half 1 = ^ 32: the swizzle is an XOR)
+    const bool fwd = (p.mode == SY_CONV_FWD);
+    unsigned ba[9][TP];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        const int toff = fwd ? (kh * kHaloW + kw) : ((2 - kh) * kHaloW + (2 - kw));
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            const int row = (wp * TP + u) * kHaloW + l31 + toff;
+            ba[tap][u] = (unsigned)(row * 64 + ((half ^ ((row >> 2) & 3)) << 4));
+        }
+    }
+
+    sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, 0); });
+    sy_static_for<0, 9>([&](auto t_) { fetch(t_, 0); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
+    for (int cs = 0; cs < ncs; ++cs) {
+        sy_wait_vmcnt<(9 - NI) * 2 * TC>();      // the slab's DMA pieces (older than the last (9 - NI) taps of fragment loads)
+        sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
+        const unsigned hbo = (unsigned)((cs & 1) * BUF);
+        uint4 b[BD][TP];
+        auto read_step = [&](auto s_) {
+            constexpr int S = decltype(s_)::value;
+            constexpr int TAP = S >> 1, G = S & 1;
+#pragma unroll
+            for (int u = 0; u < TP; ++u)
+                b[S % BD][u] = *reinterpret_cast<const uint4*>(smem + ((hbo + ba[TAP][u]) ^ (unsigned)(G * 32)));
+        };
+        sy_static_for<0, BD - 1>([&](auto s_) { read_step(s_); });
+        sy_static_for<0, 18>([&](auto s_) {
+            constexpr int S = decltype(s_)::value;
+            constexpr int TAP = S >> 1, G = S & 1;
+            if constexpr (S + BD - 1 < 18) read_step(sy_int<S + BD - 1>());
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), fr[TAP][t][G], b[S % BD][u], acc[t][u]);
+            if constexpr (G == 1) {
+                fetch(sy_int<TAP>(), cs + 1);
+                if constexpr (TAP < NI) issue_piece(sy_int<TAP>(), cs + 1);
+            }
+            sy_sched_fence();
+        });
+    }
+    sy_wait_vmcnt<0>();                           // the out-of-range pieces of the slab after the last one
+    sy_barrier();
+
+    SY_LATE_ARGS(ConvArgs, p);
+    int e_bx = bid.x, e_n = n, e_h0 = h0, e_w0 = w0, e_by = bid.y;
+    SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_n); SY_LAUNDER_INT(e_h0); SY_LAUNDER_INT(e_w0); SY_LAUNDER_INT(e_by);
+    TilePixels mp;
+    mp.n = e_n; mp.h0 = e_h0; mp.w0 = e_w0; mp.Ho = p_late.Ho; mp.Wo = p_late.Wo; mp.rep = e_by;
+    mp.seg = p_late.seg_M > 0 ? (e_n * p_late.HoWo) / p_late.seg_M : 0;
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        int n_, rem_;
+        if (!mp.map((wp * TP + u) * 32 + l31, n_, rem_)) {
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+        }
+    }
+    conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+}
+
+template <typename T, int WC, int WP, int TC, int TP, int GEN = 1>
 int launch_halo(const ConvArgs& a_in, void* stream) {
     constexpr int NW = WC * WP, CT = WC * TC * 32, TH = WP * TP, PT = TH * 32;
     constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
@@ -196,17 +351,20 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return SY_ERR_LAUNCH;
+        const void* fn = GEN == 2 ? (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP> : (const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
+    if constexpr (GEN == 2) {
+        SY_LAUNCH((conv3x3_halo2_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
+    } else {
+        SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
+    }
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-// tile codes 112..116 of sy_conv_desc::tile (SY_TILE_HALO + k)
+// tile codes 112..118 of sy_conv_desc::tile (SY_TILE_HALO + k)
 template <typename T>
 int launch_halo_typed(const ConvArgs& a, void* stream) {
     switch (a.tile) {
@@ -215,6 +373,8 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         case 114: return launch_halo<T, 4, 2, 1, 1>(a, stream);     // 128 ch x ( 2 rows x 32 px), 8 waves x (32 ch x 32 px)
         case 115: return launch_halo<T, 4, 1, 1, 2>(a, stream);     // 128 ch x ( 2 rows x 32 px)
         case 116: return launch_halo<T, 1, 4, 2, 2>(a, stream);     //  64 ch x ( 8 rows x 32 px)
+        case 117: return launch_halo<T, 4, 1, 1, 2, 2>(a, stream);  // second generation (in-wave software pipeline) of 115
+        case 118: return launch_halo<T, 4, 1, 1, 4, 2>(a, stream);  // ... of 113
         default: return SY_ERR_ARG;
     }
 }

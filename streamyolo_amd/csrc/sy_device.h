@@ -237,6 +237,14 @@ static inline void sy_wave_fence() { (void)__shfl(0, 0); }
 __device__ __forceinline__ void sy_wave_fence() { __builtin_amdgcn_wave_barrier(); }
 #endif
 
+// Scheduling fence: the compiler keeps the instruction order of a hand-pipelined loop body on both sides of it (nothing
+// is moved across); no instruction is emitted.
+#ifdef SY_EMU
+static inline void sy_sched_fence() {}
+#else
+__device__ __forceinline__ void sy_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+
 // wave-uniform value hint (lets hipcc keep per-wave constants in SGPRs and branch on them with SALU)
 #ifdef SY_EMU
 static inline int sy_uniform(int v) { return v; }

@@ -174,10 +174,10 @@ def test_wgrad_many_splits_fold(backend):
     assert _rel(dw.cpu(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [112, 113, 114, 115, 116])
+@pytest.mark.parametrize("tile", [112, 113, 114, 115, 116, 117, 118])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "fwd"), ("bf16", "dgrad"), ("fp32", "dgrad")])
 def test_conv3x3_halo_kernel(backend, tile, dt, mode):
-    """csrc/conv3x3_halo.h (tile codes 112..116): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
+    """csrc/conv3x3_halo.h (tile codes 112..118; 117 / 118 = the in-wave software-pipelined generation): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
     gradient (first write, accumulate, channel-slice output), on an image whose width and height are ragged against the
     32-pixel / TH-row tiles, with Cout ragged against the channel tile; against torch and against the implicit-GEMM kernel."""
     g = torch.Generator().manual_seed(tile + len(mode))
@@ -297,3 +297,55 @@ def test_conv1x1_stream_kernel(backend, cin, cout, N, H, W):
         assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
         ops.conv2d(dyv, wt, dxv, 1, 1, mode=ops.CONV_DGRAD, tile=120, wfrag=wft, accumulate=True)
         assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]
+
+
+@pytest.mark.parametrize("tile", [121, 122, 123])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("cin,cout,N,H,W", [(64, 72, 2, 7, 9), (128, 160, 4, 5, 13), (256, 128, 2, 9, 11), (512, 64, 2, 6, 13)])
+def test_conv1x1_tile_kernel(backend, tile, dt, cin, cout, N, H, W):
+    """csrc/conv1x1_tile.h (tile codes 121..123): 1x1 stride-1 training forward (raw output + per-frame BatchNorm
+    statistics), the eval epilogue (affine + SiLU + residual), and the data gradient (first write and accumulate), with pixel
+    and channel tiles ragged against the image; against torch and against the implicit-GEMM kernel."""
+    if (tile == 122 and cout > 64) or (tile == 123 and cin > 256):
+        pytest.skip("not a tuner candidate for this shape")
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(cin + cout + tile)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt).requires_grad_(True)
+    w = _q(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    y = F.conv2d(x, w)
+    xv = View.alloc(N, H, W, cin + 8, dt, backend, zero=True).slice(8, cin); xv.set_nchw(x.detach().to(backend))
+    wp = pack_conv_weight(w, code).to(backend)
+    wf = pack_conv_weight_frag(wp, 1)
+    yv = View.alloc(N, H, W, cout + 16, dt, backend, zero=True).slice(16, cout)
+    ssum = torch.zeros(2 * 4 * cout, device=backend); ssq = torch.zeros(2 * 4 * cout, device=backend)
+    ops.conv2d(xv, wp, yv, 1, 1, stats=(ssum, ssq), tile=tile, wfrag=wf, segments=2)
+    assert _rel(yv.nchw().cpu(), y.detach()) < TOL[dt]
+    assert float(yv.buf[..., :16].float().abs().max()) == 0.0
+    for s_ in range(2):
+        ys = y.detach()[s_ * (N // 2):(s_ + 1) * (N // 2)]
+        assert _rel(ssq.view(2, 4, cout)[s_].sum(0).cpu(), (ys ** 2).sum((0, 2, 3))) < 1e-3
+        assert float((ssum.view(2, 4, cout)[s_].sum(0).cpu() - ys.sum((0, 2, 3))).abs().max()) < 1e-2 * float(ys.abs().sum((0, 2, 3)).max())
+    ref = View.alloc(N, H, W, cout, dt, backend)
+    ops.conv2d(xv, wp, ref, 1, 1, stats=(torch.zeros_like(ssum), torch.zeros_like(ssq)), tile=19, segments=2)
+    assert _rel(yv.nchw().cpu(), ref.nchw().cpu()) < 1e-2
+    # eval-style epilogue: affine + SiLU + residual
+    scale, shift = (torch.rand(cout, generator=g) + 0.5), torch.randn(cout, generator=g) * 0.3
+    res = _q(torch.randn(N, cout, H, W, generator=g), dt)
+    rv = View.alloc(N, H, W, cout, dt, backend); rv.set_nchw(res.to(backend))
+    ops.conv2d(xv, wp, yv, 1, 1, scale.to(backend), shift.to(backend), res=rv, epilogue=ops.EPI_SILU, tile=tile, wfrag=wf)
+    assert _rel(yv.nchw().cpu(), F.silu(y.detach() * scale[None, :, None, None] + shift[None, :, None, None]) + res) < TOL[dt]
+    # data gradient: dy [N,H,W,cout_pad] x W^T -> dx, then +=
+    if cout in (64, 128, 256, 512):
+        dy = _q(torch.randn(y.shape, generator=g), dt)
+        y.backward(dy)
+        dyv = View.alloc(N, H, W, cout, dt, backend); dyv.set_nchw(dy.to(backend))
+        wt = pack_conv_weight(w, code, transpose=True).to(backend)
+        wft = pack_conv_weight_frag(wt, 1)
+        dxv = View.alloc(N, H, W, cin + 32, dt, backend, zero=True).slice(32, cin)
+        if (tile == 122 and cin > 64) or (tile == 123 and cout > 256):
+            return
+        ops.conv2d(dyv, wt, dxv, 1, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wft)
+        assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
+        ops.conv2d(dyv, wt, dxv, 1, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wft, accumulate=True)
+        assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]
+        assert float(dxv.buf[..., :32].float().abs().max()) == 0.0

@@ -29,11 +29,17 @@ SHAPES = [
     ("head0.3x3", 8, 75, 120, 256, 256, 3, 1),
     ("head1.3x3", 8, 38, 60, 256, 256, 3, 1),
     ("head2.3x3", 8, 19, 30, 256, 256, 3, 1),
+    ("p4.reduce", 16, 38, 60, 512, 256, 1, 1),
+    ("d5.m.c1", 16, 19, 30, 512, 512, 1, 1),
+    ("d2.conv1", 16, 150, 240, 128, 64, 1, 1),
+    ("d3.conv1", 16, 75, 120, 256, 128, 1, 1),
+    ("head0.stem", 8, 75, 120, 256, 256, 1, 1),
 ]
 NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256", 6: "dma128x64",
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
          22: "rs128x64", 23: "rs64x64", 35: "d2-128x128", 36: "d2-64x256", 38: "d2-128x64", 39: "d2-64x64",
          51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64",
+         121: "k1-128x64", 122: "k1-64x128", 123: "k1-128x128", 117: "halo2-128x2", 118: "halo2-128x4w",
          120: "stream1x1", 112: "halo128x4", 113: "halo128x4w", 114: "halo128x2-8w", 115: "halo128x2", 116: "halo64x8",
          99: "w3-128x128", 102: "w3-128x64", 103: "w3-64x64", 24: "rs256x64", 88: "wr256x64", 89: "wr256x128", 83: "wr128x128", 84: "wr64x256", 85: "wr32x256", 86: "wr128x64", 87: "wr64x64"}
 
@@ -45,7 +51,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--chain", type=int, default=1, help="launches per timed event pair (amortises the event / launch gap)")
-    ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad"], help="dgrad: the data gradient of the layer (3x3 s1 / 1x1 shapes)")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "stats"],
+                    help="dgrad: the data gradient of the layer (3x3 s1 / 1x1 shapes); stats: training forward (raw output + BatchNorm sums)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     tiles = [int(t) for t in a.tiles.split(",")]
@@ -71,16 +78,23 @@ def main():
                 continue
             scale = shift = None
             kw = dict(mode=ops.CONV_DGRAD)
+        if a.mode == "stats":
+            scale = shift = None
+            kw = dict(stats=(torch.zeros(32 * cout, device=dev), torch.zeros(32 * cout, device=dev)), segments=2)
         flops = 2.0 * cin * cout * k * k * y.pixels
         res = []
         for t in tiles:
-            if t == 120 and (k != 1 or st != 1 or cin not in (64, 128, 256) or a.mode != "dgrad"):
+            if 121 <= (t & 255) <= 123 and (k != 1 or st != 1 or cin not in (64, 128, 256, 512) or ((t & 255) == 122 and cout > 64)
+                                            or ((t & 255) == 123 and cin > 256)):
                 res.append(float("nan"))
                 continue
-            if 112 <= t < 120 and (k != 3 or st != 1):
+            if t == 120 and (k != 1 or st != 1 or cin not in (64, 128, 256) or a.mode == "fwd"):
                 res.append(float("nan"))
                 continue
-            if t < 112 and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
+            if 112 <= (t & 255) < 120 and (k != 3 or st != 1):
+                res.append(float("nan"))
+                continue
+            if (t & 255) < 112 and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
                 res.append(float("nan"))
                 continue
             try:
