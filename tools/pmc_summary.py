@@ -12,13 +12,13 @@ cnt = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]:
-            key = (re.sub(r".*<(.*)>.*", r"\1", r["Kernel_Name"]), r.get("Grid_Size", ""))
+            key = (re.sub(r"^.*?(\w+)<(.*)>.*", r"\1<\2>", r["Kernel_Name"]), r.get("Grid_Size", ""))
             cnt[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = defaultdict(list)
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]:
-            key = (re.sub(r".*<(.*)>.*", r"\1", r["Kernel_Name"]), r.get("Grid_Size", r.get("Grid_Size_X", "")))
+            key = (re.sub(r"^.*?(\w+)<(.*)>.*", r"\1<\2>", r["Kernel_Name"]), r.get("Grid_Size", r.get("Grid_Size_X", "")))
             dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for key in sorted(set(cnt) | set(dur)):
     c = {k: sum(v) / len(v) for k, v in cnt.get(key, {}).items()}
