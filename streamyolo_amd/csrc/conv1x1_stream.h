@@ -159,18 +159,13 @@ __global__ __launch_bounds__(256, (NS <= 4 ? 3 : 2)) void conv1x1_stream_kernel(
         sy_wave_fence();                          // the patch is rewritten by the next tile
     }
     if (want_stats) {
-        // reduce over the 32 pixels of each half-wave, then one atomic per channel and kind from lanes 0 / 32
+        // reduce over the 32 pixels of each half-wave, then one atomic per channel and kind from lanes 16 / 48
         const int copy = blockIdx.z * p.stat_copies + (int)((unsigned)blockIdx.y % (unsigned)p.stat_copies);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float a = ssum[r], b = ssq[r];
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                a += __shfl_xor(a, off);
-                b += __shfl_xor(b, off);
-            }
+            const float a = sy_sum32_upper(ssum[r]), b = sy_sum32_upper(ssq[r]);
             const int co = c0 + wave * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
-            if (l31 == 0 && co < p.Cout) {
+            if (l31 == 16 && co < p.Cout) {
                 atomicAdd(p.stat_sum + (long long)copy * p.Cout + co, a);
                 atomicAdd(p.stat_sq + (long long)copy * p.Cout + co, b);
             }

@@ -40,7 +40,7 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.wfrag = (const unsigned char*)d->wfrag;
     a.wfrag_extent = (d->wfrag != nullptr && d->wfrag_bytes > 0 && d->wfrag_bytes < 0xFFFFFFF0LL) ? (unsigned)d->wfrag_bytes : 0u;
     a.tile = d->tile & 0xff;
-    a.ablate = (d->tile >> 8) & 7;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
+    a.ablate = (d->tile >> 8) & 31;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return sy_conv_launch_bf16(a, stream);

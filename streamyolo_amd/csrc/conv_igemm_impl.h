@@ -59,7 +59,7 @@ struct ConvArgs {
     unsigned x_extent, w_extent; // bytes addressable from x / w (FAST loader's buffer bounds)
     const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
     unsigned wfrag_extent;
-    int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads
+    int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads, 8 = no statistics atomics, 16 = no cross-lane statistics reduction
 };
 
 // LDS in front of the staged output tile: BN-statistics scratch [WP][CT][2] floats
@@ -670,13 +670,9 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float a = ssum[r], b = ssq[r];
-#pragma unroll
-                            for (int off = 1; off < 32; off <<= 1) {
-                                a += __shfl_xor(a, off);
-                                b += __shfl_xor(b, off);
-                            }
+                            if (!(p.ablate & 16)) { a = sy_sum32_upper(a); b = sy_sum32_upper(b); }
                             const int cl = (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
-                            if (l31 == 0) {
+                            if (l31 == 16) {
                                 red[(wp * CT + cl) * 2 + 0] = a;
                                 red[(wp * CT + cl) * 2 + 1] = b;
                             }
@@ -807,14 +803,9 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             float* red = reinterpret_cast<float*>(smem);          // [WP][CT][2]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float a = ssum[r], b = ssq[r];
-#pragma unroll
-                for (int off = 1; off < 32; off <<= 1) {
-                    a += __shfl_xor(a, off);
-                    b += __shfl_xor(b, off);
-                }
+                const float a = sy_sum32_upper(ssum[r]), b = sy_sum32_upper(ssq[r]);
                 const int cl = (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
-                if (l31 == 0) {
+                if (l31 == 16) {
                     red[(wp * CT + cl) * 2 + 0] = a;
                     red[(wp * CT + cl) * 2 + 1] = b;
                 }
@@ -845,7 +836,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             *dst = v;
         }
     }
-    if (want_stats) {
+    if (want_stats && !(p.ablate & 8)) {
         const float* red = reinterpret_cast<const float*>(smem);
         const int copy = mp.seg * p.stat_copies + (int)((unsigned)mp.rep % (unsigned)p.stat_copies);
         for (int cl = tid; cl < CT; cl += kThreads) {

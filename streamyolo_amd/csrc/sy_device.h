@@ -237,6 +237,32 @@ static inline void sy_wave_fence() { (void)__shfl(0, 0); }
 __device__ __forceinline__ void sy_wave_fence() { __builtin_amdgcn_wave_barrier(); }
 #endif
 
+// Sum of x over the 32 lanes that share lane >> 5 (the pixel columns of one MFMA accumulator half), valid in the lanes with
+// (lane & 16) != 0.  Five DPP adds on the VALU (quad swaps, half-row and row mirrors, then lane 15 of rows 0 / 2 broadcast into
+// rows 1 / 3) instead of five __shfl_xor = ds_bpermute round trips through the LDS pipeline: the conv epilogue's BatchNorm
+// statistics reduce 32 values per wave and tile, and the bpermute version was 40 % of the 1x1 kernels' time
+// (profiles/r02/m_stats_ablation.txt).
+#ifdef SY_EMU
+static inline float sy_sum32_upper(float x) {
+    for (int off = 1; off < 32; off <<= 1) x += __shfl_xor(x, off);
+    return x;
+}
+#else
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float sy_add_dpp(float x) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, true);
+    return x + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float sy_sum32_upper(float x) {
+    x = sy_add_dpp<0xB1, 0xF>(x);        // quad_perm [1, 0, 3, 2]
+    x = sy_add_dpp<0x4E, 0xF>(x);        // quad_perm [2, 3, 0, 1]
+    x = sy_add_dpp<0x141, 0xF>(x);       // row_half_mirror
+    x = sy_add_dpp<0x140, 0xF>(x);       // row_mirror: every lane of a 16-lane row holds the row's sum
+    x = sy_add_dpp<0x142, 0xA>(x);       // row_bcast15 into rows 1 and 3: + the sum of the row below
+    return x;
+}
+#endif
+
 // Scheduling fence: the compiler keeps the instruction order of a hand-pipelined loop body on both sides of it (nothing
 // is moved across); no instruction is emitted.
 #ifdef SY_EMU

@@ -401,18 +401,23 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
 
 // reduce: sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat.  Thread = (pixel row, channel chunk); register
 // partials, LDS tree over the rows of the workgroup, then ONE atomic per channel per workgroup.
+// A workgroup owns a channel SLICE of CS channels (blockIdx.z; 64 channels = one 128-byte line per pixel row), not all C:
+// the closing atomics are what this kernel waits for — the device retires ~40 G float atomics/s whatever their
+// addresses (profiles/r02/k_stats_copies.txt), 1024 workgroups x 2 C atomics were 13 us of a 21 us launch at C = 256 and 27 us
+// at C = 512 — and with slices a launch issues (workgroups x 2 CS) of them whatever C is.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typename T::elem* y, int ldy,
                                                                     const typename T::elem* da, int ldda,
                                                                     const float* scale, const float* shift,
                                                                     const float* mean, const float* invstd, float* sums,
-                                                                    long long pixels, int C, int copies) {
+                                                                    long long pixels, int C, int CS, int copies) {
     __shared__ float red[kBlock * 2 * 8];
-    const int cpp = C / T::kEPC;
+    const int cpp = CS / T::kEPC;
     const int rows = kBlock / cpp;
     const int cc = threadIdx.x % cpp;
     const int pr = threadIdx.x / cpp;
-    const int c0 = cc * T::kEPC;
+    const int cb = blockIdx.z * CS;                    // first channel of the slice
+    const int c0 = cb + cc * T::kEPC;
     {   // segment blockIdx.y
         const long long ro = (long long)blockIdx.y * pixels;
         const int ao = blockIdx.y * C;
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         const int kind = t & 1, j = (t >> 1) % T::kEPC, ch = (t >> 1) / T::kEPC;
         float v = 0.0f;
         for (int r = 0; r < rows; ++r) v += red[(j * 2 + kind) * kBlock + r * cpp + ch];
-        atomicAdd(sums + (long long)(blockIdx.x % copies) * 2 * C + kind * C + ch * T::kEPC + j, v);
+        atomicAdd(sums + (long long)(blockIdx.x % copies) * 2 * C + kind * C + cb + ch * T::kEPC + j, v);
     }
 }
 
@@ -637,10 +642,17 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
     static const int cap_reduce = env_cap("SY_BN_REDUCE_BLOCKS", 1024);
-    // (fewer workgroups = fewer of the 2 C closing atomics each was tried: 5.7 instead of 3.3 ms per l step at a 64 K atomic budget)
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, C, e, cap_reduce / nseg), nseg), dim3(kBlock), 0, stream,
+    static const int slice_max = env_cap("SY_BN_REDUCE_SLICE", 64);
+    // channel slice of a workgroup: the largest chunk multiple <= 64 channels that divides C (64 = one 128-byte line per row)
+    int CS = C;
+    for (int c = (slice_max / e) * e; c >= e; c -= e)
+        if (c <= C && C % c == 0) { CS = c; break; }
+    const int nsl = C / CS;
+    int cap = cap_reduce / (nseg * nsl);
+    if (cap < 1) cap = 1;
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_reduce_kernel<T>), dim3(row_grid(pixels, CS, e, cap), nseg, nsl), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
-                                       mean, invstd, sums, (long long)pixels, C, copies));
+                                       mean, invstd, sums, (long long)pixels, C, CS, copies));
 }
 
 extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,

@@ -53,12 +53,13 @@ def main():
     ap.add_argument("--chain", type=int, default=1, help="launches per timed event pair (amortises the event / launch gap)")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad", "stats"],
                     help="dgrad: the data gradient of the layer (3x3 s1 / 1x1 shapes); stats: training forward (raw output + BatchNorm sums)")
+    ap.add_argument("--copies", type=int, default=16, help="stats mode: replicas of the statistics arrays per segment")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     tiles = [int(t) for t in a.tiles.split(",")]
     sel = [int(i) for i in a.shapes.split(",")] if a.shapes else range(len(SHAPES))
     def nm(t):
-        return NAMES[t & 255] + {0: "", 1: "-noX", 2: "-noW", 3: "-noXW"}[t >> 8]
+        return NAMES[t & 255] + {0: "", 1: "-noX", 2: "-noW", 3: "-noXW", 8: "-noAtom", 24: "-noStatRed"}[t >> 8]
     print("%-10s %-28s " % ("layer", "shape") + " ".join("%15s" % nm(t) for t in tiles) + "   (TFLOP/s, median of %d)" % a.reps)
     for i in sel:
         name, N, Ho, Wo, cin, cout, k, st = SHAPES[i]
@@ -80,7 +81,7 @@ def main():
             kw = dict(mode=ops.CONV_DGRAD)
         if a.mode == "stats":
             scale = shift = None
-            kw = dict(stats=(torch.zeros(32 * cout, device=dev), torch.zeros(32 * cout, device=dev)), segments=2)
+            kw = dict(stats=(torch.zeros(2 * a.copies * cout, device=dev), torch.zeros(2 * a.copies * cout, device=dev)), segments=2)
         flops = 2.0 * cin * cout * k * k * y.pixels
         res = []
         for t in tiles:
