@@ -34,10 +34,17 @@ struct BF16 {   // bfloat16 storage; arithmetic is always fp32
     static constexpr int kEPC = 8;     // elements per 16-byte chunk
     static __device__ __forceinline__ float to_f32(elem h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
     static __device__ __forceinline__ elem from_f32(float f) {        // round-to-nearest-even
+#ifdef SY_EMU
         unsigned u = __builtin_bit_cast(unsigned, f);
         if ((u & 0x7fffffffu) > 0x7f800000u) return (elem)((u >> 16) | 0x40);   // quiet NaN
         u += 0x7fffu + ((u >> 16) & 1u);
         return (elem)(u >> 16);
+#else
+        // the hardware conversion (v_cvt_pk_bf16_f32, same rounding): the integer formulation above costs ~10 VALU
+        // instructions and two exec-mask branches PER ELEMENT, and the BatchNorm / pooling / resize kernels convert every
+        // element they store
+        return __builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
     }
     // two fp32 -> packed pair, round-to-nearest-even: v_cvt_pk_bf16_f32 on gfx950 (one VALU op for two elements)
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -342,7 +349,14 @@ static inline float sy_exp(float x) { return expf(x); }
 #else
 __device__ __forceinline__ float sy_exp(float x) { return __expf(x); }      // v_exp_f32 based, ~1e-6 relative
 #endif
-__device__ __forceinline__ float sy_sigmoid(float z) { return 1.0f / (1.0f + sy_exp(-z)); }
+// 1 / x to 1 ulp (v_rcp_f32) — a correctly rounded fp32 division is a 12-instruction sequence on this ISA, and every SiLU of
+// the BatchNorm passes and conv epilogues has one
+#ifdef SY_EMU
+static inline float sy_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float sy_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+__device__ __forceinline__ float sy_sigmoid(float z) { return sy_rcp(1.0f + sy_exp(-z)); }
 __device__ __forceinline__ float sy_silu(float z) { return z * sy_sigmoid(z); }
 // d silu(z)/dz = s * (1 + z * (1 - s))
 __device__ __forceinline__ float sy_silu_grad(float z) { float s = sy_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }

@@ -382,20 +382,28 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
     float sc[T::kEPC], sh[T::kEPC];
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
-    for (long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp; pix < pixels; pix += (long long)gridDim.x * rows) {
-        Chunk<T> v = Chunk<T>::load(y + pix * ldy + c0);
+    // two rows in flight per thread: the next row's loads are issued before this row's arithmetic
+    const long long step = (long long)gridDim.x * rows;
+    long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
+    Chunk<T> v, rv, vn, rn;
+    if (pix < pixels) {
+        v = Chunk<T>::load(y + pix * ldy + c0);
+        if (res != nullptr) rv = Chunk<T>::load(res + pix * ldr + c0);
+    }
+    for (; pix < pixels; pix += step) {
+        const long long nxt = pix + step;
+        if (nxt < pixels) {
+            vn = Chunk<T>::load(y + nxt * ldy + c0);
+            if (res != nullptr) rn = Chunk<T>::load(res + nxt * ldr + c0);
+        }
         Chunk<T> o;
         float r[T::kEPC];
 #pragma unroll
-        for (int j = 0; j < T::kEPC; ++j) r[j] = 0.0f;
-        if (res != nullptr) {
-            Chunk<T> rv = Chunk<T>::load(res + pix * ldr + c0);
-#pragma unroll
-            for (int j = 0; j < T::kEPC; ++j) r[j] = T::to_f32(rv.e[j]);
-        }
+        for (int j = 0; j < T::kEPC; ++j) r[j] = res != nullptr ? T::to_f32(rv.e[j]) : 0.0f;
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
         o.store(out + pix * ldo + c0);
+        v = vn; rv = rn;
     }
 }
 
@@ -431,9 +439,12 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         s0[j] = 0.0f; s1[j] = 0.0f;
     }
     const long long first = pr < rows ? (long long)blockIdx.x * rows + pr : pixels;     // idle tail threads skip the loop
-    for (long long pix = first; pix < pixels; pix += (long long)gridDim.x * rows) {
-        Chunk<T> yv = Chunk<T>::load(y + pix * ldy + c0);
-        Chunk<T> gv = Chunk<T>::load(da + pix * ldda + c0);
+    const long long step = (long long)gridDim.x * rows;
+    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread
+    if (first < pixels) { yv = Chunk<T>::load(y + first * ldy + c0); gv = Chunk<T>::load(da + first * ldda + c0); }
+    for (long long pix = first; pix < pixels; pix += step) {
+        const long long nxt = pix + step;
+        if (nxt < pixels) { yn = Chunk<T>::load(y + nxt * ldy + c0); gn = Chunk<T>::load(da + nxt * ldda + c0); }
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) {
             const float yy = T::to_f32(yv.e[j]);
@@ -441,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
             s0[j] += dz;
             s1[j] += dz * ((yy - mu[j]) * is[j]);
         }
+        yv = yn; gv = gn;
     }
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) {
@@ -504,9 +516,13 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         m0[j] = s_fold[c] * inv_m;
         m1[j] = s_fold[C + c] * inv_m;
     }
-    for (long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp; pix < pixels; pix += (long long)gridDim.x * rows) {
-        Chunk<T> yv = Chunk<T>::load(y + pix * ldy + c0);
-        Chunk<T> gv = Chunk<T>::load(da + pix * ldda + c0);
+    const long long step = (long long)gridDim.x * rows;
+    long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
+    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread
+    if (pix < pixels) { yv = Chunk<T>::load(y + pix * ldy + c0); gv = Chunk<T>::load(da + pix * ldda + c0); }
+    for (; pix < pixels; pix += step) {
+        const long long nxt = pix + step;
+        if (nxt < pixels) { yn = Chunk<T>::load(y + nxt * ldy + c0); gn = Chunk<T>::load(da + nxt * ldda + c0); }
         Chunk<T> o;
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) {
@@ -524,6 +540,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
             }
             gv.store(dst);
         }
+        yv = yn; gv = gn;
     }
 }
 
