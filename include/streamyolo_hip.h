@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 2
+#define SY_ABI_VERSION 3
 #define SY_API __attribute__((visibility("default")))
 
 enum { SY_DT_BF16 = 0, SY_DT_F16 = 1, SY_DT_F32 = 2 };
@@ -236,6 +236,16 @@ typedef struct sy_bn_running_entry {
     float momentum;
 } sy_bn_running_entry;
 SY_API int sy_bn_running_update(const sy_bn_running_entry* entries, int n_entries, int max_C, void* stream);
+/* sy_bn_finalize + sy_bn_silu_apply in one launch (the training forward of every BaseConv: nn.BatchNorm2d in training mode
+   followed by nn.SiLU, yolox BaseConv.forward; one kernel boundary less on the critical path per layer).  Statistics
+   [nseg][copies][C] as sy_conv2d's epilogue leaves them, count = elements per channel per segment; scale / shift / mean /
+   invstd [nseg][C] are OUTPUTS (the backward pass reads them); running statistics: sy_bn_running_update.  C must have a
+   divisor <= 64 that is a multiple of the 16-byte chunk (every width of the reference's models has). */
+SY_API int sy_bn_finalize_apply(const float* sum, const float* sqsum, int copies, double count, const float* gamma,
+                                const float* beta, float eps, float* scale, float* shift, float* mean, float* invstd,
+                                const void* y, int ldy, const void* res, int ldr, void* out, int ldo, int64_t pixels, int C,
+                                int dtype, int nseg, void* stream);
+
 /* a = silu(scale*y + shift) [+ res], y raw conv output; views as in sy_conv2d. */
 SY_API int sy_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift, const void* res,
                      int ldr, void* out, int ldo, int64_t pixels, int C, int dtype, int nseg, void* stream);

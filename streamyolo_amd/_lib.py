@@ -101,6 +101,7 @@ SIGNATURES = {
     "sy_bn_running_update": (_I, [_P, _I, _I, _P]),
     "sy_bn_finalize": (_I, [_P, _P, _I, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
     "sy_bn_silu_apply": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
+    "sy_bn_finalize_apply": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
@@ -127,7 +128,7 @@ def _bind(path):
             raise HipLibraryError("streamyolo_amd: %s lacks symbol %s (stale build?)" % (path, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sy_abi_version() != 2:
+    if lib.sy_abi_version() != 3:
         raise HipLibraryError("streamyolo_amd: ABI version mismatch in %s" % path)
     return lib
 
@@ -136,8 +137,10 @@ def lib():
     """The bound library (loads libstreamyolo_hip.so on first use; raises HipLibraryError if absent)."""
     global _lib, _lib_path
     if _lib is None:
-        _lib = _bind(DEFAULT_PATH)
-        _lib_path = DEFAULT_PATH
+        # STREAMYOLO_HIP_LIB: another build of the SAME library (A/B timing of two kernel versions on one box, tools/)
+        path = os.environ.get("STREAMYOLO_HIP_LIB") or DEFAULT_PATH
+        _lib = _bind(path)
+        _lib_path = path
     return _lib if _tape is None else _TapeProxy(_lib, _tape)
 
 

@@ -379,10 +379,9 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
         y += ro * ldy; out += ro * ldo; scale += blockIdx.y * C; shift += blockIdx.y * C;
         if (res != nullptr) res += ro * ldr;
     }
-    float sc[T::kEPC], sh[T::kEPC];
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
-    // two rows in flight per thread: the next row's loads are issued before this row's arithmetic
+    // two rows in flight per thread: the next row's loads are issued before this row's arithmetic, and the FIRST row's
+    // before the per-channel parameters (independent latencies overlap: these launches last 10-20 us, a dependent chain of
+    // three memory round trips at their head was a quarter of that)
     const long long step = (long long)gridDim.x * rows;
     long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
     Chunk<T> v, rv, vn, rn;
@@ -390,6 +389,94 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
         v = Chunk<T>::load(y + pix * ldy + c0);
         if (res != nullptr) rv = Chunk<T>::load(res + pix * ldr + c0);
     }
+    float sc[T::kEPC], sh[T::kEPC];
+#pragma unroll
+    for (int j = 0; j < T::kEPC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+    for (; pix < pixels; pix += step) {
+        const long long nxt = pix + step;
+        if (nxt < pixels) {
+            vn = Chunk<T>::load(y + nxt * ldy + c0);
+            if (res != nullptr) rn = Chunk<T>::load(res + nxt * ldr + c0);
+        }
+        Chunk<T> o;
+        float r[T::kEPC];
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) r[j] = res != nullptr ? T::to_f32(rv.e[j]) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
+        o.store(out + pix * ldo + c0);
+        v = vn; rv = rn;
+    }
+}
+
+// bn_finalize + bn_silu_apply in ONE launch.  A dependent launch on the step's critical path costs ~13 us whatever it does
+// (kernel boundary: drain, L2 write-back, dispatch — measured by skipping the 128 finalize launches of an l step: -1.7 ms,
+// profiles/r02/s_*), so the 4 us finalize kernel is folded into the apply pass: a workgroup owns a channel SLICE (CS <= 64
+// channels = one 128-byte line per pixel row, blockIdx.z) of a row range, folds the statistic replicas of ITS slice only
+// (2 x copies x CS loads per workgroup, in the order bn_finalize_kernel / bn_running_update_kernel use: eight float partials per
+// channel, summed in double), derives the affine in LDS, and streams its rows; the first row's loads are in flight meanwhile.
+// The workgroups with blockIdx.x == 0 also publish scale / shift / mean / invstd for the backward pass.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bn_finalize_apply_kernel(const float* sum, const float* sqsum, int copies, double count,
+                                                                   const float* gamma, const float* beta, float eps,
+                                                                   float* scale, float* shift, float* mean_out,
+                                                                   float* invstd_out, const typename T::elem* y, int ldy,
+                                                                   const typename T::elem* res, int ldr,
+                                                                   typename T::elem* out, int ldo, long long pixels, int C,
+                                                                   int CS) {
+    __shared__ float s_part[2][8][64];
+    __shared__ float s_aff[2][64];
+    const int cpp = CS / T::kEPC;
+    const int rows = kBlock / cpp;
+    const int cc = threadIdx.x % cpp;
+    const int cb = blockIdx.z * CS;
+    const int c0 = cb + cc * T::kEPC;
+    {   // segment blockIdx.y: rows [seg * pixels, (seg + 1) * pixels), statistics [seg][copies][C], affine [seg][C]
+        const long long ro = (long long)blockIdx.y * pixels;
+        const long long so = (long long)blockIdx.y * copies * C;
+        const int ao = blockIdx.y * C;
+        y += ro * ldy; out += ro * ldo;
+        if (res != nullptr) res += ro * ldr;
+        sum += so; sqsum += so; scale += ao; shift += ao; mean_out += ao; invstd_out += ao;
+    }
+    const bool live = (int)threadIdx.x < rows * cpp;
+    const long long step = (long long)gridDim.x * rows;
+    long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
+    Chunk<T> v, rv, vn, rn;
+    if (live && pix < pixels) {
+        v = Chunk<T>::load(y + pix * ldy + c0);
+        if (res != nullptr) rv = Chunk<T>::load(res + pix * ldr + c0);
+    }
+    // ---- fold the replicas of this slice: item = (kind, replica group rg, channel c)
+    for (int it = threadIdx.x; it < 2 * 8 * CS; it += kBlock) {
+        const int c = it % CS, rg = (it / CS) & 7, kind = it / (8 * CS);
+        const float* src = (kind ? sqsum : sum) + cb + c;
+        float a = 0.0f;
+        for (int k = rg; k < copies; k += 8) a += src[(long long)k * C];
+        s_part[kind][rg][c] = a;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < CS) {
+        const int c = threadIdx.x;
+        double ds = 0.0, dq = 0.0;
+        for (int k = 0; k < 8; ++k) { ds += (double)s_part[0][k][c]; dq += (double)s_part[1][k][c]; }
+        const double mean = ds / count;
+        double var = dq / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[cb + c] * invstd;
+        const float sh = beta[cb + c] - (float)mean * sc;
+        s_aff[0][c] = sc;
+        s_aff[1][c] = sh;
+        if (blockIdx.x == 0) {
+            scale[cb + c] = sc; shift[cb + c] = sh; mean_out[cb + c] = (float)mean; invstd_out[cb + c] = invstd;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float sc[T::kEPC], sh[T::kEPC];
+#pragma unroll
+    for (int j = 0; j < T::kEPC; ++j) { sc[j] = s_aff[0][cc * T::kEPC + j]; sh[j] = s_aff[1][cc * T::kEPC + j]; }
     for (; pix < pixels; pix += step) {
         const long long nxt = pix + step;
         if (nxt < pixels) {
@@ -432,16 +519,16 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         y += ro * ldy; da += ro * ldda; scale += ao; shift += ao; mean += ao; invstd += ao;
         sums += (long long)blockIdx.y * copies * 2 * C;
     }
+    const long long first = pr < rows ? (long long)blockIdx.x * rows + pr : pixels;     // idle tail threads skip the loop
+    const long long step = (long long)gridDim.x * rows;
+    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread; the first row's loads go out before the parameters'
+    if (first < pixels) { yv = Chunk<T>::load(y + first * ldy + c0); gv = Chunk<T>::load(da + first * ldda + c0); }
     float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], s0[T::kEPC], s1[T::kEPC];
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) {
         sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
         s0[j] = 0.0f; s1[j] = 0.0f;
     }
-    const long long first = pr < rows ? (long long)blockIdx.x * rows + pr : pixels;     // idle tail threads skip the loop
-    const long long step = (long long)gridDim.x * rows;
-    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread
-    if (first < pixels) { yv = Chunk<T>::load(y + first * ldy + c0); gv = Chunk<T>::load(da + first * ldda + c0); }
     for (long long pix = first; pix < pixels; pix += step) {
         const long long nxt = pix + step;
         if (nxt < pixels) { yn = Chunk<T>::load(y + nxt * ldy + c0); gn = Chunk<T>::load(da + nxt * ldda + c0); }
@@ -493,6 +580,12 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
     const int cc = threadIdx.x % cpp;
     const int c0 = cc * T::kEPC;
     const float inv_m = 1.0f / (float)pixels;
+    // the first row's loads go out before the replica fold, its barrier and the parameter loads (independent latencies overlap)
+    const long long step = (long long)gridDim.x * rows;
+    long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
+    const bool live = (int)threadIdx.x < rows * cpp;
+    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread
+    if (live && pix < pixels) { yv = Chunk<T>::load(y + pix * ldy + c0); gv = Chunk<T>::load(da + pix * ldda + c0); }
     for (int i = threadIdx.x; i < 2 * C; i += kBlock) {
         float a = 0.0f;
         for (int k = 0; k < copies; ++k) a += sums[(long long)k * 2 * C + i];
@@ -516,10 +609,6 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         m0[j] = s_fold[c] * inv_m;
         m1[j] = s_fold[C + c] * inv_m;
     }
-    const long long step = (long long)gridDim.x * rows;
-    long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
-    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread
-    if (pix < pixels) { yv = Chunk<T>::load(y + pix * ldy + c0); gv = Chunk<T>::load(da + pix * ldda + c0); }
     for (; pix < pixels; pix += step) {
         const long long nxt = pix + step;
         if (nxt < pixels) { yn = Chunk<T>::load(y + nxt * ldy + c0); gn = Chunk<T>::load(da + nxt * ldda + c0); }
@@ -649,6 +738,31 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
+}
+
+extern "C" int sy_bn_finalize_apply(const float* sum, const float* sqsum, int copies, double count, const float* gamma,
+                                    const float* beta, float eps, float* scale, float* shift, float* mean, float* invstd,
+                                    const void* y, int ldy, const void* res, int ldr, void* out, int ldo, int64_t pixels, int C,
+                                    int dtype, int nseg, void* stream) {
+    if (sum == nullptr || sqsum == nullptr || gamma == nullptr || beta == nullptr || scale == nullptr || shift == nullptr ||
+        mean == nullptr || invstd == nullptr || y == nullptr || out == nullptr || copies <= 0 || count <= 0.0 || pixels <= 0 ||
+        C <= 0 || nseg < 1)
+        return SY_ERR_ARG;
+    const int e = epc_of(dtype);
+    if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
+    // channel slice of a workgroup: the largest chunk multiple <= 64 channels that divides C
+    int CS = C;
+    for (int c = (64 / e) * e; c >= e; c -= e)
+        if (c <= C && C % c == 0) { CS = c; break; }
+    if (CS > 64) return SY_ERR_UNSUPPORTED;
+    const int nsl = C / CS;
+    static const int cap_fa = env_cap("SY_BN_FAPPLY_BLOCKS", 2048);
+    int cap = cap_fa / (nseg * nsl);
+    if (cap < 1) cap = 1;
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_finalize_apply_kernel<T>), dim3(row_grid(pixels, CS, e, cap), nseg, nsl), dim3(kBlock), 0,
+                                       stream, sum, sqsum, copies, count, gamma, beta, eps, scale, shift, mean, invstd,
+                                       (const typename T::elem*)y, ldy, (const typename T::elem*)res, ldr,
+                                       (typename T::elem*)out, ldo, (long long)pixels, C, CS));
 }
 
 extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,

@@ -263,6 +263,16 @@ def bn_finalize(ssum, ssq, count, gamma, beta, eps, momentum, running_mean, runn
                                     stream_of(ssum)), "sy_bn_finalize")
 
 
+def bn_finalize_apply(ssum, ssq, count, gamma, beta, eps, scale, shift, mean, invstd, y, out, res=None, nseg=1):
+    """sy_bn_finalize + sy_bn_silu_apply in one launch (training forward); scale / shift / mean / invstd are outputs."""
+    C_ = gamma.numel()
+    check(_lib.lib().sy_bn_finalize_apply(ssum.data_ptr(), ssq.data_ptr(), ssum.numel() // (nseg * C_), float(count),
+                                          gamma.data_ptr(), beta.data_ptr(), float(eps), scale.data_ptr(), shift.data_ptr(),
+                                          mean.data_ptr(), invstd.data_ptr(), y.ptr(), y.ld,
+                                          None if res is None else res.ptr(), 0 if res is None else res.ld, out.ptr(), out.ld,
+                                          y.pixels // nseg, y.C, y.dtype, nseg, stream_of(y.buf)), "sy_bn_finalize_apply")
+
+
 class BnRunningTable:
     """Device table for sy_bn_running_update.  `modules` = [(bn_module, [(sum, sqsum, count), ...calls in order])]."""
 
@@ -481,7 +491,9 @@ _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 102
                      (17, 256), (33, 256), (18, 256),
                      # 3x3 stride 1: all nine taps per workgroup (conv_wgrad9_kernel); few splits: the split-K slabs + fold are a
                      # third of its time at 1024 workgroups (profiles/r02/f_wgrad_probe.txt)
-                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512)]
+                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512),
+                     # ... on eight waves (conv_wgrad9b_kernel)
+                     (51, 128), (51, 256), (67, 256), (67, 512)]
 _wgrad_cache = {}
 
 
@@ -499,7 +511,7 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
     dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
     best, best_t = (0, 0), float("inf")
     for (t, tb) in _WGRAD_CANDIDATES:
-        if t in (49, 65):
+        if t in (49, 65, 51, 67):
             if k != 3 or stride != 1 or Cin % 32 or Cout % 16:
                 continue
         elif (t & 15) in (1, 5, 6) and Cout < 128:

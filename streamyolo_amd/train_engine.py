@@ -32,6 +32,11 @@ from .model.plan_cache import compute_dtype_for
 from .ops import View, EPI_LINEAR, CONV_DGRAD
 
 
+# one launch for BatchNorm finalize + BN.SiLU apply (sy_bn_finalize_apply); "0": the two separate launches (A/B timing)
+# (default off: kernel time 2.77 vs 2.90 ms per l step, but the step itself is not faster at 32 statistic replicas, and the 8
+# replicas that make it 0.26 ms faster break the 1e-5 run-to-run reproducibility of the fp16 step — profiles/r02/t_*, u_*)
+_FUSED_FINALIZE = __import__("os").environ.get("STREAMYOLO_FUSED_FINALIZE", "0") != "0"
+
 class _GradSpace:
     """Gradient mirrors of activation buffers + first-write / accumulate bookkeeping per channel range."""
 
@@ -416,9 +421,13 @@ class TrainPlan:
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
                    wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
         mom = bn.momentum if bn.momentum is not None else 0.1
-        ops.bn_finalize(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, mom, None, None, scale, shift, mean, invstd,
-                        nseg=2)
-        ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
+        if _FUSED_FINALIZE:
+            ops.bn_finalize_apply(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, scale, shift, mean, invstd, raw2, y2,
+                                  res=None if a.res is None else a.res.pair(), nseg=2)
+        else:
+            ops.bn_finalize(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, mom, None, None, scale, shift, mean, invstd,
+                            nseg=2)
+            ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
 
     # ---- launch programs ------------------------------------------------------------------------------------
     # Step 1 runs the Python wrappers directly (kernel variants get tuned).  Step 2 runs them again under
@@ -523,9 +532,13 @@ class TrainPlan:
             mom = bn.momentum if bn.momentum is not None else 0.1
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
-            ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
-                            None, None, scale, shift, mean, invstd)
-            ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
+            if _FUSED_FINALIZE:
+                ops.bn_finalize_apply(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, scale, shift, mean, invstd,
+                                      op.yraw, op.y, res=op.res)
+            else:
+                ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
+                                None, None, scale, shift, mean, invstd)
+                ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
         elif k == "resize":
             ops.resize_nearest(op.src, op.dst)
         elif k == "spp":
@@ -787,7 +800,7 @@ class TrainPlan:
         """Per-op-kind kernel time (ms / step) with HIP events on the launch stream (bench.py roofline).
         detail=True: per (kind, shape) rows [(kind, shape, launches / step, ms / step, flops / step)] instead."""
         evs = []
-        real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply",
+        real = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_silu_apply", "bn_finalize_apply",
                                              "bn_silu_bwd_reduce", "bn_silu_bwd_apply", "resize_nearest",
                                              "resize_nearest_bwd", "spp_pool", "spp_pool_bwd", "view_copy", "focus_pack")}
 

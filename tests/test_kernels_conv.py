@@ -227,7 +227,7 @@ def test_conv3x3_halo_kernel(backend, tile, dt, mode):
         assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("tile", [49, 65])
+@pytest.mark.parametrize("tile", [49, 65, 51, 67])
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 144, 7, 37), (1, 32, 48, 5, 70)])
 def test_wgrad_all_taps_kernel(backend, tile, N, cin, cout, H, W):
     """conv_wgrad9_kernel (tile codes 49 / 65): 3x3 stride-1 weight gradient with all nine taps per workgroup and the x halo

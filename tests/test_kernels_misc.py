@@ -140,6 +140,43 @@ def test_bn_train_silu_fwd_bwd(backend, dt, C):
     assert torch.equal(drv.nchw(), want)
 
 
+@pytest.mark.parametrize("dt,C,copies,nseg", [("bf16", 192, 32, 2), ("bf16", 16, 3, 1), ("fp16", 96, 8, 2), ("fp32", 64, 32, 1), ("bf16", 512, 8, 2)])
+def test_bn_finalize_apply_fused_equals_the_two_launches(backend, dt, C, copies, nseg):
+    """sy_bn_finalize_apply (one launch, channel-sliced workgroups folding their own replicas) == sy_bn_finalize followed by
+    sy_bn_silu_apply, bit for bit: same fold order, same double-precision finalize, same apply arithmetic; with a residual and
+    per-frame statistics segments."""
+    g = torch.Generator().manual_seed(C + copies)
+    N, H, W = 2 * nseg, 5, 7
+    tdt = ops.TORCH_DTYPE[ops.dtype_code(dt)]
+    dev = backend
+    y = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(tdt).float()
+    res = torch.randn(N, C, H, W, generator=g).to(tdt).float()
+    yv = View.alloc(N, H, W, C, dt, dev); yv.set_nchw(y.to(dev))
+    rv = View.alloc(N, H, W, C + 8, dt, dev).slice(8, C); rv.set_nchw(res.to(dev))
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+    # replica arrays [nseg][copies][C] with the per-segment sums spread unevenly over the replicas
+    per = N // nseg
+    parts = torch.rand(nseg, copies, C, generator=g) + 0.1
+    parts = parts / parts.sum(1, keepdim=True)
+    ssum = torch.stack([y[s * per:(s + 1) * per].sum((0, 2, 3)) for s in range(nseg)])[:, None, :] * parts
+    ssq = torch.stack([(y[s * per:(s + 1) * per] ** 2).sum((0, 2, 3)) for s in range(nseg)])[:, None, :] * parts
+    ssum, ssq = ssum.reshape(-1).contiguous().to(dev), ssq.reshape(-1).contiguous().to(dev)
+    count = per * H * W
+    a = [torch.empty(nseg * C, device=dev) for _ in range(4)]
+    b = [torch.empty(nseg * C, device=dev) for _ in range(4)]
+    o1, o2 = View.alloc(N, H, W, C, dt, dev), View.alloc(N, H, W, C + 16, dt, dev, zero=True).slice(16, C)
+    ops.bn_finalize(ssum, ssq, count, gamma, beta, 1e-3, 0.03, None, None, *a, nseg=nseg)
+    ops.bn_silu_apply(yv, a[0], a[1], o1, res=rv, nseg=nseg)
+    ops.bn_finalize_apply(ssum, ssq, count, gamma, beta, 1e-3, *b, yv, o2, res=rv, nseg=nseg)
+    for t1, t2 in zip(a, b):
+        assert torch.equal(t1, t2)
+    assert torch.equal(o1.nchw(), o2.nchw())
+    assert float(o2.buf[..., :16].float().abs().max()) == 0.0
+    ref = torch.cat([F.silu(F.batch_norm(y[s * per:(s + 1) * per], None, None, gamma.cpu(), beta.cpu(), True, 0.03, 1e-3))
+                     for s in range(nseg)]) + res
+    assert _rel(o2.nchw().cpu(), ref) < (2e-2 if dt == "bf16" else 2e-3 if dt == "fp16" else 1e-5)
+
+
 def test_bn_running_update_batched(backend):
     """sy_bn_running_update: several modules in one launch; a module called twice applies both momentum updates in
     call order (dfp_pafpn.py:120-165 calls the shared backbone per frame, current frame first)."""

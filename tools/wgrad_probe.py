@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--chain", type=int, default=1, help="launches per timed event pair")
     ap.add_argument("--variants", default="", help="tile/target pairs, e.g. 17/2048,18/256")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -37,9 +38,9 @@ def main():
         flops = 2.0 * cin * cout * k * k * dy.pixels
         res = []
         for (t, tb) in variants:
-            if t in (49, 65) and (k != 3 or st != 1 or cin % 32):
+            if (t & 255) in (49, 65, 51, 67) and (k != 3 or st != 1 or cin % 32):
                 res.append(float("nan")); continue
-            if t < 48 and (t & 15) in (1, 5, 6) and cout < 128 and t != 0:
+            if (t & 255) < 48 and (t & 15) in (1, 5, 6) and cout < 128 and t != 0:
                 res.append(float("nan")); continue
             try:
                 ops.conv2d_wgrad(x, dy, dw, k, st, oihw=True, workspace=ws, tile=t, target_blocks=tb)
@@ -48,10 +49,11 @@ def main():
                 for _ in range(a.reps):
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
-                    ops.conv2d_wgrad(x, dy, dw, k, st, oihw=True, workspace=ws, tile=t, target_blocks=tb)
+                    for _ in range(a.chain):
+                        ops.conv2d_wgrad(x, dy, dw, k, st, oihw=True, workspace=ws, tile=t, target_blocks=tb)
                     e.record()
                     torch.cuda.synchronize()
-                    ts.append(s.elapsed_time(e))
+                    ts.append(s.elapsed_time(e) / a.chain)
                 ts.sort()
                 res.append(flops / (ts[len(ts) // 2] * 1e-3) / 1e12)
             except Exception as ex:                                    # noqa: BLE001
