@@ -305,7 +305,9 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
 // straddles a tap) and buffer-addressable operands.
 constexpr int kSubPitch = 1024 + 128;
 
-template <typename T, int WR, int WC, int TR, int TC, int STG>
+// LIN = 1: 1x1 stride-1 layer over dense tensors (xbs = H W ldx, dybs = Ho Wo lddy): pixel m lives at element m * ld of both
+// operands, a slab's addresses are per-lane constants + one wave-uniform offset, validity is m < M.
+template <typename T, int WR, int WC, int TR, int TC, int STG, int LIN>
 __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
     constexpr int RT = WR * TR * 32, CT = WC * TC * 32;
     constexpr int SA = RT / 16, SB = CT / 16, NS = SA + SB;
@@ -330,6 +332,10 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
 
     // ---- DMA assignment: wave w fills X subtiles w + 4 j (j < LA) and dY subtiles w + 4 j (j < LB).
     //      Lane -> (pixel lane>>1, 16-byte channel half lane&1).
+    // These kernels are instruction-issue bound (profiles/r02/r_pmc_wgrad.txt: 40 instructions per MFMA on the 1x1 layers):
+    // the ring is kept full past the last slab (out-of-range pieces deposit zeros into an idle stage) so the wait in front of a
+    // slab is ONE counted vmcnt, a piece's offset is OR-ed with an all-ones mask instead of selected (hipcc turns the select
+    // into an exec-mask branch), and all fragments of a slab are requested before its first MFMA.
     constexpr int LA = SA / 4, LB = SB / 4;
     static_assert(SA % 4 == 0 && SB % 4 == 0, "every wave stages the same number of subtiles of each operand");
     const int wv = sy_uniform(wave);
@@ -341,9 +347,9 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
         const int k = r0 + (wv + 4 * j) * 16;
         a_ok[j] = k < p.K;
         const int kk = a_ok[j] ? k : 0;
-        const int tap = kk / p.Cin;
+        const int tap = LIN ? 0 : kk / p.Cin;
         const int ci = kk - tap * p.Cin;
-        a_dh[j] = tap / p.KW;
+        a_dh[j] = LIN ? 0 : tap / p.KW;
         a_dw[j] = tap - a_dh[j] * p.KW;
         a_rel[j] = (a_dh[j] * p.W + a_dw[j]) * p.ldx + ci + half8;
     }
@@ -357,35 +363,44 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
     const sy_buffer bufdy = sy_make_buffer(p.dy, p.dy_extent);
     const sy_lds_base_t lds0 = sy_lds_base(smem);
     PixelCursor cur;
-    cur.init(slab0 * SLAB + (lane >> 1), p.Ho, p.Wo);
+    if (!LIN) cur.init(slab0 * SLAB + (lane >> 1), p.Ho, p.Wo);
+    int m_next = slab0 * SLAB;                    // LIN: first pixel of the next slab to issue (wave-uniform)
+    const int m_lane = lane >> 1;
 
     int issued = 0, stage_w = 0;
     auto issue_slab = [&]() {
         const unsigned stage = (unsigned)(stage_w * STAGE + wv * kSubPitch);
-        const bool m_ok = cur.m < p.M;
-        const int hb = cur.ho * p.stride - p.pad, wb = cur.wo * p.stride - p.pad;
-        const int xo = cur.n * (int)p.xbs + (hb * p.W + wb) * p.ldx;
-        const int yo = cur.n * (int)p.dybs + (cur.ho * p.Wo + cur.wo) * p.lddy;
+        const bool live = issued < nslab;
+        if constexpr (LIN) {
+            const bool m_ok = live && m_next + m_lane < p.M;
+            const int xo = (m_next + m_lane) * p.ldx, yo = (m_next + m_lane) * p.lddy;
 #pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            const int hi = hb + a_dh[j], wi = wb + a_dw[j];
-            const bool ok = m_ok && a_ok[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            sy_glds16_buf_at(bufx, ok ? (unsigned)((xo + a_rel[j]) * 2) : 0xFFFFFFFFu, lds0, stage + 4 * j * kSubPitch);
+            for (int j = 0; j < LA; ++j)
+                sy_glds16_buf_at(bufx, (unsigned)((xo + a_rel[j]) * 2) | ((m_ok && a_ok[j]) ? 0u : 0xFFFFFFFFu), lds0, stage + 4 * j * kSubPitch);
+#pragma unroll
+            for (int j = 0; j < LB; ++j)
+                sy_glds16_buf_at(bufdy, (unsigned)((yo + b_rel[j]) * 2) | ((m_ok && b_ok[j]) ? 0u : 0xFFFFFFFFu), lds0,
+                                 stage + (SA + 4 * j) * kSubPitch);
+            m_next += SLAB;
+        } else {
+            const bool m_ok = live && cur.m < p.M;
+            const int hb = cur.ho * p.stride - p.pad, wb = cur.wo * p.stride - p.pad;
+            const int xo = cur.n * (int)p.xbs + (hb * p.W + wb) * p.ldx;
+            const int yo = cur.n * (int)p.dybs + (cur.ho * p.Wo + cur.wo) * p.lddy;
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int hi = hb + a_dh[j], wi = wb + a_dw[j];
+                const bool ok = m_ok && a_ok[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                sy_glds16_buf_at(bufx, (unsigned)((xo + a_rel[j]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0, stage + 4 * j * kSubPitch);
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j)
+                sy_glds16_buf_at(bufdy, (unsigned)((yo + b_rel[j]) * 2) | ((m_ok && b_ok[j]) ? 0u : 0xFFFFFFFFu), lds0,
+                                 stage + (SA + 4 * j) * kSubPitch);
+            if (live) cur.advance(SLAB, p.Ho, p.Wo);
         }
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-            sy_glds16_buf_at(bufdy, (m_ok && b_ok[j]) ? (unsigned)((yo + b_rel[j]) * 2) : 0xFFFFFFFFu, lds0,
-                             stage + (SA + 4 * j) * kSubPitch);
-        cur.advance(SLAB, p.Ho, p.Wo);
         ++issued;
         stage_w = (stage_w + 1 == STG) ? 0 : stage_w + 1;
-    };
-    auto wait_slab = [&](int ahead) {             // at most `ahead` later slabs of this wave's loads still in flight
-        constexpr int LJ2 = LA + LB;
-        if (ahead >= 3) sy_wait_vmcnt<3 * LJ2>();
-        else if (ahead == 2) sy_wait_vmcnt<2 * LJ2>();
-        else if (ahead == 1) sy_wait_vmcnt<LJ2>();
-        else sy_wait_vmcnt<0>();
     };
 
     f32x16 acc[TR][TC];
@@ -400,35 +415,38 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
     // [+4 for the second half of its 8 k-values], column quad i&3 of subtile 2*tile + parity
     const int lane_off = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 
-    for (int j = 0; j < STG - 1 && j < nslab; ++j) issue_slab();
+    for (int j = 0; j < STG - 1; ++j) issue_slab();
     int stage_r = 0;
     for (int s = 0; s < nslab; ++s) {
-        wait_slab(issued - s - 1);
-        sy_barrier();                             // slab s complete for every wave; everyone is past slab s-1
-        if (issued < nslab) issue_slab();
+        sy_wait_vmcnt<(STG - 2) * (LA + LB)>();   // slab s landed; the STG - 2 slabs behind it stay in flight
+        sy_barrier();                             // ... for every wave; everyone is past slab s-1
+        issue_slab();
         const unsigned char* const base = smem + stage_r * STAGE + lane_off;
         stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
+        uint4 a[2][TR], b[2][TC];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 a[TR], b[TC];
 #pragma unroll
             for (int t = 0; t < TR; ++t) {
                 const unsigned char* ptr = base + ((wr * TR + t) * 2) * kSubPitch + ks * 512;
                 const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
-                a[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                a[ks][t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
                 const unsigned char* ptr = base + (SA + (wcn * TC + u) * 2) * kSubPitch + ks * 512;
                 const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
-                b[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                b[ks][u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int t = 0; t < TR; ++t)
 #pragma unroll
-                for (int u = 0; u < TC; ++u) acc[t][u] = sy_mfma_group(T(), a[t], b[u], acc[t][u]);
-        }
+                for (int u = 0; u < TC; ++u) acc[t][u] = sy_mfma_group(T(), a[ks][t], b[ks][u], acc[t][u]);
     }
+    sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
     wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
 }
 
@@ -463,22 +481,34 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
     if (nslab <= 0) return;
 
     // ---- DMA assignment per slab: wave w issues x instructions {w, w + 4} (subtile j >> 2, 32-pixel quarter j & 3 of the
-    //      flattened 3 x 34 window) and dy subtiles {w, w + 4}; lane -> (pixel lane >> 1, 16-byte channel half lane & 1)
+    //      flattened 3 x 34 window) and dy subtiles {w, w + 4}; lane -> (pixel lane >> 1, 16-byte channel half lane & 1).
+    //      The kernel is instruction-issue bound (profiles/r02/r_pmc_wgrad.txt: 183 instructions per 18 MFMAs), so a slab's
+    //      addresses are per-lane constants + ONE wave-uniform element offset per operand, validity is two unsigned compares per
+    //      piece, and the ring is kept full past the last slab (out-of-range pieces: zeros into an idle stage) so that the wait in
+    //      front of every slab is the same counted `vmcnt`.
     const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
     const sy_buffer bufdy = sy_make_buffer(p.dy, p.dy_extent);
     const sy_lds_base_t lds0 = sy_lds_base(smem);
     const int half8 = (lane & 1) * 8;
-    int x_hy[2], x_hx[2], x_c[2];
-    bool x_ok[2];
+    int x_rel[2], x_hy1[2], x_hx1[2];               // element offset relative to pixel (cur_h, w0); window row / column - 1
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int j = wv + 4 * i;
         const int pp = (j & 3) * 32 + (lane >> 1);             // flattened halo pixel
-        x_ok[i] = pp < kHaloPix;
-        x_hy[i] = pp / 34;
-        x_hx[i] = pp - x_hy[i] * 34;
-        x_c[i] = ci0 + (j >> 2) * 16 + half8;
+        const int hy = pp / 34, hx = pp - hy * 34;
+        x_hy1[i] = pp < kHaloPix ? hy - 1 : 0x40000000;        // beyond the window: never valid
+        x_hx1[i] = hx - 1;
+        x_rel[i] = ((hy - 1) * p.W + (hx - 1)) * p.ldx + ci0 + (j >> 2) * 16 + half8;
     }
+    int y_rel[2];
+    bool y_cok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co = c0 + (wv + 4 * i) * 16 + half8;
+        y_cok[i] = co < p.Cout;
+        y_rel[i] = (lane >> 1) * p.lddy + co;
+    }
+    const int y_px = lane >> 1;
     int cur_n, cur_h, cur_ws;                                   // slab cursor of the NEXT slab to issue
     {
         const int per_img = p.Ho * wsegs;
@@ -491,33 +521,28 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
     auto issue_slab = [&]() {
         const unsigned stage = (unsigned)(stage_w * STAGE);
         const int w0 = cur_ws * 32;
+        const bool live = issued < nslab;
+        const int xbase = cur_n * (int)p.xbs + (cur_h * p.W + w0) * p.ldx;        // wave-uniform
+        const int ybase = cur_n * (int)p.dybs + (cur_h * p.Wo + w0) * p.lddy;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = wv + 4 * i;
-            const int hi = cur_h - 1 + x_hy[i], wi = w0 - 1 + x_hx[i];
-            const bool ok = x_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && !(p.ablate & 1);
-            const int off = cur_n * (int)p.xbs + (hi * p.W + wi) * p.ldx + x_c[i];
-            sy_glds16_buf_at(bufx, ok ? (unsigned)(off * 2) : 0xFFFFFFFFu, lds0,
+            const bool ok = live && (unsigned)(x_hy1[i] + cur_h) < (unsigned)p.H && (unsigned)(x_hx1[i] + w0) < (unsigned)p.W &&
+                            !(p.ablate & 1);
+            // (OR with an all-ones mask instead of a select: hipcc turns the select into an exec-mask branch around the add)
+            sy_glds16_buf_at(bufx, (unsigned)((xbase + x_rel[i]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0,
                              stage + (unsigned)((j >> 2) * kXSub + (j & 3) * 1024));
         }
-        const int wo = w0 + (lane >> 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = wv + 4 * i;
-            const int co = c0 + j * 16 + half8;
-            const bool ok = wo < p.Wo && co < p.Cout && !(p.ablate & 2);
-            const int off = cur_n * (int)p.dybs + (cur_h * p.Wo + wo) * p.lddy + co;
-            sy_glds16_buf_at(bufdy, ok ? (unsigned)(off * 2) : 0xFFFFFFFFu, lds0, stage + (unsigned)(2 * kXSub + j * kSubPitch));
+            const bool ok = live && y_cok[i] && w0 + y_px < p.Wo && !(p.ablate & 2);
+            sy_glds16_buf_at(bufdy, (unsigned)((ybase + y_rel[i]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0,
+                             stage + (unsigned)(2 * kXSub + j * kSubPitch));
         }
         if (++cur_ws == wsegs) { cur_ws = 0; if (++cur_h == p.Ho) { cur_h = 0; ++cur_n; } }
         ++issued;
         stage_w = (stage_w + 1 == STG) ? 0 : stage_w + 1;
-    };
-    auto wait_slab = [&](int ahead) {             // at most `ahead` later slabs of this wave's loads still in flight
-        if (ahead >= 3) sy_wait_vmcnt<12>();
-        else if (ahead == 2) sy_wait_vmcnt<8>();
-        else if (ahead == 1) sy_wait_vmcnt<4>();
-        else sy_wait_vmcnt<0>();
     };
 
     f32x16 acc[9];
@@ -531,27 +556,39 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
     const int x_lane = ((lane >> 4) & 1) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
     const int y_lane = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 
-    for (int j = 0; j < STG - 1 && j < nslab; ++j) issue_slab();
+    for (int j = 0; j < STG - 1; ++j) issue_slab();
     int stage_r = 0;
     for (int s = 0; s < nslab; ++s) {
-        wait_slab(issued - s - 1);
-        sy_barrier();                             // slab s complete for every wave; everyone is past slab s - 1
-        if (issued < nslab) issue_slab();
+        sy_wait_vmcnt<4 * (STG - 2)>();           // slab s landed; the STG - 2 slabs behind it stay in flight
+        sy_barrier();                             // ... for every wave; everyone is past slab s - 1
+        issue_slab();
         const unsigned char* const xb = smem + stage_r * STAGE + x_lane;
         const unsigned char* const yb = smem + stage_r * STAGE + 2 * kXSub + (wv * 2) * kSubPitch + y_lane;
         stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
+        // fragments of step (k-half, tap) + 2 are read while step (k-half, tap) multiplies
+        uint4 a[3], b[2];
+        auto read_a = [&](auto st_) {
+            constexpr int ST = decltype(st_)::value;
+            constexpr int KS = ST / 9, TAP = ST % 9;
+            const unsigned char* ptr = xb + ((TAP / 3) * 34 + (TAP % 3)) * 32 + KS * 512;
+            const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
+            a[ST % 3] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        };
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const uint2 blo = sy_lds_read_tr16(yb + ks * 512), bhi = sy_lds_read_tr16(yb + ks * 512 + 128);
-            const uint4 b = make_uint4(blo.x, blo.y, bhi.x, bhi.y);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const unsigned char* ptr = xb + ((t / 3) * 34 + (t % 3)) * 32 + ks * 512;
-                const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
-                acc[t] = sy_mfma_group(T(), make_uint4(lo.x, lo.y, hi.x, hi.y), b, acc[t]);
-            }
+            const uint2 lo = sy_lds_read_tr16(yb + ks * 512), hi = sy_lds_read_tr16(yb + ks * 512 + 128);
+            b[ks] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
+        read_a(sy_int<0>());
+        read_a(sy_int<1>());
+        sy_static_for<0, 18>([&](auto st_) {
+            constexpr int ST = decltype(st_)::value;
+            if constexpr (ST + 2 < 18) read_a(sy_int<ST + 2>());
+            acc[ST % 9] = sy_mfma_group(T(), a[ST % 3], b[ST / 9], acc[ST % 9]);
+            sy_sched_fence();
+        });
     }
+    sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
 
     // ---- epilogue: D[row = (tap, ci)][col = co]; partial slab of this split, or += into dW (one split)
     const int l31 = lane & 31, half = lane >> 5;
@@ -765,21 +802,31 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
     }
 }
 
+template <typename T, int WR, int WC, int TR, int TC, int STG, int LIN>
+int launch_tr_kernel_lin(const WgradArgs& a, dim3 grid, void* stream) {
+    constexpr size_t smem = (size_t)STG * ((WR * TR + WC * TC) * 2) * kSubPitch;
+#ifndef SY_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<T, WR, WC, TR, TC, STG, LIN>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return SY_ERR_LAUNCH;
+        attr_done = true;
+    }
+#endif
+    SY_LAUNCH((conv_wgrad_tr_kernel<T, WR, WC, TR, TC, STG, LIN>), grid, dim3(kThreadsW), smem, stream, a);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
 template <typename T, int WR, int WC, int TR, int TC, int STG>
 int launch_tr_kernel(const WgradArgs& a, dim3 grid, void* stream) {
     if constexpr (T::kEPC == 8 && ((WR * TR + WC * TC) * 2) % 4 == 0) {
-        constexpr size_t smem = (size_t)STG * ((WR * TR + WC * TC) * 2) * kSubPitch;
-#ifndef SY_EMU
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<T, WR, WC, TR, TC, STG>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-                return SY_ERR_LAUNCH;
-            attr_done = true;
-        }
-#endif
-        SY_LAUNCH((conv_wgrad_tr_kernel<T, WR, WC, TR, TC, STG>), grid, dim3(kThreadsW), smem, stream, a);
-        return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+        // 1x1 stride 1 over dense tensors: linear pixel addressing
+        const bool lin = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W &&
+                         a.xbs == (long long)a.H * a.W * a.ldx && a.dybs == (long long)a.Ho * a.Wo * a.lddy &&
+                         (long long)a.M * a.ldx < 0x3fffffffLL && (long long)a.M * a.lddy < 0x3fffffffLL;
+        return lin ? launch_tr_kernel_lin<T, WR, WC, TR, TC, STG, 1>(a, grid, stream)
+                   : launch_tr_kernel_lin<T, WR, WC, TR, TC, STG, 0>(a, grid, stream);
     } else {
         return SY_ERR_UNSUPPORTED;
     }

@@ -227,11 +227,8 @@ __device__ __forceinline__ sy_lds_base_t sy_lds_base(unsigned char* p) {
 }
 __device__ __forceinline__ void sy_glds16_buf_at(const sy_buffer& b, unsigned voff, sy_lds_base_t base, unsigned off) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(base + off);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(b), "s"(dst)
-                 : "memory");
+    // M0 as a register-constrained input: the compiler loads it (and knows it is live), no save / restore around the DMA
+    asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(b), "{m0}"(dst) : "memory");
 }
 #endif
 
