@@ -138,6 +138,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
 }
 
+// (A persistent variant — weights loaded once per workgroup, pixel tiles walked through two tile buffers, BatchNorm sums carried
+//  in registers and reduced once — was built, parity-green and 10-25 % SLOWER on every layer but one
+//  (profiles/r02/x_conv_probe_persistent_1x1.txt: three barriers per tile and half the resident workgroups cost more than the
+//  saved prologue / statistics work: these kernels live on latency hiding across workgroups, not on instruction count.)
+
 template <typename T, int WC, int WP, int TC, int TP, int NS>
 int launch_1x1_tile_ns(const ConvArgs& a_in, void* stream) {
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;

@@ -349,3 +349,4 @@ def test_conv1x1_tile_kernel(backend, tile, dt, cin, cout, N, H, W):
         ops.conv2d(dyv, wt, dxv, 1, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wft, accumulate=True)
         assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]
         assert float(dxv.buf[..., :32].float().abs().max()) == 0.0
+
