@@ -239,48 +239,64 @@ __global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float*
     __syncthreads();
 
     // ---- dynamic k + matching: one wave per GT -----------------------------------------------------------
+    // Both selections need at most ten entries of a row (k = int(sum of the ten largest IoUs) <= 10), in (value, index) order.
+    // The rows live in global memory and a sweep per selected entry (twenty dependent passes of C / 64 loads per lane, each
+    // exposed to L2 latency) was this kernel's whole time — 0.32 ms on the step's critical path with 8 workgroups on the chip.
+    // Now ONE pass per row: every lane keeps the ten best of its own C / 64 entries in registers (sorted), and the wave
+    // merges the lanes' heads entry by entry (wave_argmin).  Same (value, smaller index first) order as the sweeps had.
     for (int g = wave; g < G; g += NW) {
         const float* irow = ioum + (long long)g * L.acap;
-        float* crow = cost + (long long)g * L.acap;
-        // sum of the 10 largest IoUs: ten arg-max sweeps with a "taken" threshold (value, index) ordering
-        float sum = 0.0f;
-        float last_v = INFINITY;
-        int last_i = -1;
+        const float* crow = cost + (long long)g * L.acap;
         const int nk = C < 10 ? C : 10;
-        for (int it = 0; it < nk; ++it) {
-            float bv = INFINITY;          // arg-min of (-iou)
-            int bi = 0x7fffffff;
+        float tv[10];
+        int ti[10];
+        auto collect = [&](const float* row, float sign) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) { tv[j] = INFINITY; ti[j] = 0x7fffffff; }
             for (int c = lane; c < C; c += 64) {
-                const float v = -irow[c];
-                // skip entries already taken: (v, c) must come strictly after (last_v', last_i) in (value, index) order
-                const float lv = -last_v;
-                const bool after = (it == 0) || (v > lv) || (v == lv && c > last_i);
-                if (after && (v < bv || (v == bv && c < bi))) { bv = v; bi = c; }
+                float v = sign * row[c];
+                int i = c;
+                if (!(v < tv[9] || (v == tv[9] && i < ti[9]))) continue;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {            // pass the entry through the sorted list
+                    const bool lt = v < tv[j] || (v == tv[j] && i < ti[j]);
+                    const float ov = tv[j];
+                    const int oi = ti[j];
+                    tv[j] = lt ? v : ov; ti[j] = lt ? i : oi;
+                    v = lt ? ov : v; i = lt ? oi : i;
+                }
             }
+        };
+        auto pop = [&](float& bv, int& bi) {              // smallest remaining entry of the wave; its lane drops it
+            bv = tv[0]; bi = ti[0];
+            const float mine_v = bv;
+            const int mine_i = bi;
             wave_argmin(bv, bi);
-            if (bi >= C) break;                       // no candidate left (cannot happen with sanitised IoUs; bounds the index)
+            if (mine_v == bv && mine_i == bi && bi != 0x7fffffff) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+                tv[9] = INFINITY; ti[9] = 0x7fffffff;
+            }
+        };
+        collect(irow, -1.0f);                            // ten largest IoUs
+        float sum = 0.0f;
+        for (int it = 0; it < nk; ++it) {
+            float bv;
+            int bi;
+            pop(bv, bi);
+            if (bi >= C) break;                           // no candidate left (cannot happen with sanitised IoUs; bounds the index)
             sum += -bv;
-            last_v = -bv;
-            last_i = bi;
         }
         int kg = (sum == sum && sum < 1.0e9f) ? (int)sum : 1;
         if (kg < 1) kg = 1;
         if (kg > C) kg = C;
         if (lane == 0) s_k[g] = kg;
-        float lcv = -INFINITY;
-        int lci = -1;
-        for (int it = 0; it < kg; ++it) {
-            float bv = INFINITY;
-            int bi = 0x7fffffff;
-            for (int c = lane; c < C; c += 64) {
-                const float v = crow[c];
-                const bool after = (it == 0) || (v > lcv) || (v == lcv && c > lci);
-                if (after && (v < bv || (v == bv && c < bi))) { bv = v; bi = c; }
-            }
-            wave_argmin(bv, bi);
-            if (bi >= C) break;                       // uniform: fewer comparable candidates than k
-            lcv = bv;
-            lci = bi;
+        collect(crow, 1.0f);                             // kg (<= 10) smallest costs
+        for (int it = 0; it < kg && it < 10; ++it) {
+            float bv;
+            int bi;
+            pop(bv, bi);
+            if (bi >= C) break;                           // uniform: fewer comparable candidates than k
             if (lane == 0) { atomicAdd(&mcnt[bi], 1); mgt[bi] = g; }
         }
     }

@@ -886,11 +886,19 @@ class _PlanFunction(torch.autograd.Function):
     def backward(ctx, g_total, _g_stats):
         plan = ctx.plan
         arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
-        outs, o = [], 0
-        for p in plan.params:
-            outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
-            o += p.numel()
-        return (None, None, None, None) + tuple(outs)
+        return (None, None, None, None) + _arena_views(arena, plan.params)
+
+
+def _arena_views(arena, params):
+    """One gradient tensor per parameter as a view of the (cloned) flat arena, in parameter order: a single C++ call when every
+    parameter is fp32 (393 Python-level slice + view pairs cost ~1 ms of host time per step on the drop-in path)."""
+    if all(p.dtype == arena.dtype for p in params):
+        return tuple(torch._C._nn.unflatten_dense_tensors(arena, list(params)))
+    outs, o = [], 0
+    for p in params:
+        outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
+        o += p.numel()
+    return tuple(outs)
 
 
 class _BackboneFunction(torch.autograd.Function):
@@ -908,11 +916,7 @@ class _BackboneFunction(torch.autograd.Function):
     def backward(ctx, *gouts):
         plan = ctx.plan
         arena = plan.backward(None, d_fused=[g.float() for g in gouts]).clone()
-        outs, o = [], 0
-        for p in plan.params:
-            outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
-            o += p.numel()
-        return (None, None) + tuple(outs)
+        return (None, None) + _arena_views(arena, plan.params)
 
 
 class _HeadFunction(torch.autograd.Function):
@@ -934,11 +938,7 @@ class _HeadFunction(torch.autograd.Function):
         plan = ctx.plan
         arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
         gf = tuple(g.to(plan.tdtype) for g in plan.fused_grads())
-        outs, o = [], 0
-        for p in plan.params:
-            outs.append(arena[o:o + p.numel()].view(p.shape).to(p.dtype))
-            o += p.numel()
-        return (None, None, None) + gf + tuple(outs)
+        return (None, None, None) + gf + _arena_views(arena, plan.params)
 
 
 def backbone_train_forward(pafpn, x):
