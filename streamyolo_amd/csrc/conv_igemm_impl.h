@@ -612,7 +612,13 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
     // (+= outputs — data gradients of activations with several consumers — are staged too: the write-out pass reads
     //  the old row chunk, adds in fp32 and stores, all coalesced; the staged value was already rounded to 16 bits,
     //  one extra rounding the gradient path tolerates.  Residual adds keep the direct path: single rounding.)
-    const bool stage_out = kCanStage && vec_ok && !p.y_f32 && p.res == nullptr && ((p.ldy & 7) == 0) &&
+    // (residual adds — the eval Bottleneck convs — take the staged path too when the residual tile can be loaded as whole pixel
+    //  rows: it is parked in the staging rows first, every lane adds its own 4-channel groups in fp32 and rounds ONCE, in place)
+    constexpr bool kResStage = (WC * TC >= TP);                 // residual row offsets reuse the statistics scratch [WP][CT][2]
+    const bool res_ok = p.res == nullptr || (kResStage && !want_stats && !p.accumulate && ((p.ldr & 7) == 0) &&
+                                             (p.epilogue == SY_EPI_LINEAR || p.epilogue == SY_EPI_SILU) &&      // = the lean path below
+                                             ((reinterpret_cast<unsigned long long>(p.res) & 15ull) == 0));
+    const bool stage_out = kCanStage && vec_ok && !p.y_f32 && res_ok && ((p.ldy & 7) == 0) &&
                            ((reinterpret_cast<unsigned long long>(p.y) & 15ull) == 0);
     unsigned char* const stg = smem + kStatBytes;               // [PT][kStagePitch]
     long long* const stg_off = reinterpret_cast<long long*>(smem + kStatBytes + PT * kStagePitch);   // [PT] element offsets
@@ -625,17 +631,35 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                       (!want_stats || (p.epilogue == SY_EPI_LINEAR && p.scale == nullptr && p.shift == nullptr));
     if (lean) {
         if constexpr (kCanStage) {
-            auto body = [&](auto silu_, auto aff_, auto stats_) {
+            auto body = [&](auto silu_, auto aff_, auto stats_, auto res_) {
                 constexpr bool SILU = decltype(silu_)::value != 0, AFF = decltype(aff_)::value != 0,
-                               STATS = decltype(stats_)::value != 0;
+                               STATS = decltype(stats_)::value != 0, RES = decltype(res_)::value != 0;
+                long long* const stg_roff = reinterpret_cast<long long*>(smem);     // [PT] residual row offsets (RES only)
                 if (wc == 0 && half == 0) {                         // output element offset of every tile pixel, once
 #pragma unroll
                     for (int u = 0; u < TP; ++u) {
-                        long long off = -1;
+                        long long off = -1, roff = -1;
                         int n, rem;
-                        if (mp.map((wp * TP + u) * 32 + l31, n, rem)) off = (long long)n * p.ybs + (long long)rem * p.ldy;
+                        if (mp.map((wp * TP + u) * 32 + l31, n, rem)) {
+                            off = (long long)n * p.ybs + (long long)rem * p.ldy;
+                            roff = (long long)n * p.rbs + (long long)rem * p.ldr;
+                        }
                         stg_off[(wp * TP + u) * 32 + l31] = off;
+                        if (RES) stg_roff[(wp * TP + u) * 32 + l31] = roff;
                     }
+                }
+                if constexpr (RES) {                                // the residual tile, whole pixel rows, into the staging rows
+                    __syncthreads();
+                    constexpr int CPR = CT / 8;
+                    for (int i = tid; i < PT * CPR; i += kThreads) {
+                        const int px = i / CPR, ck = i - px * CPR;
+                        const long long roff = stg_roff[px];
+                        const int co = c0 + ck * 8;
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (roff >= 0 && co < p.Cout) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const elem*>(p.res) + roff + co);
+                        *reinterpret_cast<uint4*>(stg + px * kStagePitch + ck * 16) = v;
+                    }
+                    __syncthreads();
                 }
                 sy_static_for<0, TC>([&](auto tc_) {
                     constexpr int t = decltype(tc_)::value;
@@ -662,6 +686,13 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                                 if (SILU) z = sy_silu(z);
                                 v[j] = z;
                             }
+                            if (RES) {                              // this lane's own 4 channels of its pixel: read, add, round once
+                                const uint2 rr = *reinterpret_cast<const uint2*>(row + q * 16);
+                                elem re[4];
+                                __builtin_memcpy(re, &rr, 8);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += T::to_f32(re[j]);
+                            }
                             *reinterpret_cast<uint2*>(row + q * 16) = make_uint2(T::pack2(v[0], v[1]), T::pack2(v[2], v[3]));
                         }
                     }
@@ -682,11 +713,19 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             };
             const bool aff = p.scale != nullptr && p.shift != nullptr;
             const bool silu = p.epilogue == SY_EPI_SILU;
-            if (want_stats) body(sy_int<0>(), sy_int<0>(), sy_int<1>());          // training forward: raw output + statistics
-            else if (silu && aff) body(sy_int<1>(), sy_int<1>(), sy_int<0>());    // eval BaseConv
-            else if (!silu && !aff) body(sy_int<0>(), sy_int<0>(), sy_int<0>());  // data gradient
-            else if (silu) body(sy_int<1>(), sy_int<0>(), sy_int<0>());
-            else body(sy_int<0>(), sy_int<1>(), sy_int<0>());
+            if (want_stats) body(sy_int<0>(), sy_int<0>(), sy_int<1>(), sy_int<0>());          // training forward: raw output + statistics
+            else if (p.res != nullptr) {
+                if constexpr (kResStage) {
+                    if (silu && aff) body(sy_int<1>(), sy_int<1>(), sy_int<0>(), sy_int<1>());   // eval Bottleneck conv with shortcut
+                    else if (silu) body(sy_int<1>(), sy_int<0>(), sy_int<0>(), sy_int<1>());
+                    else if (aff) body(sy_int<0>(), sy_int<1>(), sy_int<0>(), sy_int<1>());
+                    else body(sy_int<0>(), sy_int<0>(), sy_int<0>(), sy_int<1>());
+                }
+            }
+            else if (silu && aff) body(sy_int<1>(), sy_int<1>(), sy_int<0>(), sy_int<0>());    // eval BaseConv
+            else if (!silu && !aff) body(sy_int<0>(), sy_int<0>(), sy_int<0>(), sy_int<0>());  // data gradient
+            else if (silu) body(sy_int<1>(), sy_int<0>(), sy_int<0>(), sy_int<0>());
+            else body(sy_int<0>(), sy_int<1>(), sy_int<0>(), sy_int<0>());
         }
     } else
     // compile-time loop over the wave's channel tiles: accumulator indices must be constants (a runtime
