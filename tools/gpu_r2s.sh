@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 stage s: what is a launch on the critical path worth? (timing-only experiment: forward BatchNorm finalize launches skipped)
+# round-2 stage s: RETIRED timing experiment (the STREAMYOLO_EXP_SKIP_FINALIZE switch no longer exists; see profiles/r02/README.md: its result was an artefact)
 mkdir -p gpurun_out/s
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
