@@ -22,7 +22,9 @@
 
 namespace sy_conv {
 
-template <typename T, int WC, int WP, int TC, int TP, int NS>
+// NCH > 1 (Cin = NCH x 512): the K extent is walked in NCH chunks of NS = 16 slabs through the same LDS image and weight
+// registers (accumulators persist; a barrier after a chunk's MFMAs frees the image for the next burst).
+template <typename T, int WC, int WP, int TC, int TP, int NS, int NCH = 1>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) void conv1x1_tile_kernel(ConvArgs p) {
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
@@ -72,22 +74,26 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
 #pragma unroll
     for (int t = 0; t < TC; ++t) {
         const int ct = bid.x * (CT / 32) + wc * TC + t;
-        foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * NS) * 128 + lane) * 16) : 0xFFFFFFFFu;
+        foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * NS * NCH) * 128 + lane) * 16) : 0xFFFFFFFFu;
     }
     uint4 fr[NS][TC][2];
-    sy_static_for<0, NS>([&](auto s_) {
-        constexpr int S = decltype(s_)::value;
+    auto burst = [&](int chunk) {
+        const unsigned cx = (unsigned)(chunk * NS * BK * ESZ), cf = (unsigned)(chunk * NS * 2048);
+        sy_static_for<0, NS>([&](auto s_) {
+            constexpr int S = decltype(s_)::value;
 #pragma unroll
-        for (int i = 0; i < PW; ++i)
-            sy_glds16_buf_at(bufx, voff[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : voff[i] + (unsigned)(S * BK * ESZ), lds0,
-                             (unsigned)((S * PPS + wave + i * NW) * 1024));
+            for (int i = 0; i < PW; ++i)
+                sy_glds16_buf_at(bufx, voff[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : voff[i] + cx + (unsigned)(S * BK * ESZ), lds0,
+                                 (unsigned)((S * PPS + wave + i * NW) * 1024));
 #pragma unroll
-        for (int t = 0; t < TC; ++t)
+            for (int t = 0; t < TC; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-                fr[S][t][g] = sy_buffer_load16_s(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + (unsigned)(g * 1024), (unsigned)(S * 2048));
-        sy_sched_fence();                        // slab order: the counted waits below (and the compiler's own) rely on it
-    });
+                for (int g = 0; g < 2; ++g)
+                    fr[S][t][g] = sy_buffer_load16_s(buff, foff[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff[t] + (unsigned)(g * 1024), cf + (unsigned)(S * 2048));
+            sy_sched_fence();                    // slab order: the counted waits below (and the compiler's own) rely on it
+        });
+    };
+    burst(0);
 
     f32x16 acc[TC][TP];
 #pragma unroll
@@ -105,6 +111,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
         ba[u] = (unsigned)(row * 64 + ((half ^ ((row >> 2) & 3)) << 4));
     }
 
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+    if (chunk > 0) {
+        sy_barrier();                             // every wave is done with the previous chunk's image
+        burst(chunk);
+    }
     sy_static_for<0, NG>([&](auto g_) {
         constexpr int GI = decltype(g_)::value;
         // VMEM operations issued after the last piece of this group: its own last slab's fragments + everything of the later slabs
@@ -130,6 +141,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
             sy_sched_fence();
         });
     });
+    }
 
     SY_LATE_ARGS(ConvArgs, p);
     int e_bx = bid.x, e_by = bid.y, e_bz = bid.z;
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
 //  (profiles/r02/x_conv_probe_persistent_1x1.txt: three barriers per tile and half the resident workgroups cost more than the
 //  saved prologue / statistics work: these kernels live on latency hiding across workgroups, not on instruction count.)
 
-template <typename T, int WC, int WP, int TC, int TP, int NS>
+template <typename T, int WC, int WP, int TC, int TP, int NS, int NCH = 1>
 int launch_1x1_tile_ns(const ConvArgs& a_in, void* stream) {
     constexpr int CT = WC * TC * 32, PT = WP * TP * 32;
     ConvArgs a = a_in;
@@ -157,13 +169,13 @@ int launch_1x1_tile_ns(const ConvArgs& a_in, void* stream) {
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv1x1_tile_kernel<T, WC, WP, TC, TP, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv1x1_tile_kernel<T, WC, WP, TC, TP, NS, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    SY_LAUNCH((conv1x1_tile_kernel<T, WC, WP, TC, TP, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
+    SY_LAUNCH((conv1x1_tile_kernel<T, WC, WP, TC, TP, NS, NCH>), grid, dim3(WC * WP * 64), smem, stream, a);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
@@ -176,6 +188,12 @@ int launch_1x1_tile_cfg(const ConvArgs& a, void* stream) {
         case 16:
             if constexpr (TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16>(a, stream);
             return SY_ERR_UNSUPPORTED;
+        case 32:                                  // Cin 1024 / 2048: two / four chunks of 512 channels
+            if constexpr (WC == 4 && TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16, 2>(a, stream);
+            return SY_ERR_UNSUPPORTED;
+        case 64:
+            if constexpr (WC == 4 && TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16, 4>(a, stream);
+            return SY_ERR_UNSUPPORTED;
         default: return SY_ERR_UNSUPPORTED;
     }
 }
@@ -187,7 +205,7 @@ int launch_1x1_tile(const ConvArgs& a, void* stream) {
         return SY_ERR_UNSUPPORTED;
     } else {
         // 1x1 stride 1 (forward and data gradient are the same gather), whole 64-byte channel slabs, 32-bit addressable input,
-        // fragment-packed weights, Cin in {64, 128, 256, 512}
+        // fragment-packed weights, Cin in {64, 128, 256, 512, 1024, 2048}
         if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
         if (a.Cin % 32 != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
         switch (a.tile) {

@@ -459,9 +459,9 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     if (k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256) and code != DT_F32 and STREAM_1X1
             and (with_stats or mode == CONV_DGRAD)):
         cands.append(120)                      # weight-stationary pixel stream (csrc/conv1x1_stream.h): raw outputs only
-    if k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256, 512) and code != DT_F32:
+    if k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256, 512, 1024, 2048) and code != DT_F32:
         # whole-K burst kernel (csrc/conv1x1_tile.h): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px (Cin <= 256)
-        cands += [t for t in TILE_1X1K if not (t == 122 and Cout > 64) and not (t == 123 and Cin > 256)]
+        cands += [t for t in TILE_1X1K if not (t == 122 and Cout > 64) and not (t == 123 and Cin > 256) and not (t != 121 and Cin > 512)]
     best, best_t = 0, float("inf")
     for t in cands:
         if t >= TILE_WR and wf is None:

@@ -34,6 +34,9 @@ SHAPES = [
     ("d2.conv1", 16, 150, 240, 128, 64, 1, 1),
     ("d3.conv1", 16, 75, 120, 256, 128, 1, 1),
     ("head0.stem", 8, 75, 120, 256, 256, 1, 1),
+    ("d5.conv3", 16, 19, 30, 1024, 1024, 1, 1),
+    ("p5.csp.c1", 16, 19, 30, 1024, 512, 1, 1),
+    ("p4.csp.c1", 16, 38, 60, 1024, 256, 1, 1),
 ]
 NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256", 6: "dma128x64",
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
@@ -85,8 +88,8 @@ def main():
         flops = 2.0 * cin * cout * k * k * y.pixels
         res = []
         for t in tiles:
-            if 121 <= (t & 255) <= 123 and (k != 1 or st != 1 or cin not in (64, 128, 256, 512) or ((t & 255) == 122 and cout > 64)
-                                            or ((t & 255) == 123 and cin > 256)):
+            if 121 <= (t & 255) <= 123 and (k != 1 or st != 1 or cin not in (64, 128, 256, 512, 1024, 2048) or ((t & 255) == 122 and cout > 64)
+                                            or ((t & 255) == 123 and cin > 256) or ((t & 255) != 121 and cin > 512)):
                 res.append(float("nan"))
                 continue
             if t == 120 and (k != 1 or st != 1 or cin not in (64, 128, 256) or a.mode == "fwd"):
