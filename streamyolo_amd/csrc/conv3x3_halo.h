@@ -22,6 +22,10 @@
 #pragma once
 #include "conv_igemm_impl.h"
 
+#ifndef SY_HALO2_BD
+#define SY_HALO2_BD 3
+#endif
+
 namespace sy_conv {
 
 constexpr int kHaloW = 34;            // 32 pixels + 1 halo pixel on each side
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
     constexpr int HR = (TH + 2) * kHaloW;
     constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;
     constexpr int BUF = NW * NI * 16 * 64;
-    constexpr int BD = 3;                        // pixel-fragment ring: two (tap, k-half) steps of reads in flight
+    constexpr int BD = (TC * TP <= 2) ? SY_HALO2_BD : 3;   // pixel-fragment ring: BD - 1 (tap, k-half) steps of reads in flight
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(NI <= 9, "one DMA piece per tap");
 

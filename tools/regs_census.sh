@@ -1,7 +1,7 @@
 #!/bin/bash
 # VGPR / spill census of the instantiations listed in tools/probes/regs_probe.hip
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only tools/probes/regs_probe.hip -o /tmp/regs.s 2>/tmp/regs.err || tail -20 /tmp/regs.err
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off $EXTRA_FLAGS -S --cuda-device-only tools/probes/regs_probe.hip -o /tmp/regs.s 2>/tmp/regs.err || tail -20 /tmp/regs.err
 python3 - <<'PY'
 import re
 txt=open('/tmp/regs.s').read()
