@@ -17,6 +17,7 @@ MI355X-first design (not a translation of the reference's eager module tree):
 Reference lines each piece follows are cited in the builders below.
 """
 import math
+import os
 
 import torch
 
@@ -89,7 +90,30 @@ class FocusOp:
 # ------------------------------------------------------------------------------------------------
 # network builders
 # ------------------------------------------------------------------------------------------------
+class MergedConv:
+    """Two BaseConvs that read the SAME input (CSPLayer conv2 / conv1, the first cls / reg tower conv of a head level) as ONE
+    launch with their output channels stacked — eval plans only (BatchNorm folded into the epilogue's affine): one read of the
+    input, twice the GEMM N on the narrowest layers, one launch less on the latency-bound streaming step."""
+
+    def __init__(self, mods):
+        self.mods = tuple(mods)
+        m0 = self.mods[0]
+        assert all(m.ksize == m0.ksize and m.stride == m0.stride and m.conv.in_channels == m0.conv.in_channels for m in self.mods)
+        self.ksize, self.stride = m0.ksize, m0.stride
+        self.out_channels = sum(m.conv.out_channels for m in self.mods)
+
+    def parameters(self):
+        for m in self.mods:
+            yield from m.parameters()
+
+    def buffers(self):
+        for m in self.mods:
+            yield from m.buffers()
+
+
 class _Builder:
+    merge_siblings = False                       # InferencePlan: True (training plans keep one op per BaseConv)
+
     def __init__(self, dtype, device):
         self.dtype, self.device = dtype, device
         self.ops = []
@@ -99,18 +123,25 @@ class _Builder:
 
     def conv(self, mod, x, y=None, res=None, need_dx=True, tag=""):
         if y is None:
-            y = self.buf(x.N, ops.conv_out_size(x.H, mod.ksize, mod.stride),
-                         ops.conv_out_size(x.W, mod.ksize, mod.stride), mod.conv.out_channels)
+            cout = mod.out_channels if isinstance(mod, MergedConv) else mod.conv.out_channels
+            y = self.buf(x.N, ops.conv_out_size(x.H, mod.ksize, mod.stride), ops.conv_out_size(x.W, mod.ksize, mod.stride), cout)
         self.ops.append(ConvOp(mod, x, y, res, need_dx, tag))
         return y
 
     def csp(self, mod, x, out=None, tag=""):
         """CSPLayer: conv3(cat[m(conv1(x)), conv2(x)])  (yolox CSPLayer, Appendix C; trap T6)."""
         hid = mod.hidden
-        cat = self.buf(x.N, x.H, x.W, 2 * hid)
         n = mod.n
-        a = self.conv(mod.conv1, x, cat.slice(0, hid) if n == 0 else None, tag=tag + ".conv1")
-        self.conv(mod.conv2, x, cat.slice(hid, hid), tag=tag + ".conv2")
+        if self.merge_siblings and n >= 1 and hid % 32 == 0:
+            # one buffer [m(conv1) | conv2 | conv1]: the merged launch writes [conv2 | conv1], conv3 reads the first two thirds
+            wide = self.buf(x.N, x.H, x.W, 3 * hid)
+            cat = wide.slice(0, 2 * hid)
+            self.conv(MergedConv((mod.conv2, mod.conv1)), x, wide.slice(hid, 2 * hid), tag=tag + ".conv2+conv1")
+            a = wide.slice(2 * hid, hid)
+        else:
+            cat = self.buf(x.N, x.H, x.W, 2 * hid)
+            a = self.conv(mod.conv1, x, cat.slice(0, hid) if n == 0 else None, tag=tag + ".conv1")
+            self.conv(mod.conv2, x, cat.slice(hid, hid), tag=tag + ".conv2")
         for i, b in enumerate(mod.m):
             u = self.conv(b.conv1, a, tag="%s.m.%d.conv1" % (tag, i))
             dst = cat.slice(0, hid) if i == n - 1 else None
@@ -179,9 +210,14 @@ def build_head_net(b, head, feats):
     preds = []
     for k, x in enumerate(feats):
         st = b.conv(head.stems[k], x, tag="head.stem%d" % k)
-        c = b.conv(head.cls_convs[k][0], st, tag="head.cls%d.0" % k)
+        c0, r0 = head.cls_convs[k][0], head.reg_convs[k][0]
+        if b.merge_siblings and c0.conv.out_channels % 32 == 0:
+            both = b.conv(MergedConv((c0, r0)), st, tag="head.cls%d.0+reg%d.0" % (k, k))       # the towers' first convs share `st`
+            c, r = both.slice(0, c0.conv.out_channels), both.slice(c0.conv.out_channels, r0.conv.out_channels)
+        else:
+            c = b.conv(c0, st, tag="head.cls%d.0" % k)
+            r = b.conv(r0, st, tag="head.reg%d.0" % k)
         c = b.conv(head.cls_convs[k][1], c, tag="head.cls%d.1" % k)
-        r = b.conv(head.reg_convs[k][0], st, tag="head.reg%d.0" % k)
         r = b.conv(head.reg_convs[k][1], r, tag="head.reg%d.1" % k)
         op = PredOp(k, head.cls_preds[k], head.reg_preds[k], head.obj_preds[k], c, r, a0, head.strides[k])
         b.ops.append(op)
@@ -205,6 +241,16 @@ class ParamCache:
 
     def conv_eval(self, mod):
         """(packed weight, scale, shift) with eval-mode BN folded (eps read at call time — trap T1)."""
+        if isinstance(mod, MergedConv):
+            key = ("eval", id(mod))
+            parts = [self.conv_eval(m) for m in mod.mods]
+            ver = tuple(self.entries[("eval", id(m))][0] for m in mod.mods)     # the parts' own versions
+            e = self.entries.get(key)
+            if e is None or e[0] != ver:
+                e = (ver, torch.cat([p[0] for p in parts], 0).contiguous(), torch.cat([p[1] for p in parts]).contiguous(),
+                     torch.cat([p[2] for p in parts]).contiguous())
+                self.entries[key] = e
+            return e[1:]
         bn = mod.bn
         key = ("eval", id(mod))
         ver = self._ver(mod.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var) + (bn.eps,)
@@ -233,6 +279,15 @@ class ParamCache:
     def conv_weight_frag(self, mod, transpose=False):
         """Fragment-ordered copy of the packed weights for the SY_TILE_WR kernels (None if not applicable)."""
         key = ("wf", id(mod), transpose)
+        if isinstance(mod, MergedConv):
+            assert not transpose
+            w = self.conv_eval(mod)[0]
+            ver = self.entries[("eval", id(mod))][0]
+            e = self.entries.get(key)
+            if e is None or e[0] != ver:
+                e = (ver, pack_conv_weight_frag(w, mod.ksize))
+                self.entries[key] = e
+            return e[1]
         ver = self._ver(mod.conv.weight)
         e = self.entries.get(key)
         if e is None or e[0] != ver:
@@ -275,6 +330,7 @@ class InferencePlan:
         self.cache = ParamCache(self.dtype, device)
         self._stream_tape, self._tape_param_list = None, None
         b = _Builder(self.dtype, device)
+        b.merge_siblings = os.environ.get("STREAMYOLO_MERGE_SIBLINGS", "1") != "0"
         self.b = b
         self.pair = (mode == "off_pipe")
         self.fused = None
