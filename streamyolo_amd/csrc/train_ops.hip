@@ -734,7 +734,7 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    static const int cap_apply = env_cap("SY_BN_APPLY_BLOCKS", 4096);
+    static const int cap_apply = env_cap("SY_BN_APPLY_BLOCKS", 2048);
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
@@ -772,7 +772,7 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    static const int cap_reduce = env_cap("SY_BN_REDUCE_BLOCKS", 1024);
+    static const int cap_reduce = env_cap("SY_BN_REDUCE_BLOCKS", 768);
     static const int slice_max = env_cap("SY_BN_REDUCE_SLICE", 64);
     // channel slice of a workgroup: the largest chunk multiple <= 64 channels that divides C (64 = one 128-byte line per row)
     int CS = C;
@@ -804,7 +804,9 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
                   const_cast<float*>(sums), 2 * C, copies);
         copies = 1;
     }
-    static const int cap_bapply = env_cap("SY_BN_BAPPLY_BLOCKS", 2048);
+    // (grid caps re-swept after the instruction diet of these kernels, profiles/r02/ai_*, aj_*: fewer, fatter workgroups —
+    //  apply 4096 -> 2048, backward reduce 1024 -> 768, backward apply 2048 -> 1024: -0.16 ... -0.27 ms per l step)
+    static const int cap_bapply = env_cap("SY_BN_BAPPLY_BLOCKS", 1024);
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
