@@ -9,6 +9,10 @@
 #include <stdlib.h>
 #include "sy_pointwise.h"
 
+#ifndef SY_BN_ROWS_IN_FLIGHT
+#define SY_BN_ROWS_IN_FLIGHT 2          // rows (16-byte chunks per operand) a thread of the BatchNorm row kernels keeps in flight
+#endif
+
 namespace {
 
 // ---- SPP: max over 5x5, 9x9, 13x13 windows, stride 1, -inf padding (nested windows share loads) ----
@@ -384,19 +388,27 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
     // three memory round trips at their head was a quarter of that)
     const long long step = (long long)gridDim.x * rows;
     long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
-    Chunk<T> v, rv, vn, rn;
-    if (pix < pixels) {
-        v = Chunk<T>::load(y + pix * ldy + c0);
-        if (res != nullptr) rv = Chunk<T>::load(res + pix * ldr + c0);
+    constexpr int D = SY_BN_ROWS_IN_FLIGHT;
+    Chunk<T> vq[D], rq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const long long pd = pix + d * step;
+        if (pd < pixels) {
+            vq[d] = Chunk<T>::load(y + pd * ldy + c0);
+            if (res != nullptr) rq[d] = Chunk<T>::load(res + pd * ldr + c0);
+        }
     }
     float sc[T::kEPC], sh[T::kEPC];
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
     for (; pix < pixels; pix += step) {
-        const long long nxt = pix + step;
+        const Chunk<T> v = vq[0], rv = rq[0];
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d) { vq[d] = vq[d + 1]; rq[d] = rq[d + 1]; }
+        const long long nxt = pix + D * step;
         if (nxt < pixels) {
-            vn = Chunk<T>::load(y + nxt * ldy + c0);
-            if (res != nullptr) rn = Chunk<T>::load(res + nxt * ldr + c0);
+            vq[D - 1] = Chunk<T>::load(y + nxt * ldy + c0);
+            if (res != nullptr) rq[D - 1] = Chunk<T>::load(res + nxt * ldr + c0);
         }
         Chunk<T> o;
         float r[T::kEPC];
@@ -405,7 +417,6 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
         o.store(out + pix * ldo + c0);
-        v = vn; rv = rn;
     }
 }
 
@@ -521,8 +532,13 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
     }
     const long long first = pr < rows ? (long long)blockIdx.x * rows + pr : pixels;     // idle tail threads skip the loop
     const long long step = (long long)gridDim.x * rows;
-    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread; the first row's loads go out before the parameters'
-    if (first < pixels) { yv = Chunk<T>::load(y + first * ldy + c0); gv = Chunk<T>::load(da + first * ldda + c0); }
+    constexpr int D = SY_BN_ROWS_IN_FLIGHT;   // rows in flight per thread; the first rows' loads go out before the parameters'
+    Chunk<T> yq[D], gq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const long long pd = first + d * step;
+        if (pd < pixels) { yq[d] = Chunk<T>::load(y + pd * ldy + c0); gq[d] = Chunk<T>::load(da + pd * ldda + c0); }
+    }
     float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], s0[T::kEPC], s1[T::kEPC];
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) {
@@ -530,8 +546,11 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         s0[j] = 0.0f; s1[j] = 0.0f;
     }
     for (long long pix = first; pix < pixels; pix += step) {
-        const long long nxt = pix + step;
-        if (nxt < pixels) { yn = Chunk<T>::load(y + nxt * ldy + c0); gn = Chunk<T>::load(da + nxt * ldda + c0); }
+        const Chunk<T> yv = yq[0], gv = gq[0];
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d) { yq[d] = yq[d + 1]; gq[d] = gq[d + 1]; }
+        const long long nxt = pix + D * step;
+        if (nxt < pixels) { yq[D - 1] = Chunk<T>::load(y + nxt * ldy + c0); gq[D - 1] = Chunk<T>::load(da + nxt * ldda + c0); }
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) {
             const float yy = T::to_f32(yv.e[j]);
@@ -539,7 +558,6 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
             s0[j] += dz;
             s1[j] += dz * ((yy - mu[j]) * is[j]);
         }
-        yv = yn; gv = gn;
     }
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) {
@@ -584,8 +602,13 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
     const long long step = (long long)gridDim.x * rows;
     long long pix = (long long)blockIdx.x * rows + threadIdx.x / cpp;
     const bool live = (int)threadIdx.x < rows * cpp;
-    Chunk<T> yv, gv, yn, gn;                  // two rows in flight per thread
-    if (live && pix < pixels) { yv = Chunk<T>::load(y + pix * ldy + c0); gv = Chunk<T>::load(da + pix * ldda + c0); }
+    constexpr int D = SY_BN_ROWS_IN_FLIGHT;   // rows in flight per thread
+    Chunk<T> yq[D], gq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const long long pd = pix + d * step;
+        if (live && pd < pixels) { yq[d] = Chunk<T>::load(y + pd * ldy + c0); gq[d] = Chunk<T>::load(da + pd * ldda + c0); }
+    }
     for (int i = threadIdx.x; i < 2 * C; i += kBlock) {
         float a = 0.0f;
         for (int k = 0; k < copies; ++k) a += sums[(long long)k * 2 * C + i];
@@ -610,8 +633,11 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         m1[j] = s_fold[C + c] * inv_m;
     }
     for (; pix < pixels; pix += step) {
-        const long long nxt = pix + step;
-        if (nxt < pixels) { yn = Chunk<T>::load(y + nxt * ldy + c0); gn = Chunk<T>::load(da + nxt * ldda + c0); }
+        Chunk<T> yv = yq[0], gv = gq[0];
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d) { yq[d] = yq[d + 1]; gq[d] = gq[d + 1]; }
+        const long long nxt = pix + D * step;
+        if (nxt < pixels) { yq[D - 1] = Chunk<T>::load(y + nxt * ldy + c0); gq[D - 1] = Chunk<T>::load(da + nxt * ldda + c0); }
         Chunk<T> o;
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) {
@@ -629,7 +655,6 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
             }
             gv.store(dst);
         }
-        yv = yn; gv = gn;
     }
 }
 
