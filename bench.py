@@ -2,7 +2,10 @@
 """bench.py — throughput of the StreamYOLO dual-frame hot path on N MI355X GPUs of one node.
 
     python bench.py --gpus N --steps K --warmup W [--workload train|infer] [--model l] [--batch 8]
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    N>1: `python bench.py --gpus N` launches its own N ranks (one process per GPU, re-executing itself under
+    torch.distributed.run on 127.0.0.1, as the reference's tools/train.py:133-141 `launch(main, num_gpu, ...)` does); started
+    under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it uses the ranks it was given.  Either way
+    WORLD_SIZE must equal --gpus and N devices must be visible, otherwise it exits with an error (never a 1-GPU line).
 
 A "step" = one pass of the hot path over one batch of synthetic 600x960 frame pairs that are already
 resident in HBM when the timed region starts:
@@ -22,6 +25,8 @@ Extra objects on the line:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -60,6 +65,11 @@ def parse():
                     help="stream: also copy the frame from pinned host memory inside every step (PCIe-inclusive latency; "
                          "never the headline value)")
     ap.add_argument("--train-graph", type=int, default=0, help="train: hipGraph replay instead of launch tapes (slower on ROCm 7)")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="train, 1 GPU, default path: after the timed region also time (a) the drop-in boundary "
+                         "(model(x, targets)['total_loss'].backward(), the unchanged trainer's call sequence) and (b) the same "
+                         "step at 4 frame pairs per GPU (BASELINE.json configs[3]'s per-GPU load = the weak-scaling denominator "
+                         "of an 8-GPU global-batch-32 run) and report them beside `value`")
     ap.add_argument("--path", default="trainstep", choices=["trainstep", "dropin"],
                     help="train: 'trainstep' = streamyolo_amd.TrainStep (sync-free fast path, gradients stay in the flat arena); "
                          "'dropin' = the UNCHANGED reference trainer's call sequence, model(inps, targets)['total_loss'].backward() "
@@ -137,21 +147,75 @@ def pmc_traffic_full(workload, args, B):
         return None, None, None
 
 
+# TEST-SUITE ONLY (tests/test_bench_spawn.py): run the launcher / rank / reduction plumbing of this file against the
+# SIMT-emulator build of the kernels on CPU tensors with the gloo backend.  The line it prints says so and is not a measurement.
+EMU_SELFTEST = os.environ.get("STREAMYOLO_BENCH_EMU", "0") == "1"
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command line (one per GPU) and pass rank 0's
+    JSON line through.  The reference launches its own workers the same way (tools/train.py:133-141)."""
+    n = args.gpus
+    if not EMU_SELFTEST:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible on this node" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cores() // n)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class _Mark:
+    """Per-step time mark: a HIP event on the launch stream (GPU) or the host clock (emulator self-test)."""
+
+    def __init__(self, cuda):
+        self.ev = torch.cuda.Event(enable_timing=True) if cuda else None
+        self.t = 0.0
+
+    def record(self):
+        if self.ev is not None:
+            self.ev.record()
+        else:
+            self.t = time.perf_counter()
+
+    def ms_to(self, other):
+        return self.ev.elapsed_time(other.ev) if self.ev is not None else (other.t - self.t) * 1e3
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                          # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
+    if EMU_SELFTEST:
+        from streamyolo_amd import _lib
+        _lib.use_library(os.path.join(ROOT, "tests", "emu", "_build", "libstreamyolo_emu.so"))
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
+        if torch.cuda.device_count() < world:
+            raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
+    on_gpu = dev.type == "cuda"
 
     import streamyolo_amd as sy
     from oracle import streamyolo_oracle as O                   # FLOP accounting + cpu_baseline leg only
@@ -213,9 +277,9 @@ def main():
             model.train()
             model.head.use_l1 = True
             from streamyolo_amd.train_engine import get_train_plan
-            profile = lambda n: get_train_plan(model, x).profile(x, (lab, sup), n)      # noqa: E731
+            profile_rows = lambda n: get_train_plan(model, x).profile(x, (lab, sup), n, detail=True)      # noqa: E731
         else:
-            profile = stepper.profile
+            profile_rows = lambda n: stepper.plan.profile(x, (lab, sup), n, detail=True)                  # noqa: E731
     elif workload == "stream":
         # BASELINE.json configs[4]: on_pipe steady state, one 600x960 frame per step, decode + NMS included
         from streamyolo_amd.postprocess import postprocess_device
@@ -285,38 +349,67 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # per-step durations: one HIP event on the launch stream after every step (no synchronisation inside the timed region);
-    # median and p10 / p90 over the timed steps beside the mean that `value` is computed from
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        step()
-        marks[i + 1].record()
-    host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # launch-side time (the GPU runs behind it)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    def timed(fn, warmup, steps):
+        """W untimed steps, barrier + synchronize, EXACTLY `steps` steps, barrier + synchronize -> (elapsed s on this rank,
+        host-side launch ms per step, sorted per-step ms from marks on the launch stream)."""
+        for _ in range(warmup):
+            fn()
+        barrier()
+        # per-step durations: one HIP event on the launch stream after every step (no synchronisation inside the timed
+        # region); SURVEY.md §8(d): median and p10 / p90 over the timed steps beside the mean that `value` is computed from
+        marks = [_Mark(on_gpu) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            fn()
+            marks[i + 1].record()
+        host = (time.perf_counter() - t0) / steps * 1e3          # launch-side time (the GPU runs behind it)
+        barrier()
+        el = time.perf_counter() - t0
+        return el, host, sorted(marks[i].ms_to(marks[i + 1]) for i in range(steps))
+
+    elapsed, host_ms, per_step = timed(step, args.warmup, args.steps)
     pct = lambda q: per_step[min(len(per_step) - 1, max(0, int(round(q * (len(per_step) - 1)))))]      # noqa: E731
     step_stats = {"median": round(pct(0.5), 4), "p10": round(pct(0.1), 4), "p90": round(pct(0.9), 4)}
+    rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
+        elapsed = max(float(e.item()) for e in every)            # MAX over ranks
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant kernels, HIP events on the launch stream (rank 0) -----------------
     roofline = None
-    if rank == 0:
-        prof = profile(3)                                       # {kind: ms per step}
-        mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad"))
+    if rank == 0 and on_gpu:
+        dominant = None
+        if workload == "train":
+            rows = profile_rows(3)                              # [(kind, shape, launches, ms, flops)] per step
+            prof = {}
+            for kind, _, _, ms, _ in rows:
+                prof[kind] = prof.get(kind, 0.0) + ms
+            # the single largest kernel of the family: the 3x3 stride-1 forward + data-gradient layers (conv3x3_halo2_kernel,
+            # 55 % of a pair's conv FLOPs) with ITS OWN fraction of the MFMA peak, next to the family's
+            d_ms = sum(ms for kind, shp, _, ms, _ in rows if kind in ("conv", "dgrad") and shp.endswith("k3 s1"))
+            d_fl = sum(fl for kind, shp, _, _, fl in rows if kind in ("conv", "dgrad") and shp.endswith("k3 s1"))
+            w_ms = sum(ms for kind, shp, _, ms, _ in rows if kind == "wgrad")
+            w_fl = sum(fl for kind, shp, _, _, fl in rows if kind == "wgrad")
+            if d_ms > 0:
+                dominant = {"kernel": "conv3x3_halo2_kernel (3x3 stride-1 forward + data gradient)", "ms_per_step": round(d_ms, 4),
+                            "achieved": d_fl / (d_ms * 1e-3) / 1e12, "frac": d_fl / (d_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype],
+                            "second": {"kernel": "conv_wgrad9_kernel / conv_wgrad_tr_kernel (+ wgrad_fold)", "ms_per_step": round(w_ms, 4),
+                                       "achieved": w_fl / (w_ms * 1e-3) / 1e12 if w_ms > 0 else 0.0,
+                                       "frac": (w_fl / (w_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype]) if w_ms > 0 else 0.0},
+                            "hbm_bound_passes_ms": {k: round(v, 4) for k, v in prof.items() if k.startswith("bn_")}}
+        else:
+            prof = profile(3)                                   # {kind: ms per step}
+        mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad", "conv(pred)", "dgrad(pred)", "wgrad(pred)"))
         ach = flops_pair * B / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         traffic, traffic_src, traffic_commit = pmc_traffic_full(workload, args, B)
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_halo(2)_kernel+conv1x1_tile_kernel+conv1x1_stream_kernel" +
@@ -326,10 +419,43 @@ def main():
                     "traffic_source": traffic_src, "traffic_commit": traffic_commit,
                     "flops_per_step": flops_pair * B, "kernel_ms_per_step": mfma_ms,
                     "per_kind_ms": {k: round(v, 4) for k, v in prof.items()},
+                    "dominant": dominant,
                     "whole_step_frac": flops_pair * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype]}
 
+    # ---- beside the headline (1 GPU, default training path): the drop-in boundary and configs[3]'s per-GPU load ----------
+    extras = None
+    if workload == "train" and world == 1 and args.extras and args.path == "trainstep" and not args.train_graph:
+        extras = {}
+        ks, kw = max(5, args.steps // 2), 3
+
+        def dropin_step():
+            for p_ in model.parameters():                     # optimizer.zero_grad() (set_to_none)
+                p_.grad = None
+            out = model(x, (lab, sup))
+            out["total_loss"].backward()
+        el, hst, _ = timed(dropin_step, kw, ks)
+        extras["dropin"] = {"ms_per_step": el / ks * 1e3, "value": B * ks / el, "steps": ks, "host_launch_ms_per_step": round(hst, 3),
+                            "what": "model(x, targets)['total_loss'].backward() — the unchanged trainer's call sequence "
+                                    "(exps/train_utils/double_trainer.py:107-114) through train_forward's autograd.Function"}
+        if B == 8 and not args.u8_input:
+            x4, lab4, sup4 = x[:4].contiguous(), lab[:4].contiguous(), sup[:4].contiguous()
+            st4 = TrainStep(model, world_size=1, process_group=None, graph=False)
+            el, hst, _ = timed(lambda: st4.step(x4, (lab4, sup4)), kw + 2, ks)
+            extras["per_gpu_batch_4"] = {"ms_per_step": el / ks * 1e3, "value": 4 * ks / el, "steps": ks,
+                                         "host_launch_ms_per_step": round(hst, 3),
+                                         "what": "same step at 4 frame pairs / GPU: BASELINE.json configs[3] (global batch 32 on 8 "
+                                                 "GPUs) per-GPU load, the 1-GPU denominator of its weak-scaling efficiency"}
+
+    comm = None
+    if workload == "train" and world > 1:
+        pl = stepper.plan
+        comm = {"backend": "gloo (emulator self-test)" if EMU_SELFTEST else "nccl (RCCL over xGMI)",
+                "allreduce_bytes_per_step": int(pl.arena.numel()) * 4, "buckets": len(pl.buckets),
+                "buckets_overlapped_with_backward": int(getattr(stepper, "last_overlapped", 0)),
+                "rank_ms_per_step": [round(v, 4) for v in rank_ms]}
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU_SELFTEST:
         cpu = cpu_baseline(args, workload, flops_pair)
 
     if rank == 0:
@@ -338,7 +464,7 @@ def main():
             else "frame-pairs/sec (600x960) StreamYOLO-%s %s" % (args.model, "fwd+bwd" if workload == "train" else "fwd (eval)"),
             "value": value, "unit": "frames/s" if workload == "stream" else "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "step_ms": step_stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic" if not EMU_SELFTEST else "synthetic (SIMT-EMULATOR SELF-TEST on CPU: NOT a measurement)",
             "config": {"workload": "StreamYOLO-%s %dx%d %s, %d frame pairs/GPU/step, %s"
                                    % (args.model, args.height, args.width,
                                       "training step: dual-frame forward + TAL loss + backward" if workload == "train"
@@ -353,7 +479,7 @@ def main():
                        "u8_input": bool(args.u8_input) if workload in ("stream", "train") else None,
                        "h2d_in_step": bool(args.h2d) if workload == "stream" else None,
                        "host_launch_ms_per_step": round(host_ms, 3)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "extras": extras, "comm": comm,
         }
         print(json.dumps(line))
     if dist is not None:

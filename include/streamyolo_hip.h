@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 3
+#define SY_ABI_VERSION 4
 #define SY_API __attribute__((visibility("default")))
 
 enum { SY_DT_BF16 = 0, SY_DT_F16 = 1, SY_DT_F32 = 2 };
@@ -290,6 +290,48 @@ SY_API int sy_resize_nearest_bwd(const void* dout, int N, int Ho, int Wo, int C,
 /* backward of sy_spp_pool: dbuf holds grads of the 4 slices; routes pooled grads to their arg-max into slice 0 */
 SY_API int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int W, int C, int ld, int64_t bs,
                     int dtype, void* stream);
+
+/* ---- small fp32 helpers of the backward plan ---------------------------------------------------------------------
+ * sy_rows_add_f32: dst[r][0..cols) += src[r][0..cols) for r < rows (row pitches in elements); zero_src != 0 zeroes the
+ * source behind the read (a scratch the next accumulating sy_conv2d_wgrad launch reuses).  Used where a weight gradient is
+ * computed in a padded layout (Focus stem: 12 real + 4 zero channels).
+ * sy_pred_grad_fold: the parameter gradients of one head level's three 1x1 prediction convs (autograd of
+ * tal_head.py:167-171): bias gradients (+)= column sums of d_raw over the level's B x rows anchors (deterministic two-stage
+ * sum), weight gradients (+)= the [reg 0-3 | obj 4] / [cls] rows of `scratch` ([2][scratch_rows][ld] fp32, filled by two
+ * sy_conv2d_wgrad launches), scratch zeroed behind the read.  `workspace`: sy_pred_grad_fold_workspace_floats floats. */
+SY_API int sy_rows_add_f32(float* dst, int64_t ldd, float* src, int64_t lds, int rows, int cols, int zero_src, void* stream);
+SY_API int64_t sy_pred_grad_fold_workspace_floats(int num_classes);
+SY_API int sy_pred_grad_fold(const float* d_raw, int B, int64_t batch_stride, int rows, int num_classes, float* scratch,
+                             int scratch_rows, int ld, int cin, float* g_reg, float* g_obj, float* g_cls, float* gb_reg, float* gb_obj, float* gb_cls,
+                             float* workspace, void* stream);
+
+/* ---- native launch tapes ---------------------------------------------------------------------------------------
+ * Replaces the per-iteration Python dispatch of the reference trainer / evaluator loops
+ * (exps/train_utils/double_trainer.py:95-131: ~2000 eager ops per train_one_iter; sAP/streamyolo/streamyolo_det.py:176-184
+ * per streamed frame).  A plan's step is a fixed launch list: sy_tape_begin() opens a recording on the calling thread —
+ * every kernel launch of every entry point above still executes, and its closure (kernel, grid, block, LDS size, argument
+ * values) is appended; sy_tape_mark() appends stream-control entries between them; sy_tape_end() returns the tape.
+ * sy_tape_replay() re-issues the list from C on the given streams, starting at entry *pos: it returns at a BREAK entry (and
+ * at BUCKET entries when stop_buckets != 0) with *pos = the entry to resume at, *stop_kind / *stop_arg = that entry and
+ * *stop_on_side = 1 if the launch cursor is on the side stream; at the end *stop_kind = SY_TAPE_END.  side_stream == NULL
+ * (or == main_stream): one-stream replay, the stream marks are ignored.  A tape holds raw pointers: it is valid while the
+ * buffers it was recorded over live.  Not thread safe per tape; recordings do not nest. */
+enum { SY_TAPE_END = -1, SY_TAPE_LAUNCH = 0,
+       SY_TAPE_SIDE = 1,     /* side stream waits for main; cursor -> side                                    */
+       SY_TAPE_FORK = 2,     /* side stream waits for main; cursor unchanged                                  */
+       SY_TAPE_SIDE_NW = 3,  /* cursor -> side, no new dependency                                             */
+       SY_TAPE_MAIN = 4,     /* cursor -> main; arg >= 0: event on side = "ring slot `arg` is free again"      */
+       SY_TAPE_ACQUIRE = 5,  /* main waits for the event of ring slot `arg` (if one is pending)               */
+       SY_TAPE_JOIN = 6,     /* main waits for everything issued on side                                      */
+       SY_TAPE_BREAK = 7,    /* return to the caller (host-side snippet `arg` runs there)                     */
+       SY_TAPE_BUCKET = 8    /* gradient bucket `arg` is final on both streams                                */ };
+SY_API void* sy_tape_begin(void);
+SY_API int sy_tape_mark(int kind, int arg);
+SY_API void* sy_tape_end(void);
+SY_API int sy_tape_size(const void* tape, int* n_entries, int* n_launches);
+SY_API int sy_tape_replay(void* tape, void* main_stream, void* side_stream, int* pos, int stop_buckets, int* stop_kind,
+                          int* stop_arg, int* stop_on_side);
+SY_API void sy_tape_free(void* tape);
 
 SY_API const char* sy_version(void);
 SY_API int sy_abi_version(void);

@@ -107,6 +107,15 @@ SIGNATURES = {
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),
+    "sy_rows_add_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
+    "sy_pred_grad_fold_workspace_floats": (_L, [_I]),
+    "sy_pred_grad_fold": (_I, [_P, _I, _L, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sy_tape_begin": (_P, []),
+    "sy_tape_mark": (_I, [_I, _I]),
+    "sy_tape_end": (_P, []),
+    "sy_tape_size": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sy_tape_replay": (_I, [_P, _P, _P, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sy_tape_free": (None, [_P]),
     "sy_version": (C.c_char_p, []),
     "sy_abi_version": (_I, []),
 }
@@ -128,7 +137,7 @@ def _bind(path):
             raise HipLibraryError("streamyolo_amd: %s lacks symbol %s (stale build?)" % (path, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sy_abi_version() != 3:
+    if lib.sy_abi_version() != 4:
         raise HipLibraryError("streamyolo_amd: ABI version mismatch in %s" % path)
     return lib
 
@@ -161,7 +170,7 @@ class _TapeProxy:
     def __getattr__(self, name):
         fn = getattr(self.real, name)
         tape = self.tape
-        if name.endswith("_supported") or name.endswith("_bytes") or name.endswith("version"):
+        if name.endswith("_supported") or name.endswith("_bytes") or name.endswith("_floats") or name.endswith("version") or name.startswith("sy_tape_"):
             return fn                                           # queries: no stream argument, nothing to replay
 
         def call(*args):
@@ -191,6 +200,84 @@ def replay(tape, stream):
         rc = fn(*args, stream)
         if rc != 0:
             check(rc, name)
+
+
+# ---- native launch tapes (sy_tape_*, csrc/tape.hip) ------------------------------------------------------------------
+# The Python tape above still costs one ctypes call (~12 us with argument conversion) per launch.  A NativeTape records
+# at the SY_LAUNCH level inside the library — kernel, grid, block and argument values of every launch the wrappers make
+# while it is open — and sy_tape_replay re-issues the whole list from C, including the plan's stream switches and
+# event record / wait pairs.  Python is re-entered only at "snippets" (torch ops between launches) and, in data-parallel
+# runs, at gradient-bucket marks.
+TAPE_END, TAPE_LAUNCH, TAPE_SIDE, TAPE_FORK, TAPE_SIDE_NW, TAPE_MAIN, TAPE_ACQUIRE, TAPE_JOIN, TAPE_BREAK, TAPE_BUCKET = \
+    -1, 0, 1, 2, 3, 4, 5, 6, 7, 8
+TAPE_MARKS = {"side": TAPE_SIDE, "fork": TAPE_FORK, "side_nw": TAPE_SIDE_NW, "main": TAPE_MAIN, "acquire": TAPE_ACQUIRE,
+              "join": TAPE_JOIN, "bucket": TAPE_BUCKET}
+
+
+class NativeTape:
+    """with NativeTape() as t: <ops wrappers>, t.mark("side"), t.snippet(fn) ...   then t.replay(main, side, ...)."""
+
+    def __init__(self):
+        self.handle, self.snippets, self._lib = None, [], lib()
+        self._pos, self._kind, self._arg, self._side = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+
+    def __enter__(self):
+        assert _tape is None, "a Python launch tape is open"
+        if not self._lib.sy_tape_begin():
+            raise HipLibraryError("streamyolo_amd: sy_tape_begin failed (a recording is already open on this thread)")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = self._lib.sy_tape_end()
+        if et is not None:
+            self._lib.sy_tape_free(h)
+        else:
+            self.handle = h
+        return False
+
+    def mark(self, name, arg=None):
+        check(self._lib.sy_tape_mark(TAPE_MARKS[name], -1 if arg is None else int(arg)), "sy_tape_mark")
+
+    def snippet(self, fn):
+        """A host-side piece of the step (torch ops) at this position: replay() returns to Python here and runs it."""
+        self.snippets.append(fn)
+        check(self._lib.sy_tape_mark(TAPE_BREAK, len(self.snippets) - 1), "sy_tape_mark")
+
+    def size(self):
+        n, l = C.c_int(0), C.c_int(0)
+        check(self._lib.sy_tape_size(self.handle, C.byref(n), C.byref(l)), "sy_tape_size")
+        return n.value, l.value
+
+    def replay(self, main, side=None, on_snippet=None, on_bucket=None):
+        """main / side: raw hipStream_t (ctypes c_void_p or int).  on_snippet(fn, on_side) runs a recorded snippet (default:
+        fn()); on_bucket(k): called at gradient-bucket marks (None: the marks are skipped inside the library)."""
+        fn, h = self._lib.sy_tape_replay, self.handle
+        pos, kind, arg, ons = self._pos, self._kind, self._arg, self._side
+        pos.value = 0
+        stop_b = 0 if on_bucket is None else 1
+        while True:
+            rc = fn(h, main, side, C.byref(pos), stop_b, C.byref(kind), C.byref(arg), C.byref(ons))
+            if rc != 0:
+                check(rc, "sy_tape_replay")
+            k = kind.value
+            if k == TAPE_END:
+                return
+            if k == TAPE_BREAK:
+                f = self.snippets[arg.value]
+                if on_snippet is None:
+                    f()
+                else:
+                    on_snippet(f, ons.value != 0)
+            else:
+                on_bucket(arg.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.sy_tape_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 def use_library(path):

@@ -89,3 +89,96 @@ extern "C" int sy_pack_weights(const sy_pack_entry* entries, int n_entries, int 
     SY_LAUNCH(pack_weights_kernel, dim3(total_tiles), dim3(256), 0, stream, entries, n_entries);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
+
+// ---- small fp32 helpers of the backward plan (keep the step free of host-side tensor ops) --------------------------------
+namespace {
+
+// dst[r][0..cols) += src[r][0..cols) for r < rows (row pitches ldd / lds); zero_src: src rows are zeroed afterwards, so a
+// scratch that the NEXT step's accumulating weight-gradient launch reuses is clean again without a separate memset
+__global__ __launch_bounds__(256) void rows_add_kernel(float* dst, long long ldd, float* src, long long lds, int rows, int cols,
+                                                      int zero_src) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols, c = i - r * cols;
+        dst[r * ldd + c] += src[r * lds + c];
+        if (zero_src) src[r * lds + c] = 0.0f;
+    }
+}
+
+// column sums of one level's rows of d_raw [B][rows][nch] (batch stride bs): block (g, cg) sums rows g, g + G, ... for the 16
+// columns of group cg -> partial[g][cg * 16 + c]  (fixed order: the result does not depend on scheduling)
+__global__ __launch_bounds__(256) void pred_colsum_kernel(const float* d_raw, int B, long long bs, int rows, int nch, float* partial,
+                                                         int nch_pad) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, rl = threadIdx.x >> 4, col = blockIdx.y * 16 + c;
+    const long long total = (long long)B * rows;
+    float acc = 0.0f;
+    if (col < nch)
+        for (long long i = (long long)blockIdx.x * 16 + rl; i < total; i += (long long)gridDim.x * 16) {
+            const long long b = i / rows, p = i - b * rows;
+            acc += d_raw[b * bs + p * nch + col];
+        }
+    red[rl][c] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][c];
+        partial[(long long)blockIdx.x * nch_pad + col] = s;
+    }
+}
+
+// one workgroup: bias gradients += column sums (partials folded in index order), weight gradients += the wgrad scratch
+// (scratch [2][srows][ld]: [0][0..3] reg, [0][4] obj, [1][0..nc) cls), scratch zeroed behind the read
+__global__ __launch_bounds__(256) void pred_fold_kernel(const float* partial, int G, int nch_pad, int nc, float* scratch, int srows, int ld, int cin,
+                                                       float* g_reg, float* g_obj, float* g_cls, float* gb_reg, float* gb_obj,
+                                                       float* gb_cls) {
+    const int t = threadIdx.x;
+    for (int col = t; col < 5 + nc; col += 256) {
+        float s = 0.0f;
+        for (int g = 0; g < G; ++g) s += partial[(long long)g * nch_pad + col];
+        if (col < 4) gb_reg[col] += s;
+        else if (col == 4) gb_obj[0] += s;
+        else gb_cls[col - 5] += s;
+    }
+    float* s0 = scratch;                           // [srows][ld]: rows 0-3 reg, 4 obj
+    float* s1 = scratch + srows * (long long)ld;   // [srows >= nc][ld]: cls
+    for (int i = t; i < 5 * cin; i += 256) {
+        const int r = i / cin, k = i - r * cin;
+        const float v = s0[r * ld + k];
+        s0[r * ld + k] = 0.0f;
+        if (r < 4) g_reg[r * cin + k] += v; else g_obj[k] += v;
+    }
+    for (int i = t; i < nc * cin; i += 256) {
+        const int r = i / cin, k = i - r * cin;
+        g_cls[i] += s1[r * ld + k];
+        s1[r * ld + k] = 0.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" int sy_rows_add_f32(float* dst, int64_t ldd, float* src, int64_t lds, int rows, int cols, int zero_src, void* stream) {
+    if (dst == nullptr || src == nullptr || rows <= 0 || cols <= 0 || ldd < cols || lds < cols) return SY_ERR_ARG;
+    long long blocks = ((long long)rows * cols + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    SY_LAUNCH(rows_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, (long long)ldd, src, (long long)lds, rows, cols, zero_src);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+extern "C" int64_t sy_pred_grad_fold_workspace_floats(int num_classes) {
+    return 64LL * (((5 + num_classes) + 15) / 16 * 16);
+}
+
+extern "C" int sy_pred_grad_fold(const float* d_raw, int B, int64_t batch_stride, int rows, int num_classes, float* scratch,
+                                 int scratch_rows, int ld, int cin, float* g_reg, float* g_obj, float* g_cls, float* gb_reg, float* gb_obj, float* gb_cls,
+                                 float* workspace, void* stream) {
+    if (d_raw == nullptr || scratch == nullptr || workspace == nullptr || g_reg == nullptr || g_obj == nullptr || g_cls == nullptr ||
+        gb_reg == nullptr || gb_obj == nullptr || gb_cls == nullptr || B <= 0 || rows <= 0 || num_classes <= 0 || cin <= 0 || ld < cin || scratch_rows < 5 || scratch_rows < num_classes)
+        return SY_ERR_ARG;
+    const int nch = 5 + num_classes, groups = (nch + 15) / 16, nch_pad = groups * 16, G = 64;
+    SY_LAUNCH(pred_colsum_kernel, dim3(G, groups), dim3(256), 0, stream, d_raw, B, (long long)batch_stride, rows, nch, workspace, nch_pad);
+    SY_LAUNCH(pred_fold_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, G, nch_pad, num_classes, scratch, scratch_rows, ld, cin, g_reg,
+              g_obj, g_cls, gb_reg, gb_obj, gb_cls);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}

@@ -9,14 +9,42 @@
 #ifdef SY_EMU
 #include "simt_emu.h"
 #define SY_DYN_SMEM(name) unsigned char* name = emu::g_blk->dyn_smem
-#define SY_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#include "sy_tape.h"
+#include <tuple>
+#define SY_LAUNCH(kernel, grid, block, smem, stream, ...)                                                            \
+    do {                                                                                                             \
+        const dim3 sy_grid_ = (grid), sy_block_ = (block);                                                           \
+        const size_t sy_smem_ = (smem);                                                                              \
+        auto sy_args_ = std::make_tuple(__VA_ARGS__);          /* argument VALUES, evaluated now */                  \
+        auto sy_launch_fn_ = [=](void*) {                                                                            \
+            emu::launch(sy_grid_, sy_block_, sy_smem_,                                                               \
+                        [=]() { std::apply([](auto... sy_a_) { kernel(sy_a_...); }, sy_args_); });                   \
+        };                                                                                                           \
+        if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
+        sy_launch_fn_(nullptr);                                                                                      \
+    } while (0)
 #define SY_LAUNCH_OK() 0
 #else
 #include <hip/hip_runtime.h>
 #define SY_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
-#define SY_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#include "sy_tape.h"
+#include <tuple>
+// Every launch is a by-value closure (kernel, grid, block, dynamic LDS, argument VALUES — all evaluated at the launch
+// site, nothing is re-evaluated later): executed now and, while a recording is open on this thread, appended to the
+// native launch tape (sy_tape.h) for sy_tape_replay.
+#define SY_LAUNCH(kernel, grid, block, smem, stream, ...)                                                            \
+    do {                                                                                                             \
+        const dim3 sy_grid_ = (grid), sy_block_ = (block);                                                           \
+        const size_t sy_smem_ = (smem);                                                                              \
+        auto sy_args_ = std::make_tuple(__VA_ARGS__);                                                                \
+        auto sy_launch_fn_ = [=](void* sy_stream_) {                                                                 \
+            std::apply([&](auto... sy_a_) {                                                                          \
+                hipLaunchKernelGGL(kernel, sy_grid_, sy_block_, sy_smem_, (hipStream_t)sy_stream_, sy_a_...);        \
+            }, sy_args_);                                                                                            \
+        };                                                                                                           \
+        if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
+        sy_launch_fn_((void*)(stream));                                                                              \
+    } while (0)
 #define SY_LAUNCH_OK() ((int)hipGetLastError())
 #endif
 

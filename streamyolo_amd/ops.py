@@ -253,6 +253,25 @@ def view_copy(src, dst, accumulate=False):
                                   1 if accumulate else 0, stream_of(src.buf)), "sy_view_copy")
 
 
+def rows_add_f32(dst, src, rows, cols, ldd, lds, zero_src=False):
+    """dst[r][:cols] += src[r][:cols] (fp32, row pitches ldd / lds in elements); zero_src: clear the source behind the read."""
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32
+    check(_lib.lib().sy_rows_add_f32(dst.data_ptr(), ldd, src.data_ptr(), lds, rows, cols, 1 if zero_src else 0, stream_of(dst)),
+          "sy_rows_add_f32")
+
+
+def pred_grad_fold(d_raw, a0, rows, num_classes, scratch, cin, g_reg, g_obj, g_cls, gb_reg, gb_obj, gb_cls, workspace):
+    """Parameter gradients of one head level's prediction convs from d_raw[:, a0:a0+rows] and the wgrad scratch (see the header)."""
+    B, A, nch = d_raw.shape
+    assert d_raw.dtype == torch.float32 and d_raw.is_contiguous() and nch == 5 + num_classes
+    assert scratch.dim() == 3 and scratch.shape[0] == 2 and scratch.is_contiguous()
+    assert workspace.numel() >= _lib.lib().sy_pred_grad_fold_workspace_floats(num_classes)
+    check(_lib.lib().sy_pred_grad_fold(d_raw.data_ptr() + a0 * nch * 4, B, A * nch, rows, num_classes, scratch.data_ptr(),
+                                       scratch.shape[1], scratch.shape[2], cin, g_reg.data_ptr(), g_obj.data_ptr(), g_cls.data_ptr(),
+                                       gb_reg.data_ptr(), gb_obj.data_ptr(), gb_cls.data_ptr(), workspace.data_ptr(),
+                                       stream_of(d_raw)), "sy_pred_grad_fold")
+
+
 def bn_finalize(ssum, ssq, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd,
                 nseg=1):
     """count = elements per channel PER SEGMENT; statistics [nseg][copies][C], outputs [nseg][C] (see the header)."""

@@ -329,8 +329,11 @@ class TrainPlan:
         self.on_bucket = None                 # TrainStep: callable(k, main_stream, side_stream) -> starts the bucket's all-reduce
         self.bn_mods = [op.mod.bn for op in convs]
         self.stem_scratch = None
-        self.pred_scratch = torch.zeros((2, 8, int(256 * head.width)), dtype=torch.float32, device=device) \
+        # wgrad scratch of the prediction convs [reg 0-3 | obj 4] / [cls] (zero between uses: sy_pred_grad_fold clears it)
+        self.pred_scratch = torch.zeros((2, max(8, self.nc), int(256 * head.width)), dtype=torch.float32, device=device) \
             if head is not None else None
+        self.pred_ws = torch.empty(int(ops._lib.lib().sy_pred_grad_fold_workspace_floats(self.nc)), dtype=torch.float32,
+                                   device=device) if head is not None else None
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, x):
@@ -437,13 +440,13 @@ class TrainPlan:
     # per-launch host cost is one ctypes call, and no Python-side view / descriptor / bookkeeping code runs.
     def _mark(self, kind, arg=None):
         if self._rec is not None:
-            self._rec.append((None, arg, kind))
+            self._rec.mark(kind, arg)
 
     def _py(self, fn):
         """A torch-op snippet inside a pass: runs now, and is replayed from the tape later."""
         fn()
         if self._rec is not None:
-            self._rec.append((None, fn, "py"))
+            self._rec.snippet(fn)
 
     def _run(self, name, body, key=None):
         from . import _lib
@@ -453,7 +456,8 @@ class TrainPlan:
             return
         prog = self.programs.get(name)
         if prog is None or prog[0] != key:
-            with _lib.record() as tape:
+            tape = _lib.NativeTape()                             # records inside the library, at the kernel-launch level
+            with tape:
                 self._rec = tape
                 try:
                     body()
@@ -464,60 +468,26 @@ class TrainPlan:
         self._interpret(prog[1])
 
     def _interpret(self, tape):
-        from . import _lib
-        dev_cuda = self.device.type == "cuda"
+        """Replay a recorded pass: ONE library call walks the launches, stream switches and event pairs (csrc/tape.hip);
+        Python is re-entered only for the recorded torch snippets and, in data-parallel runs, at the bucket marks."""
         side = self.side
-        if dev_cuda:
+        if self.device.type == "cuda":
             main = torch.cuda.current_stream(self.device)
             main_h = C.c_void_p(main.cuda_stream)
-            side_h = C.c_void_p(side.cuda_stream) if side is not None else main_h
+            side_h = C.c_void_p(side.cuda_stream) if side is not None else None
         else:
-            main = None
-            main_h = side_h = C.c_void_p(0)
-        cur, on_side = main_h, False
-        ring_done = [None] * self.RING
-        pool, ei = self._ev_pool, 0
-        for fn, args, name in tape:
-            if fn is not None:
-                rc = fn(*args, cur)
-                if rc != 0:
-                    _lib.check(rc, name)
-            elif name == "py":
-                if on_side:
-                    with torch.cuda.stream(side):
-                        args()
-                else:
-                    args()
-            elif name == "bucket":
-                if self.on_bucket is not None:
-                    self.on_bucket(args, main, side)
-            elif side is None:
-                continue
-            elif name == "side" or name == "fork":
-                if ei == len(pool):
-                    pool.append(torch.cuda.Event())
-                ev = pool[ei]; ei += 1
-                ev.record(main)
-                side.wait_event(ev)
-                if name == "side":
-                    cur, on_side = side_h, True
-            elif name == "side_nw":
-                cur, on_side = side_h, True
-            elif name == "main":
-                if args is not None:                              # a raw-gradient ring slot is busy until here
-                    if ei == len(pool):
-                        pool.append(torch.cuda.Event())
-                    ev = pool[ei]; ei += 1
-                    ev.record(side)
-                    ring_done[args] = ev
-                cur, on_side = main_h, False
-            elif name == "acquire":
-                ev = ring_done[args]
-                if ev is not None:
-                    main.wait_event(ev)
-                    ring_done[args] = None
-            elif name == "join":
-                main.wait_stream(side)
+            main, main_h, side_h = None, C.c_void_p(0), None
+
+        def snippet(fn, on_side):
+            if on_side:
+                with torch.cuda.stream(side):
+                    fn()
+            else:
+                fn()
+        on_bucket = None
+        if self.on_bucket is not None:
+            on_bucket = lambda k: self.on_bucket(k, main, side)      # noqa: E731
+        tape.replay(main_h, side_h, snippet, on_bucket)
 
     def _forward_op(self, op):
         nch = 5 + self.nc
@@ -630,10 +600,11 @@ class TrainPlan:
         self.ring_i = 0
         nf = self.n_frame_ops
         if self.head is None:                                    # backbone alone: the feature gradients come from the caller
-            for f, g in zip(self.fused, self._seed):
+            for i, f in enumerate(self.fused):
                 gv, acc = G.target(f)
                 assert not acc
-                self._py(lambda gv=gv, g=g: gv.set_nchw(g))
+                # read THIS call's seed at replay time: the recorded snippet must not bind the recording call's tensors
+                self._py(lambda gv=gv, i=i: gv.set_nchw(self._seed[i]))
         self._bucket_marks(-1)                                   # ranges no kernel writes (unused parameters)
         for pos, a in enumerate(self._backward_sequence()):      # head, DFP fusion, then the per-frame network
             if pos < len(self.ops) - 2 * nf:
@@ -686,26 +657,16 @@ class TrainPlan:
         cin = op.reg_x.C
 
         sc = self.pred_scratch
-        g_reg = self.gview[id(op.reg_mod.weight)].view(4, cin)
-        g_obj = self.gview[id(op.obj_mod.weight)].view(1, cin)
-        g_cls = self.gview[id(op.cls_mod.weight)].view(nc, cin)
-
-        def fold():
-            g_reg.add_(sc[0, 0:4, :cin]); g_obj.add_(sc[0, 4:5, :cin]); g_cls.add_(sc[1, 0:nc, :cin])
+        g_reg, g_obj, g_cls = (self.gview[id(m.weight)] for m in (op.reg_mod, op.obj_mod, op.cls_mod))
+        gb_r, gb_o, gb_c = (self.gview[id(m.bias)] for m in (op.reg_mod, op.obj_mod, op.cls_mod))
 
         def wg():
-            self._py(lambda: sc.zero_())
+            # two MFMA weight-gradient launches into the (zero) scratch, then one fold: weight gradients += scratch rows,
+            # bias gradients += column sums of this level's d_raw rows — all C-ABI launches, nothing for the host to do
             ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1, workspace=self.wgrad_ws)
             ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1, workspace=self.wgrad_ws)
-            self._py(fold)
+            ops.pred_grad_fold(d_raw, op.a0, hwk, nc, sc, cin, g_reg, g_obj, g_cls, gb_r, gb_o, gb_c, self.pred_ws)
         self._on_side(wg)
-        gb_r, gb_o, gb_c = (self.gview[id(m.bias)] for m in (op.reg_mod, op.obj_mod, op.cls_mod))
-        d_lvl = d_raw[:, op.a0:op.a0 + hwk]
-
-        def bias():
-            db = d_lvl.sum((0, 1))
-            gb_r.add_(db[0:4]); gb_o.add_(db[4:5]); gb_c.add_(db[5:])
-        self._py(bias)
 
     def _bn_backward(self, op, dyraw):
         """Residual fan-in + BatchNorm/SiLU backward of one BaseConv call: fills `dyraw` (grad of the raw conv
@@ -739,11 +700,11 @@ class TrainPlan:
         else:                                                        # Focus stem: 12 real + 4 zero-padded channels
             if self.stem_scratch is None:
                 self.stem_scratch = torch.zeros((w.shape[0], x.C, op.k, op.k), dtype=torch.float32, device=self.device)
-            sc, gw = self.stem_scratch, self.gview[id(w)]
-            self._py(lambda: sc.zero_())
+            sc, gw = self.stem_scratch, self.gview[id(w)]                # scratch zero between uses (cleared by the fold)
             ops.conv2d_wgrad(x, dyraw, sc, op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
                              tile=wt[0], target_blocks=wt[1])
-            self._py(lambda: gw.add_(sc[:, :w.shape[1]]))
+            kk = op.k * op.k
+            ops.rows_add_f32(gw, sc, w.shape[0], w.shape[1] * kk, w.shape[1] * kk, x.C * kk, zero_src=True)
 
     def _conv_pair_backward(self, a, b2):
         """Layer i of the current-frame and support-frame networks together: per-frame BN backward (separate
@@ -910,7 +871,7 @@ class _BackboneFunction(torch.autograd.Function):
     def forward(ctx, plan, x, *params):
         ctx.plan = plan
         fused = plan.forward(x)
-        return tuple(f.buf.clone().permute(0, 3, 1, 2) for f in fused)
+        return tuple(f.buf.view(f.N, f.H, f.W, f.ld)[..., f.c_off:f.c_off + f.C].permute(0, 3, 1, 2).clone() for f in fused)
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -1061,6 +1022,7 @@ class TrainStep:
         else:
             out = self._eager(x, lab, sup)
             self.eager_steps += 1
+        self.last_overlapped = len(self._reduced)               # buckets whose all-reduce started DURING backward
         if self.world > 1:
             # buckets whose all-reduce was not started during backward (the first two steps run the Python
             # wrappers / record the tape) go out now; then wait for all of them and average

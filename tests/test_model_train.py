@@ -363,3 +363,35 @@ def test_submodule_training_calls_compose_like_the_reference(backend, golden_dir
             assert _rel(sd[k[5:]].float().cpu(), z[k]) < 1e-3, k
     assert int(sd["backbone.backbone.stem.conv.bn.num_batches_tracked"]) == 2
     assert int(sd["head.stems.2.bn.num_batches_tracked"]) == 1
+
+
+def test_submodule_training_steps_follow_changing_inputs(backend):
+    """the stand-alone DFPPAFPN training plan must seed its backward with THIS call's feature gradients on
+    every step — steps 3+ replay a launch tape, whose recorded torch snippets must not hold on to the recording call's
+    tensors.  Four steps on different inputs: split path (backbone -> head through autograd) vs the fused YOLOX.forward."""
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+
+    def fresh():
+        m = sy.build_model("nano")
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        m = m.to(backend).train().set_compute_dtype("fp32")
+        m.head.use_l1 = True
+        return m
+    split, fused = fresh(), fresh()
+    for step in range(4):
+        x = synth_frames(2, 64, 96, seed=20 + step).to(backend)
+        lab, sup = synth_labels(2, 64, 96, cfg.num_classes, num_gt=6, seed=30 + step)
+        targets = (lab.to(backend), sup.to(backend))
+        for m in (split, fused):
+            for p in m.parameters():
+                p.grad = None
+            m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)      # same state every step
+        loss = split.head(split.backbone(x), targets, x)[0]
+        loss.backward()
+        out = fused(x, targets)
+        out["total_loss"].backward()
+        assert abs(float(loss) - float(out["total_loss"])) / abs(float(out["total_loss"])) < 1e-5, step
+        ref = {n: p.grad.detach().cpu() for n, p in fused.named_parameters()}
+        worst, name, _ = _per_param_l2(split, ref)
+        assert worst < 1e-3, "step %d: %s off by %.3e (split vs fused plan)" % (step, name, worst)
