@@ -1,0 +1,52 @@
+#!/bin/bash
+# tools/gpu.sh STAGE TASK [TASK ...] — the ONE runner for everything measured on the MI355X box (replaces the per-stage
+# one-off scripts of rounds 1-2).  Every task writes under gpurun_out/STAGE/; what is to be judged is then copied to
+# profiles/rNN/STAGE_*.  Arguments inside a task are comma separated (commas become spaces).
+#
+#   gpurun --timeout 900 -- 'bash tools/gpu.sh a tests smoke bench:train_l bench:train_l_b4:--batch,4,--no-cpu-baseline prof'
+#
+# tasks
+#   tests[:PYTEST_ARGS]          pytest tests -m gpu -q [args]                          -> pytest_gpu.log
+#   smoke                        __graft_entry__.smoke()                                -> smoke.log
+#   bench:NAME[:ARGS]            python bench.py ARGS                                   -> bench_NAME.json
+#   benv:NAME:K=V,K=V[:ARGS]     same with environment variables (A/B switches)         -> bench_NAME.json
+#   prof[:ARGS]                  rocprofv3 --kernel-trace --stats of bench.py (train l, 5 steps) -> kernel_stats.csv, rocprof_last_step.txt
+#   traffic[:WORKLOAD[:MODEL]]   PMC HBM-traffic passes (tools/pmc_traffic.py)          -> traffic_WORKLOAD_MODEL.{json,txt}
+#   mfma                         MFMA-busy counter pass (tools/pmc_mfma_util.py)         -> mfma_util_train_l.txt
+#   layers                       per-layer kernel times (tools/profile_train.py)         -> train_l_layer_profile.txt
+#   host[:MODEL]                 host-side launch profile (tools/host_profile.py)        -> host_profile_train_MODEL.txt
+#   py:NAME:SCRIPT[:ARGS]        python SCRIPT ARGS                                      -> NAME.txt
+STAGE=$1; shift
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+O=gpurun_out/$STAGE
+mkdir -p "$O"
+git rev-parse HEAD > "$O/commit.txt" 2>/dev/null || cp tools/.head_commit "$O/commit.txt" 2>/dev/null
+noise='RCCL|HIP version|ROCm version|Hostname|Librccl|amdgpu.ids'
+for task in "$@"; do
+    IFS=: read -r kind a b c <<< "$task"
+    t0=$(date +%s)
+    case $kind in
+        tests) (timeout 1500 python -m pytest tests -m gpu -q ${a//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
+               grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
+        smoke) (timeout 600 python __graft_entry__.py smoke 2>&1 | grep -vE "$noise" | tail -2) > $O/smoke.log 2>&1; cat $O/smoke.log ;;
+        bench) (timeout 900 python bench.py ${b//,/ } 2>$O/bench_$a.err | tail -1) > $O/bench_$a.json
+               python tools/bench_line.py $O/bench_$a.json ;;
+        benv)  (env ${b//,/ } timeout 900 python bench.py ${c//,/ } 2>$O/bench_$a.err | tail -1) > $O/bench_$a.json
+               python tools/bench_line.py $O/bench_$a.json ;;
+        prof)  rm -rf /tmp/prof_$STAGE
+               (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$STAGE -- python $OLDPWD/bench.py --workload train --model l --steps 5 --warmup 4 --no-cpu-baseline --extras 0 ${a//,/ } 2>&1 | tail -1) > $O/rocprof_bench_line.json 2>&1
+               cp /tmp/prof_$STAGE/*/*kernel_stats.csv $O/train_l_b8_bf16_kernel_stats.csv 2>/dev/null
+               python tools/trace_analyze.py $(ls /tmp/prof_$STAGE/*/*kernel_trace.csv | head -1) > $O/rocprof_last_step.txt 2>&1
+               head -40 $O/rocprof_last_step.txt ;;
+        traffic) w=${a:-train}; m=${b:-l}
+               (timeout 1200 python tools/pmc_traffic.py --out $O/traffic_${w}_$m.json -- --workload $w --model $m 2>&1 | tail -20) > $O/traffic_${w}_$m.txt 2>&1
+               tail -20 $O/traffic_${w}_$m.txt ;;
+        mfma)  (timeout 900 python tools/pmc_mfma_util.py 2>&1 | tail -40) > $O/mfma_util_train_l.txt 2>&1; tail -30 $O/mfma_util_train_l.txt ;;
+        layers) (timeout 900 python tools/profile_train.py ${a//,/ } 2>&1 | grep -vE "$noise") > $O/train_l_layer_profile.txt 2>&1; tail -12 $O/train_l_layer_profile.txt ;;
+        host)  m=${a:-l}; (timeout 600 python tools/host_profile.py $m 2>&1 | grep -v "^$" | tail -40) > $O/host_profile_train_$m.txt 2>&1; tail -12 $O/host_profile_train_$m.txt ;;
+        py)    (timeout 1200 python $b ${c//,/ } 2>&1 | grep -vE "$noise") > $O/$a.txt 2>&1; tail -40 $O/$a.txt ;;
+        *) echo "unknown task $task" ;;
+    esac
+    echo "== $task: $(( $(date +%s) - t0 )) s"
+done

@@ -45,10 +45,6 @@ torch.cuda.synchronize()
 ps = pstats.Stats(pr)
 ps.sort_stats("tottime")
 ps.print_stats(22)
-tape = st.plan.programs
-for k, (key, t) in tape.items():
-    kinds = {}
-    for fn, args, nm in t:
-        kk = "launch" if fn is not None else nm
-        kinds[kk] = kinds.get(kk, 0) + 1
-    print(k, kinds)
+for k, (key, t) in st.plan.programs.items():
+    n_entries, n_launches = t.size()
+    print("%s: %d tape entries, %d kernel launches, %d host snippets" % (k, n_entries, n_launches, len(t.snippets)))
