@@ -119,10 +119,12 @@ SY_API int sy_focus_pack(const float* in, int N, int Ctot, int c0, int H, int W,
 /* Device-side input pipeline: uint8 HWC frames -> model input in ONE launch.
  * cur / sup: [B, Hs, Ws, 3] uint8 (BGR as cv2.imread delivers them; sup = NULL for a single on_pipe frame),
  * image_stride / row_stride in bytes.  Steps, in the reference's order:
- *   decimate (1 | 2 | 0): the load-time cv2.resize (exps/dataset/tal_flip_one_future_argoversedataset.py:179-187,
+ *   decimate (1 | 2 | 0 | -1): the load-time cv2.resize (exps/dataset/tal_flip_one_future_argoversedataset.py:179-187,
  *       streamyolo_det.py:177): 1 = copy, 2 = exact 2x = (a+b+c+d+2)>>2 (OpenCV's INTER_AREA fast path), 0 = any other
  *       camera size: r = min(H/Hs, W/Ws), OpenCV's fixed-point INTER_LINEAR to (int(Ws r), int(Hs r)) (`preproc`,
  *       exps/data/data_augment_flip.py:151-167); restated from OpenCV's source, unpinned against a cv2 binary;
+ *       -1 = the streaming detector's cv2.resize(img, (W, H)): each axis stretched on its own to exactly the H x W canvas
+ *       (sAP/streamyolo/streamyolo_det.py:176-178, canvas = (int(Hs * in_scale), int(Ws * in_scale))), same arithmetic;
  *   mirror[b] != 0: `_mirror`'s image[:, ::-1], the same flag for both frames of a pair
  *       (exps/data/data_augment_flip.py:140-148, DoubleTrainTransform :219-222);
  *   letterbox onto an H x W canvas filled with 114, image at the top-left (`preproc` :151-167);
@@ -234,6 +236,9 @@ typedef struct sy_bn_running_entry {
     double count[2];            /* elements per channel of each call */
     int32_t C, copies, calls;
     float momentum;
+    int32_t ld;                 /* elements between consecutive replicas (0 = C): > C when the module's channels are a slice of a
+                                   wider statistics array (sibling convolutions stacked into one launch) */
+    int32_t reserved;
 } sy_bn_running_entry;
 SY_API int sy_bn_running_update(const sy_bn_running_entry* entries, int n_entries, int max_C, void* stream);
 /* sy_bn_finalize + sy_bn_silu_apply in one launch (the training forward of every BaseConv: nn.BatchNorm2d in training mode

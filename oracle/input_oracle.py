@@ -26,8 +26,11 @@ def cv2_resize_linear_u8(img, dsize):
     """cv2.resize(img, dsize=(w, h), interpolation=cv2.INTER_LINEAR) for uint8 HWC images, restated from OpenCV's
     modules/imgproc/src/resize.cpp (8-bit fixed-point path; INTER_RESIZE_COEF_BITS = 11):
         scale = 1. / ((double)dst / src);  fx = (float)((dx + 0.5) * scale - 0.5);  sx = floor(fx);  fx -= sx
-        sx < 0 -> (fx, sx) = (0, 0);  sx >= src - 1 -> (fx, sx) = (0, src - 1)
-        alpha = saturate_cast<short>({1 - fx, fx} * 2048)                    (cvRound: round half to even)
+        HORIZONTAL only: sx < 0 -> (fx, sx) = (0, 0);  sx >= src - 1 -> (fx, sx) = (0, src - 1)
+        VERTICAL: the fraction is kept, the two ROW INDICES are clamped (srows[k] = clip(sy + k, 0, src - 1)) — at the top /
+        bottom border both taps read the same row with b0 + b1 = 2048, and the two separate >> 16 floors can land 1 LSB below
+        the single-row value
+        alpha / beta = saturate_cast<short>({1 - f, f} * 2048)              (cvRound: round half to even)
         horizontal:  D = S[sx] * alpha0 + S[sx + 1] * alpha1                 (int32)
         vertical:    dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
     (both scale factors exactly 2 take the INTER_AREA fast path instead: load_time_resize(img, 2)).
@@ -37,19 +40,20 @@ def cv2_resize_linear_u8(img, dsize):
     if sh == 2 * dh and sw == 2 * dw:
         return load_time_resize(img, 2)
 
-    def taps(dn, sn):
+    def taps(dn, sn, horizontal):
         scale = 1.0 / (float(dn) / float(sn))
         f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
         f = (f - s.astype(np.float32)).astype(np.float32)
-        lo, hi = s < 0, s >= sn - 1
-        f = np.where(lo | hi, np.float32(0), f)
-        s = np.where(lo, 0, np.where(hi, sn - 1, s))
+        if horizontal:
+            lo, hi = s < 0, s >= sn - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s = np.where(lo, 0, np.where(hi, sn - 1, s))
         a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
         a1 = np.rint(f * np.float32(2048)).astype(np.int64)
-        return s, np.minimum(s + 1, sn - 1), a0, a1
-    x0, x1, ax0, ax1 = taps(dw, sw)
-    y0, y1, ay0, ay1 = taps(dh, sh)
+        return np.clip(s, 0, sn - 1), np.clip(s + 1, 0, sn - 1), a0, a1
+    x0, x1, ax0, ax1 = taps(dw, sw, True)
+    y0, y1, ay0, ay1 = taps(dh, sh, False)
     src = img.astype(np.int64)
     hor = src[:, x0] * ax0[None, :, None] + src[:, x1] * ax1[None, :, None]           # [sh, dw, 3], scaled by 2^11
     S0, S1 = hor[y0], hor[y1]

@@ -43,7 +43,7 @@ class BnRunningEntry(C.Structure):
     """sy_bn_running_entry (include/streamyolo_hip.h)."""
     _fields_ = [("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("sum", C.c_void_p * 2),
                 ("sqsum", C.c_void_p * 2), ("count", C.c_double * 2), ("C", C.c_int32), ("copies", C.c_int32),
-                ("calls", C.c_int32), ("momentum", C.c_float)]
+                ("calls", C.c_int32), ("momentum", C.c_float), ("ld", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PackEntry(C.Structure):

@@ -19,8 +19,8 @@
 //                2, (a + b + c + d + 2) >> 2 — Argoverse's 1200x1920 -> 600x960;
 //   decimate 0   any other camera size: `preproc`'s r = min(H / h, W / w), cv2.resize(img, (int(w r), int(h r)),
 //                INTER_LINEAR) (data_augment_flip.py:151-167) = OpenCV's fixed-point bilinear for 8-bit images: source
-//                coordinate fx = (float)((dx + 0.5) * scale - 0.5), taps sx = floor(fx), sx + 1 (clamped at the borders with
-//                the fraction zeroed), coefficients saturate_cast<short>(frac * 2048) (round half to even), horizontal pass
+//                coordinate fx = (float)((dx + 0.5) * scale - 0.5), taps sx = floor(fx), sx + 1 (horizontally: clamped at the
+//                borders with the fraction zeroed; vertically: row indices clamped, fraction kept), coefficients saturate_cast<short>(frac * 2048) (round half to even), horizontal pass
 //                in int32, vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
 #include "sy_pointwise.h"
 
@@ -37,15 +37,19 @@ struct FrameSrc {               // uint8 HWC frames of one batch: current and (o
     const unsigned char* mirror;    // [B] flags or nullptr
     // OpenCV's INTER_LINEAR tap set of one destination coordinate (resize.cpp, 8-bit fixed-point path)
     struct Tap { int s0, s1; int a0, a1; };
-    static __device__ __forceinline__ Tap tap(int d, double scale, int ssize) {
+    // HORIZ: OpenCV zeroes the fraction at the left / right border (xofs / alpha tables); the vertical pass keeps the fraction
+    // and only clamps the two row indices (srows[k] = clip(sy + k)) — both taps then read the same row with b0 + b1 = 2048
+    template <bool HORIZ> static __device__ __forceinline__ Tap tap(int d, double scale, int ssize) {
         float f = (float)(((double)d + 0.5) * scale - 0.5);
         int s = (int)floorf(f);
         f -= (float)s;
-        if (s < 0) { f = 0.0f; s = 0; }
-        if (s >= ssize - 1) { f = 0.0f; s = ssize - 1; }
+        if (HORIZ) {
+            if (s < 0) { f = 0.0f; s = 0; }
+            if (s >= ssize - 1) { f = 0.0f; s = ssize - 1; }
+        }
         Tap t;
-        t.s0 = s;
-        t.s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+        t.s0 = s < 0 ? 0 : (s > ssize - 1 ? ssize - 1 : s);
+        t.s1 = s + 1 < 0 ? 0 : (s + 1 > ssize - 1 ? ssize - 1 : s + 1);
         t.a0 = (int)rintf((1.0f - f) * 2048.0f);            // saturate_cast<short>(float) = cvRound (round half to even)
         t.a1 = (int)rintf(f * 2048.0f);
         return t;
@@ -57,7 +61,7 @@ struct FrameSrc {               // uint8 HWC frames of one batch: current and (o
         const unsigned char* p = img[f] + n * image_stride;
         if (dec == 1) return (float)p[(long long)y * row_stride + x * 3 + c];
         if (dec == 0) {
-            const Tap ty = tap(y, scale_y, src_h), tx = tap(x, scale_x, src_w);
+            const Tap ty = tap<false>(y, scale_y, src_h), tx = tap<true>(x, scale_x, src_w);
             const unsigned char* r0 = p + (long long)ty.s0 * row_stride + c;
             const unsigned char* r1 = p + (long long)ty.s1 * row_stride + c;
             const int S0 = (int)r0[tx.s0 * 3] * tx.a0 + (int)r0[tx.s1 * 3] * tx.a1;      // horizontal pass, scaled by 2^11
@@ -160,16 +164,23 @@ extern "C" int sy_frames_u8_pack(const uint8_t* cur, const uint8_t* sup, int B, 
                                  int layout, void* out_cur, void* out_sup, int dtype, void* stream) {
     if (cur == nullptr || out_cur == nullptr || B <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0)
         return SY_ERR_ARG;
-    if (decimate < 0 || decimate > 2) return SY_ERR_UNSUPPORTED;
+    if (decimate < -1 || decimate > 2) return SY_ERR_UNSUPPORTED;
     if (decimate == 2 && ((Hs & 1) || (Ws & 1))) return SY_ERR_UNSUPPORTED;
     if (row_stride < Ws * 3 || image_stride < (int64_t)row_stride * Hs) return SY_ERR_ARG;
     int hs, ws;
     FrameSrc src;
     src.src_h = Hs; src.src_w = Ws; src.scale_y = 1.0; src.scale_x = 1.0;
-    if (decimate == 0) {
-        // preproc: r = min(H / h, W / w); resized to (int(w * r), int(h * r)) — the same double arithmetic as the Python code
-        const double r = ((double)H / Hs < (double)W / Ws) ? (double)H / Hs : (double)W / Ws;
-        hs = (int)(Hs * r); ws = (int)(Ws * r);
+    if (decimate == 0 || decimate == -1) {
+        if (decimate == 0) {
+            // preproc: r = min(H / h, W / w); resized to (int(w * r), int(h * r)) — the same double arithmetic as the Python code
+            const double r = ((double)H / Hs < (double)W / Ws) ? (double)H / Hs : (double)W / Ws;
+            hs = (int)(Hs * r); ws = (int)(Ws * r);
+        } else {
+            // streaming: cv2.resize(img, (w_img, h_img)) with the canvas = (int(h * in_scale), int(w * in_scale)) — each axis
+            // stretched on its own, no letterbox (sAP/streamyolo/streamyolo_det.py:176-178)
+            hs = H; ws = W;
+            decimate = 0;
+        }
         if (hs < 1 || ws < 1 || hs > H || ws > W) return SY_ERR_UNSUPPORTED;
         src.scale_y = 1.0 / ((double)hs / Hs); src.scale_x = 1.0 / ((double)ws / Ws);
         if (hs == Hs && ws == Ws) decimate = 1;                          // r == 1: cv::resize copies

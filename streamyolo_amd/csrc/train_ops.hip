@@ -345,11 +345,12 @@ __global__ __launch_bounds__(kBlock) void bn_running_update_kernel(const sy_bn_r
     const int c = blockIdx.y * 32 + cl;
     if ((int)blockIdx.y * 32 >= e.C) return;                     // uniform for the workgroup
     float rm = 0.0f, rv = 0.0f;
+    const long long ld = e.ld > 0 ? e.ld : e.C;                  // replica pitch (channel slice of a wider statistics array)
     if (rg == 0 && c < e.C) { rm = e.running_mean[c]; rv = e.running_var[c]; }
     for (int j = 0; j < e.calls; ++j) {
         float s = 0.0f, q = 0.0f;
         if (c < e.C)
-            for (int k = rg; k < e.copies; k += 8) { s += e.sum[j][(long long)k * e.C + c]; q += e.sqsum[j][(long long)k * e.C + c]; }
+            for (int k = rg; k < e.copies; k += 8) { s += e.sum[j][k * ld + c]; q += e.sqsum[j][k * ld + c]; }
         s_s[rg][cl] = s;
         s_q[rg][cl] = q;
         __syncthreads();

@@ -24,7 +24,8 @@ class FramePairsU8:
     cur, sup : uint8 [B, Hs, Ws, 3] (BGR, as cv2.imread delivers them), same strides
     canvas   : (H, W) letterbox size = exp.input_size / exp.test_size; the frames sit top-left on a 114 canvas
     decimate : 1, or 2 for the exact 2x load-time resize (Argoverse 1200x1920 -> 600x960), or 0 for any other camera
-               size: `preproc`'s r = min(H / h, W / w) bilinear letterbox resize (OpenCV fixed-point arithmetic)
+               size: `preproc`'s r = min(H / h, W / w) bilinear letterbox resize (OpenCV fixed-point arithmetic), or -1
+               for the streaming detector's per-axis stretch to exactly the canvas (streamyolo_det.py:176-178)
     mirror   : None or uint8 [B]; flag b flips BOTH frames of pair b horizontally (DoubleTrainTransform)
     out_size : (Ho, Wo) the plan runs at (Exp.preprocess's tsize); defaults to the canvas
 

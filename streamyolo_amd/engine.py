@@ -92,8 +92,10 @@ class FocusOp:
 # ------------------------------------------------------------------------------------------------
 class MergedConv:
     """Two BaseConvs that read the SAME input (CSPLayer conv2 / conv1, the first cls / reg tower conv of a head level) as ONE
-    launch with their output channels stacked — eval plans only (BatchNorm folded into the epilogue's affine): one read of the
-    input, twice the GEMM N on the narrowest layers, one launch less on the latency-bound streaming step."""
+    launch with their output channels stacked: one read of the input, twice the GEMM N on the narrowest layers, one launch
+    less per kernel kind.  Eval plans fold BatchNorm into the epilogue's affine (ParamCache); training plans stack the
+    operand layouts, BatchNorm parameters and gradient-arena slots of the parts (train_engine.StagedWeights / TrainPlan) —
+    per-channel batch statistics do not care which module a channel belongs to."""
 
     def __init__(self, mods):
         self.mods = tuple(mods)
@@ -147,6 +149,11 @@ class _Builder:
             dst = cat.slice(0, hid) if i == n - 1 else None
             a = self.conv(b.conv2, u, dst, res=a if b.use_add else None, tag="%s.m.%d.conv2" % (tag, i))
         return self.conv(mod.conv3, cat, out, tag=tag + ".conv3")
+
+
+def base_convs(mod):
+    """The BaseConv modules behind a ConvOp's `mod` (one, or the stacked parts of a MergedConv, in channel order)."""
+    return mod.mods if isinstance(mod, MergedConv) else (mod,)
 
 
 def build_frame_net(b, pafpn, N, H, W):

@@ -293,7 +293,8 @@ def bn_finalize_apply(ssum, ssq, count, gamma, beta, eps, scale, shift, mean, in
 
 
 class BnRunningTable:
-    """Device table for sy_bn_running_update.  `modules` = [(bn_module, [(sum, sqsum, count), ...calls in order])]."""
+    """Device table for sy_bn_running_update.  `modules` = [(bn_module, [(sum, sqsum, count[, copies, ld]), ...calls in order])];
+    sum / sqsum start at the module's first channel; ld = replica pitch when they are a channel slice of a wider array."""
 
     def __init__(self, modules, device):
         arr = (_lib.BnRunningEntry * len(modules))()
@@ -301,10 +302,12 @@ class BnRunningTable:
         for e, (bn, calls) in zip(arr, modules):
             assert 1 <= len(calls) <= 2
             e.running_mean, e.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-            for j, (ssum, ssq, count) in enumerate(calls):
+            for j, call in enumerate(calls):
+                ssum, ssq, count = call[:3]
                 e.sum[j], e.sqsum[j], e.count[j] = ssum.data_ptr(), ssq.data_ptr(), float(count)
             e.C = bn.num_features
-            e.copies = calls[0][0].numel() // e.C
+            e.copies = calls[0][3] if len(calls[0]) > 3 else calls[0][0].numel() // e.C
+            e.ld = calls[0][4] if len(calls[0]) > 4 else 0
             e.calls = len(calls)
             e.momentum = bn.momentum if bn.momentum is not None else 0.1
             self.max_c = max(self.max_c, e.C)
@@ -420,7 +423,80 @@ _TILE_CANDIDATES = {            # workgroup tile (channels x pixels) + staging s
     "c32": [21, 23, 39, 85, 87],
 }
 _tile_cache = {}
+_wgrad_cache = {}
 import os as _os
+
+
+# ---- persisted tuner choices ------------------------------------------------------------------------------------------------
+# The per-shape variant choice is a measurement (a few launches of every candidate): ~70 conv shapes + ~70 wgrad shapes per
+# (batch, size) for StreamYOLO-l.  Multi-scale training meets a new (H, W) every 10 iterations (cfgs/l_s50_onex_dfp_tal_flip.py:
+# 139-158), so the choices are written to a JSON file keyed by a hash of the kernel sources (another build re-tunes) and the
+# device name; later processes and later plans start from it.  STREAMYOLO_TUNE_CACHE: path, or "0" to disable.  The in-tree
+# default travels with the library; it also makes the variant choice — and with it the step time — reproducible run to run.
+class _TuneStore:
+    def __init__(self):
+        self.path, self.loaded, self.dirty, self.key = None, False, False, None
+
+    def _source_key(self, device):
+        import hashlib
+        here = _os.path.dirname(_os.path.abspath(__file__))
+        h = hashlib.sha256()
+        src = _os.path.join(here, "csrc")
+        for fn in sorted(_os.listdir(src)) if _os.path.isdir(src) else []:
+            if fn.endswith((".hip", ".h")):
+                with open(_os.path.join(src, fn), "rb") as f:
+                    h.update(fn.encode() + b"\0" + f.read())
+        h.update(_lib.lib().sy_version())
+        h.update(repr((HALO_TILES, STREAM_1X1, TILE_1X1K)).encode())          # candidate-set switches (A/B runs)
+        return h.hexdigest()[:16] + "|" + torch.cuda.get_device_name(device)
+
+    def load(self, device):
+        if self.loaded:
+            return
+        self.loaded = True
+        env = _os.environ.get("STREAMYOLO_TUNE_CACHE", "")
+        if env == "0" or _lib.is_emulator():
+            return
+        self.path = env or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lib", "tune_cache.json")
+        self.key = self._source_key(device)
+        try:
+            import json
+            with open(self.path) as f:
+                d = json.load(f)
+            if d.get("key") != self.key:
+                return
+            dev = str(device)
+            for k, v in d.get("tile", []):
+                _tile_cache[tuple(k) + (dev,)] = int(v)
+            for k, v in d.get("wgrad", []):
+                _wgrad_cache[tuple(k) + (dev,)] = (int(v[0]), int(v[1]))
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+
+    def save(self):
+        if not self.dirty or self.path is None:
+            return
+        self.dirty = False
+        import json
+        d = {"key": self.key, "tile": [[list(k[:-1]), v] for k, v in _tile_cache.items()],
+             "wgrad": [[list(k[:-1]), list(v)] for k, v in _wgrad_cache.items()]}
+        try:
+            tmp = self.path + ".tmp%d" % _os.getpid()
+            with open(tmp, "w") as f:
+                json.dump(d, f)
+            _os.replace(tmp, self.path)
+        except OSError:
+            pass
+
+
+_tune_store = _TuneStore()
+
+
+def save_tuned():
+    """Write tuner choices made since the last call to the cache file (plans call this after their tuning step)."""
+    _tune_store.save()
+
+
 HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "112,113,114,115,116,117,118").split(",") if t]
 STREAM_1X1 = _os.environ.get("STREAMYOLO_STREAM_1X1", "1") != "0"
 TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123").split(",") if t]
@@ -451,6 +527,7 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     library's static heuristic) when tuning is off.  Measured with HIP events on dummy tensors."""
     if not autotune_enabled(device):
         return 0
+    _tune_store.load(device)
     key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats), str(device))
     hit = _tile_cache.get(key)
     if hit is not None:
@@ -501,6 +578,7 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
         if dt < best_t:
             best, best_t = t, dt
     _tile_cache[key] = best
+    _tune_store.dirty = True
     return best
 
 
@@ -513,13 +591,12 @@ _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 102
                      (49, 128), (49, 256), (49, 512), (65, 256), (65, 512),
                      # ... on eight waves (conv_wgrad9b_kernel)
                      (51, 128), (51, 256), (67, 256), (67, 512)]
-_wgrad_cache = {}
-
 
 def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace):
     """(tile, target_blocks) of the fastest sy_conv2d_wgrad variant for this shape (cached), (0, 0) when off."""
     if not autotune_enabled(device):
         return (0, 0)
+    _tune_store.load(device)
     key = (dtype_code(dtype), N, H, W, Cin, Ho, Wo, Cout, k, stride, str(device))
     hit = _wgrad_cache.get(key)
     if hit is not None:
@@ -547,4 +624,5 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
         if dt < best_t:
             best, best_t = (t, tb), dt
     _wgrad_cache[key] = best
+    _tune_store.dirty = True
     return best

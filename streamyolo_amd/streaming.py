@@ -42,19 +42,29 @@ class StreamingDetector:
     then per camera frame `preproc` -> `model(frame, buffer=buffer, mode='on_pipe')` -> `inference` (:176-181), the
     buffer being reset at every sequence start (:150).
 
-    Frames are the raw uint8 HWC arrays `cv2.imread` returns.  With in_scale = 0.5 the reference's cv2.resize is the
-    exact 2x decimation, with any other in_scale OpenCV's fixed-point bilinear resize — both done on the device together
-    with the Focus packing (sy_frames_u8_pack, csrc/input_pipeline.hip)."""
+    Frames are the raw uint8 HWC arrays `cv2.imread` returns.  The reference resizes every frame to
+    (h_img, w_img) = (int(H * in_scale), int(W * in_scale)) with cv2.resize(img, (w_img, h_img)) (:176-178: truncation, each
+    axis stretched on its own): with in_scale = 0.5 on even frames that is the exact 2x decimation, with any other in_scale
+    OpenCV's fixed-point bilinear resize — both done on the device together with the Focus packing (sy_frames_u8_pack,
+    csrc/input_pipeline.hip)."""
 
     def __init__(self, model, frame_hw, in_scale=0.5, num_classes=8, conf_thre=0.01, nms_thresh=0.65, dtype="fp16",
                  device="cuda"):
         self.model = model.to(device).eval().set_compute_dtype(dtype)
         self.device = torch.device(device)
         self.in_scale = in_scale
-        self.decimate = {1.0: 1, 0.5: 2}.get(float(in_scale), 0)          # 0: general-ratio bilinear (streamyolo_det.py:177)
         self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
-        # cv2.resize(frame, dsize=None, fx=in_scale, fy=in_scale): dsize = round(src * scale); the plan needs even sizes
-        self.canvas = (int(round(self.frame_hw[0] * in_scale)), int(round(self.frame_hw[1] * in_scale)))
+        # h_img, w_img = int(1200 * in_scale), int(1920 * in_scale) (streamyolo_det.py:177): truncation, per axis
+        self.canvas = (int(self.frame_hw[0] * in_scale), int(self.frame_hw[1] * in_scale))
+        if self.canvas[0] % 2 or self.canvas[1] % 2:
+            raise ValueError("StreamingDetector: in_scale %r gives an odd %dx%d network input (the Focus stem needs even sizes)"
+                             % (in_scale, self.canvas[0], self.canvas[1]))
+        if self.canvas == self.frame_hw:
+            self.decimate = 1
+        elif (2 * self.canvas[0], 2 * self.canvas[1]) == self.frame_hw:
+            self.decimate = 2
+        else:
+            self.decimate = -1                                    # per-axis fixed-point bilinear stretch to the canvas
         self.num_classes, self.conf_thre, self.nms_thresh = num_classes, conf_thre, nms_thresh
         self._slot = torch.empty((1,) + self.frame_hw + (3,), dtype=torch.uint8, device=self.device)
         self._in = FramePairsU8(self._slot, None, self.canvas, self.decimate)

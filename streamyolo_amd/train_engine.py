@@ -27,7 +27,7 @@ import torch
 
 from . import ops
 from .data import FramePairsU8
-from .engine import _Builder, build_frame_net, build_fuse_net, build_head_net
+from .engine import _Builder, MergedConv, base_convs, build_frame_net, build_fuse_net, build_head_net
 from .model.plan_cache import compute_dtype_for
 from .ops import View, EPI_LINEAR, CONV_DGRAD
 
@@ -150,17 +150,33 @@ class StagedWeights:
         def _ptr(t):
             return None if t is None else t.data_ptr()
 
+        self.bn = {}                     # id(MergedConv) -> (gamma stack, beta stack) fp32, refreshed with the weights
         for op in plan_ops:
             if op.kind == "conv" and id(op.mod) not in self.conv:
-                w = op.mod.conv.weight
-                assert w.dtype == torch.float32 and w.is_contiguous()
-                co, ci, kh, kw = w.shape
+                parts = base_convs(op.mod)                                 # one BaseConv, or the stacked parts of a MergedConv
+                w0 = parts[0].conv.weight
+                ci, kh, kw = w0.shape[1:]
+                co = sum(m.conv.weight.shape[0] for m in parts)
                 taps, CI = kh * kw, (16 if ci == 12 else ci)           # Focus stem: 12 -> 16 channels (zero weights)
                 packed, packed_t = z(co * taps * CI).view(co, taps * CI), z(CI * taps * co).view(CI, taps * co)
                 frag = z(-(-co // 32) * 32 * taps * CI) if CI % bk == 0 else None
                 frag_t = z(-(-CI // 32) * 32 * taps * co) if co % bk == 0 else None
-                entry(w, packed, packed_t, frag, frag_t, co, ci, taps, 0, co, co, CI)
+                r0 = 0
+                for m in parts:
+                    w = m.conv.weight
+                    assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape[1:]) == (ci, kh, kw)
+                    entry(w, packed, packed_t, frag, frag_t, w.shape[0], ci, taps, r0, co, co, CI)
+                    r0 += w.shape[0]
                 self.conv[id(op.mod)] = (packed, packed_t, frag, frag_t)
+                if len(parts) > 1:                                     # stacked BatchNorm affine parameters (fp32 copies)
+                    gs, bs_ = z(co, torch.float32), z(co, torch.float32)
+                    r0 = 0
+                    for m in parts:
+                        c = m.bn.weight.numel()
+                        entry(m.bn.weight, gs, None, None, None, c, 1, 1, r0, co, co, 1, ops.DTYPE_NAME["fp32"])
+                        entry(m.bn.bias, bs_, None, None, None, c, 1, 1, r0, co, co, 1, ops.DTYPE_NAME["fp32"])
+                        r0 += c
+                    self.bn[id(op.mod)] = (gs, bs_)
             elif op.kind == "pred":
                 cin, nc = op.reg_mod.weight.shape[1], op.cls_mod.weight.shape[0]
                 w_ro, w_ro_t = z(5 * cin).view(5, cin), z(cin * 8).view(cin, 8)
@@ -196,6 +212,7 @@ class StagedWeights:
 
 
 CSP_FORK = os.environ.get("STREAMYOLO_CSP_FORK", "1") != "0"
+MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
 
 
 def _csp_role(tag):
@@ -219,13 +236,14 @@ class TrainPlan:
     STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
     TAPE_ON_CPU = True           # the SIMT-emulator test runs replay launch tapes too (same code path as the GPU)
 
-    def __init__(self, model, B, H, W, dtype, device, parts="full", feat_shapes=None):
+    def __init__(self, model, B, H, W, dtype, device, parts="full", feat_shapes=None, pool=None):
         """parts: "full" = YOLOX (backbone + head, the fused forward + loss + backward plan); "backbone" = a DFPPAFPN alone
         (frames -> fused FPN features, gradients of the features in); "head" = a TALHead alone on given fused features
         (`feat_shapes` = [(C, H, W)] per level) — the stand-alone training-mode entry points of the sub-modules, which the
         reference's YOLOX.forward composes (exps/model/yolox.py:32-38)."""
         self.model, self.B, self.H, self.W, self.device = model, B, H, W, device
         self.parts = parts
+        self.pool = pool                     # model-level PlanCache: shared scratch across the plans of different input sizes
         self.dtype = ops.dtype_code(dtype)
         self.tdtype = ops.TORCH_DTYPE[self.dtype]
         pafpn = model.backbone if parts == "full" else (model if parts == "backbone" else None)
@@ -233,6 +251,9 @@ class TrainPlan:
         self.head = head
         self.cache = None                    # StagedWeights, built below once the plan's ops exist
         b = _PairBuilder(self.dtype, device)
+        # sibling convolutions (CSP conv2 || conv1, the first cls / reg tower conv of a head level) as ONE conv / BatchNorm /
+        # dgrad / wgrad launch each, as in the inference plans (engine.MergedConv): -88 launches per l step, no `+=` dgrad pass
+        b.merge_siblings = MERGE_SIBLINGS_TRAIN
         if pafpn is not None:
             self.f0_cur, cur = build_frame_net(b, pafpn, B, H, W)          # current frame  (dfp_pafpn.py:120-140)
             self.n_frame_ops = len(b.ops)
@@ -299,13 +320,13 @@ class TrainPlan:
             off += S * C
         # raw-gradient scratch ring: the weight-gradient kernels of layer i run on the side stream while the main
         # stream is already producing layer i-1's raw gradient, so a slot is reused only after its wgrad retired
-        self.dyraw_ring = [torch.empty(max_raw, dtype=self.tdtype, device=device) for _ in range(self.RING)]
+        self.max_raw = max_raw
+        self._bind_scratch()
         self.ring_i = 0
         self.side = torch.cuda.Stream(device=device) if (device.type == "cuda" and self.STREAMS > 1) else None
         self.tuned = False                    # the first step (autotuning) runs on one stream
         self.force_serial = False             # profile(): per-kernel durations without overlap
         self._ev_pool = []
-        self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=device)
         for op in self.ops:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
@@ -317,7 +338,23 @@ class TrainPlan:
         self.programs, self._rec, self._param_sig = {}, None, None
 
         # ---- flat gradient arena in parameter layout ------------------------------------------------
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        # Parameter order of the arena = model.parameters() order, except that the parts of a merged convolution sit side by
+        # side — [w_a | w_b], [gamma_a | gamma_b], [beta_a | beta_b] — so the stacked launch writes ONE contiguous gradient.
+        group_of = {}
+        for op in self.ops:
+            if op.kind == "conv" and isinstance(op.mod, MergedConv):
+                parts = base_convs(op.mod)
+                block = [m.conv.weight for m in parts] + [m.bn.weight for m in parts] + [m.bn.bias for m in parts]
+                for t in block:
+                    group_of[id(t)] = block
+        self.params, seen = [], set()
+        for p in model.parameters():
+            if not p.requires_grad or id(p) in seen:
+                continue
+            for t in group_of.get(id(p), (p,)):
+                assert t.requires_grad and id(t) not in seen
+                seen.add(id(t))
+                self.params.append(t)
         n = sum(p.numel() for p in self.params)
         self.arena = torch.zeros(n, dtype=torch.float32, device=device)
         self.gview = {}
@@ -327,7 +364,7 @@ class TrainPlan:
             o += p.numel()
         self._build_buckets()
         self.on_bucket = None                 # TrainStep: callable(k, main_stream, side_stream) -> starts the bucket's all-reduce
-        self.bn_mods = [op.mod.bn for op in convs]
+        self.bn_mods = [m.bn for op in convs for m in base_convs(op.mod)]
         self.stem_scratch = None
         # wgrad scratch of the prediction convs [reg 0-3 | obj 4] / [cls] (zero between uses: sy_pred_grad_fold clears it)
         self.pred_scratch = torch.zeros((2, max(8, self.nc), int(256 * head.width)), dtype=torch.float32, device=device) \
@@ -335,12 +372,35 @@ class TrainPlan:
         self.pred_ws = torch.empty(int(ops._lib.lib().sy_pred_grad_fold_workspace_floats(self.nc)), dtype=torch.float32,
                                    device=device) if head is not None else None
 
+    def _bind_scratch(self):
+        """Split-K workspace and raw-gradient ring: shared with the module's other plans (multi-scale training keeps several
+        plans alive; these two are pure scratch, 256 MB + RING x the largest raw gradient) or plan-owned without a pool."""
+        esz = torch.empty(0, dtype=self.tdtype).element_size()
+        ring_bytes = -(-self.max_raw * esz // 256) * 256
+        if self.pool is not None:
+            self.wgrad_ws = self.pool.shared_scratch("wgrad_ws", self.WGRAD_WS_BYTES, self.device)
+            flat = self.pool.shared_scratch("dyraw_ring", ring_bytes * self.RING, self.device)
+            self._scratch_gen = self.pool.scratch_gen
+        else:
+            self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device)
+            flat = torch.empty(ring_bytes * self.RING, dtype=torch.uint8, device=self.device)
+            self._scratch_gen = 0
+        self.dyraw_ring = [flat[i * ring_bytes:i * ring_bytes + self.max_raw * esz].view(self.tdtype) for i in range(self.RING)]
+
+    def release(self):
+        """Dropped from the plan cache (LRU): free the recorded tapes now (they hold raw pointers into buffers that go back to
+        the allocator with this object)."""
+        self.programs.clear()
+
     # ------------------------------------------------------------------------------------------------
     def forward(self, x):
         """x [B,6,H,W] float on device -> raw [B, A, 5+nc] fp32 (plan-owned).  parts == "backbone": returns the fused
         feature views instead; parts == "head": x = the three fused feature tensors."""
         if self.parts != "head":
             x = x.float().contiguous()
+        if self.pool is not None and self._scratch_gen != self.pool.scratch_gen:
+            self._bind_scratch()                                 # a larger plan re-allocated the shared scratch
+            self.programs.clear()
         sig = tuple(p.data_ptr() for p in self.params)
         if sig != self._param_sig or not self.cache.valid():     # a parameter was re-allocated (.to(), load with assign)
             self._param_sig = sig
@@ -363,7 +423,10 @@ class TrainPlan:
             mods = {}
             for op in self.ops:                                      # plan order == the reference's call order
                 if op.kind == "conv":
-                    mods.setdefault(id(op.mod.bn), (op.mod.bn, []))[1].append((op.stat[0], op.stat[1], op.y.pixels))
+                    c0, ctot, SC = 0, op.y.C, self.STAT_COPIES
+                    for m in base_convs(op.mod):                     # a stacked launch: each module's channel slice of the arrays
+                        mods.setdefault(id(m.bn), (m.bn, []))[1].append((op.stat[0][c0:], op.stat[1][c0:], op.y.pixels, SC, ctot))
+                        c0 += m.bn.num_features
             self.run_table = ops.BnRunningTable(list(mods.values()), self.device)
         self.run_table.run()
         # num_batches_tracked: +1 per BN call (shared backbone/neck/jian BNs are called twice — trap T2)
@@ -411,9 +474,26 @@ class TrainPlan:
         self._mark("main", None)
         self._mark("join")
 
+    # ---- parameters of a (possibly stacked) BaseConv op -------------------------------------------------------------------
+    def _bn_params(self, op):
+        """(gamma, beta, eps, momentum) of the op's BatchNorm; a MergedConv's are the stacked fp32 copies StagedWeights keeps."""
+        parts = base_convs(op.mod)
+        bn = parts[0].bn
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        if len(parts) == 1:
+            return bn.weight, bn.bias, bn.eps, mom
+        assert all(m.bn.eps == bn.eps and m.bn.momentum == bn.momentum for m in parts)
+        g, b_ = self.cache.bn[id(op.mod)]
+        return g, b_, bn.eps, mom
+
+    def _bn_grads(self, op):
+        """(dgamma, dbeta) arena views starting at the op's first part (the parts' slots are adjacent: see the arena order)."""
+        bn = base_convs(op.mod)[0].bn
+        return self.gview[id(bn.weight)], self.gview[id(bn.bias)]
+
     def _forward_pair(self, a):
         """BaseConv of the shared per-frame network on both frames: conv (+ per-frame statistics), finalize, BN+SiLU."""
-        bn = a.mod.bn
+        gamma, beta, eps, mom = self._bn_params(a)
         x2, raw2, y2 = a.x.pair(), a.yraw.pair(), a.y.pair()
         t = a._tiles.get("fwd_stats2")
         if t is None:
@@ -423,12 +503,11 @@ class TrainPlan:
         u_sum, u_sq, _, (scale, shift, mean, invstd) = a.unit
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
                    wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
-        mom = bn.momentum if bn.momentum is not None else 0.1
         if _FUSED_FINALIZE:
-            ops.bn_finalize_apply(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, scale, shift, mean, invstd, raw2, y2,
+            ops.bn_finalize_apply(u_sum, u_sq, a.y.pixels, gamma, beta, eps, scale, shift, mean, invstd, raw2, y2,
                                   res=None if a.res is None else a.res.pair(), nseg=2)
         else:
-            ops.bn_finalize(u_sum, u_sq, a.y.pixels, bn.weight, bn.bias, bn.eps, mom, None, None, scale, shift, mean, invstd,
+            ops.bn_finalize(u_sum, u_sq, a.y.pixels, gamma, beta, eps, mom, None, None, scale, shift, mean, invstd,
                             nseg=2)
             ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
 
@@ -493,20 +572,19 @@ class TrainPlan:
         nch = 5 + self.nc
         k = op.kind
         if k == "conv":
-            bn = op.mod.bn
+            gamma, beta, eps, mom = self._bn_params(op)
             w = self.cache.conv_weight(op.mod)
             t = op.tile("fwd_stats")
             ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
             scale, shift, mean, invstd = op.aff
-            mom = bn.momentum if bn.momentum is not None else 0.1
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
             if _FUSED_FINALIZE:
-                ops.bn_finalize_apply(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, scale, shift, mean, invstd,
+                ops.bn_finalize_apply(op.stat[0], op.stat[1], op.y.pixels, gamma, beta, eps, scale, shift, mean, invstd,
                                       op.yraw, op.y, res=op.res)
             else:
-                ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, bn.weight, bn.bias, bn.eps, mom,
+                ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, gamma, beta, eps, mom,
                                 None, None, scale, shift, mean, invstd)
                 ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
         elif k == "resize":
@@ -549,7 +627,9 @@ class TrainPlan:
             self.dpad[..., 8:8 + nc] = d_raw[..., 5:]
         self._seed = d_fused
         self._run("bwd", lambda: self._backward_ops(d_raw), key=None if d_raw is None else d_raw.data_ptr())
-        self.tuned = True                                            # kernels are tuned after the first full step
+        if not self.tuned:
+            self.tuned = True                                        # kernels are tuned after the first full step
+            ops.save_tuned()                                         # ... and the choices persisted (next plan / process)
         return self.arena
 
     def fused_grads(self):
@@ -570,7 +650,7 @@ class TrainPlan:
         last = {}
         for pos, op in enumerate(self._backward_sequence()):
             if op.kind == "conv":
-                prm = (op.mod.conv.weight, op.mod.bn.weight, op.mod.bn.bias)
+                prm = tuple(t for m in base_convs(op.mod) for t in (m.conv.weight, m.bn.weight, m.bn.bias))
             elif op.kind == "pred":
                 prm = tuple(t for m in (op.reg_mod, op.obj_mod, op.cls_mod) for t in (m.weight, m.bias))
             else:
@@ -672,16 +752,17 @@ class TrainPlan:
         """Residual fan-in + BatchNorm/SiLU backward of one BaseConv call: fills `dyraw` (grad of the raw conv
         output) and accumulates dgamma / dbeta."""
         G = self.grads
-        bn = op.mod.bn
+        gamma = self._bn_params(op)[0]
+        dgamma, dbeta = self._bn_grads(op)
         dY = G.view(op.y)
         dres, acc = (None, False) if op.res is None else G.target(op.res)    # y = silu(bn(conv)) + res: dres (+)= dY
         scale, shift, mean, invstd = op.aff
         ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
-        ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, bn.weight, op.bsum, dyraw,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], dres=dres, dres_accumulate=acc)
+        ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, gamma, op.bsum, dyraw,
+                              dgamma, dbeta, dres=dres, dres_accumulate=acc)
 
     def _wgrad(self, op, x, dyraw):
-        w = op.mod.conv.weight
+        w = base_convs(op.mod)[0].conv.weight                        # stacked parts: their arena slots follow this one
         key = "wgrad%d" % x.N
         wt = op._tiles.get(key)
         if wt is None:
@@ -714,7 +795,8 @@ class TrainPlan:
         full = self._scratch(2 * N * H * W * C).view(2 * N, H, W, C)
         slot = self._slot
         dy2 = View(full, 2 * N, H, W, C)
-        bn = a.mod.bn
+        gamma = self._bn_params(a)[0]
+        dgamma, dbeta = self._bn_grads(a)
         dYa, dYb = G.view(a.y), G.view(b2.y)
         assert dYa.root[0] is dYb.root[0]
         dY2 = dYa.pair()
@@ -727,8 +809,8 @@ class TrainPlan:
         _, _, u_bsum, (scale, shift, mean, invstd) = a.unit
         raw2 = a.yraw.pair()
         ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
-        ops.bn_silu_bwd_apply(raw2, dY2, scale, shift, mean, invstd, bn.weight, u_bsum, dy2,
-                              self.gview[id(bn.weight)], self.gview[id(bn.bias)], nseg=2, dres=dres2, dres_accumulate=acca)
+        ops.bn_silu_bwd_apply(raw2, dY2, scale, shift, mean, invstd, gamma, u_bsum, dy2,
+                              dgamma, dbeta, nseg=2, dres=dres2, dres_accumulate=acca)
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot)
         if a.need_dx:
             dxa, acca = G.target(a.x)
@@ -820,11 +902,7 @@ def get_train_plan(model, x):
     dt = compute_dtype_for(model, x)
     B, _, H, W = x.shape
     key = ("train", B, H, W, dt, str(x.device))
-    plan = model._plans.plans.get(key)
-    if plan is None:
-        plan = TrainPlan(model, B, H, W, dt, x.device)
-        model._plans.plans[key] = plan
-    return plan
+    return model._plans.get(key, lambda: TrainPlan(model, B, H, W, dt, x.device, pool=model._plans))
 
 
 class _PlanFunction(torch.autograd.Function):
@@ -910,9 +988,7 @@ def backbone_train_forward(pafpn, x):
     dt = compute_dtype_for(pafpn, x)
     B, _, H, W = x.shape
     key = ("train-backbone", B, H, W, dt, str(x.device))
-    plan = pafpn._plans.plans.get(key)
-    if plan is None:
-        plan = pafpn._plans.plans[key] = TrainPlan(pafpn, B, H, W, dt, x.device, parts="backbone")
+    plan = pafpn._plans.get(key, lambda: TrainPlan(pafpn, B, H, W, dt, x.device, parts="backbone", pool=pafpn._plans))
     return _BackboneFunction.apply(plan, x, *plan.params)
 
 
@@ -923,9 +999,8 @@ def head_train_forward(head, xin, labels):
     dt = compute_dtype_for(head, x0)
     shapes = tuple((int(t.shape[1]), int(t.shape[2]), int(t.shape[3])) for t in xin)
     key = ("train-head", int(x0.shape[0]), shapes, dt, str(x0.device))
-    plan = head._plans.plans.get(key)
-    if plan is None:
-        plan = head._plans.plans[key] = TrainPlan(head, int(x0.shape[0]), 0, 0, dt, x0.device, parts="head", feat_shapes=shapes)
+    plan = head._plans.get(key, lambda: TrainPlan(head, int(x0.shape[0]), 0, 0, dt, x0.device, parts="head", feat_shapes=shapes,
+                                                  pool=head._plans))
     lab, sup = split_targets_head(head, labels)
     total, stats = _HeadFunction.apply(plan, lab, sup, xin[0], xin[1], xin[2], *plan.params)
     return total, stats[0], stats[2], stats[3], stats[1], stats[4]

@@ -198,3 +198,25 @@ def test_general_ratio_letterbox_matches_the_oracle_bit_exact(backend, hs, ws, c
     want = IO.pair_tensor(cur.numpy(), sup.numpy(), canvas, decimate=0, mirror=mirror.numpy())
     got = FramePairsU8(cur.to(backend), sup.to(backend), canvas, decimate=0, mirror=mirror.to(backend)).to_nchw()
     assert got.shape == want.shape and torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("hs,ws,canvas", [(45, 80, (30, 52)), (40, 64, (52, 84)), (61, 97, (20, 32)), (64, 96, (32, 48))])
+def test_streaming_per_axis_stretch_matches_the_oracle_bit_exact(backend, hs, ws, canvas):
+    """decimate=-1: the streaming detector's cv2.resize(img, (w_img, h_img)) — each axis stretched on its own to
+    exactly the canvas, no letterbox (sAP/streamyolo/streamyolo_det.py:176-178) — shrinking, enlarging (the vertical border
+    rows keep their fraction: OpenCV clamps only the row indices there) and the exact-2x shortcut."""
+    g = torch.Generator().manual_seed(hs * 17 + ws)
+    cur = torch.randint(0, 256, (2, hs, ws, 3), generator=g, dtype=torch.uint8)
+    want = np.stack([IO.preproc(IO.cv2_resize_linear_u8(f, (canvas[1], canvas[0])), canvas) for f in cur.numpy()])
+    got = FramePairsU8(cur.to(backend), None, canvas, decimate=-1).to_nchw()
+    assert tuple(got.shape) == want.shape and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_vertical_border_rows_keep_their_fraction():
+    """OpenCV's vertical pass clamps the two ROW INDICES at the top / bottom border but keeps the fraction (horizontally it zeroes
+    the fraction): when enlarging, border rows go through two separate `>> 16` floors with b0 + b1 = 2048 and may land 1 LSB
+    below the source value, never above; interior behaviour is unchanged (constant images stay within 1 LSB)."""
+    img = np.full((5, 7, 3), 201, dtype=np.uint8)
+    out = IO.cv2_resize_linear_u8(img, (21, 15)).astype(np.int32)
+    assert out.max() <= 201 and out.min() >= 200
+    assert np.all(out[2:-2] == 201)                                  # rows whose two taps are distinct rows: exact

@@ -1,0 +1,98 @@
+"""Multi-scale training as the reference trainer drives it: a new (H, W) every 10 iterations
+(cfgs/l_s50_onex_dfp_tal_flip.py:139-158 `random_resize`, exps/train_utils/double_trainer.py:276-279).  The plan cache must
+stay bounded (LRU), plans of different sizes share their scratch, steps after a size switch reproduce the oracle, and memory
+stays flat once every size has been seen."""
+import numpy as np
+import pytest
+import torch
+
+import streamyolo_amd as sy
+from oracle import streamyolo_oracle as O
+from streamyolo_amd.model.plan_cache import PlanCache
+from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
+
+SIZES = [(64, 96), (96, 128), (64, 128), (96, 160)]
+
+
+def _oracle_loss(cfg, sd, x, lab, sup):
+    osd = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        return float(O.forward_train(osd, x, lab, sup, cfg)["total_loss"])
+
+
+def test_size_switches_reproduce_the_oracle_with_a_bounded_plan_cache(backend, monkeypatch):
+    monkeypatch.setattr(PlanCache, "MAX_TRAIN_PLANS", 2)
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    model = sy.build_model("nano")
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model = model.to(backend).train().set_compute_dtype("fp32")
+    model.head.use_l1 = True
+    want = {}
+    seen_scratch = set()
+    for rnd in range(2):
+        for i, (H, W) in enumerate(SIZES):
+            x = synth_frames(2, H, W, seed=40 + i)
+            lab, sup = synth_labels(2, H, W, cfg.num_classes, num_gt=5, seed=50 + i)
+            if (H, W) not in want:
+                want[(H, W)] = _oracle_loss(cfg, sd, x, lab, sup)
+            model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)      # same state for every step
+            for p in model.parameters():
+                p.grad = None
+            steps = 3 if rnd == 1 and i == 0 else 1                 # one size also runs into its launch-tape replay
+            for _ in range(steps):
+                model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+                out = model(x.to(backend), (lab.to(backend), sup.to(backend)))
+                out["total_loss"].backward()
+                got = float(out["total_loss"])
+                assert abs(got - want[(H, W)]) / abs(want[(H, W)]) < 1e-3, (rnd, H, W, got, want[(H, W)])
+            train_plans = [k for k in model._plans.plans if str(k[0]).startswith("train")]
+            assert len(train_plans) <= 2
+            assert train_plans[-1][2:4] == (H, W)                   # most recently used last
+            seen_scratch.add(model._plans.scratch["wgrad_ws"].data_ptr())
+    assert len(seen_scratch) == 1                                   # ONE split-K workspace for every size
+
+
+@pytest.mark.gpu
+def test_multiscale_memory_stays_flat_and_later_plans_build_from_the_tuner_cache(tmp_path, monkeypatch):
+    """GPU: cycle through five sizes twice with at most three training plans alive: allocated memory after the second cycle
+    is not above the first cycle's peak, every step matches the oracle loss (bf16 bound), and a plan rebuilt for a size seen
+    before (its tuner choices are persisted) is ready much faster than the first build."""
+    import time
+    from streamyolo_amd import _lib, ops
+    _lib.use_library(_lib.DEFAULT_PATH)
+    monkeypatch.setenv("STREAMYOLO_TUNE_CACHE", str(tmp_path / "tune.json"))
+    ops._tune_store.__init__()
+    dev = torch.device("cuda:0")
+    cfg = O.OracleConfig.named("s")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    model = sy.build_model("s")
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model = model.to(dev).train().set_compute_dtype("bf16")
+    model.head.use_l1 = True
+    sizes = [(416, 672), (480, 768), (544, 864), (608, 960), (448, 704)]     # multiples of 32, as random_resize draws them
+    peak, build_s = [], {}
+    for rnd in range(2):
+        for i, (H, W) in enumerate(sizes):
+            x = synth_frames(2, H, W, seed=60 + i)
+            lab, sup = synth_labels(2, H, W, cfg.num_classes, num_gt=8, seed=70 + i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = model(x.to(dev), (lab.to(dev), sup.to(dev)))
+            out["total_loss"].backward()
+            torch.cuda.synchronize()
+            build_s.setdefault((H, W), []).append(time.perf_counter() - t0)
+            if rnd == 0:
+                want = _oracle_loss(cfg, sd, x, lab, sup)
+                assert abs(float(out["total_loss"]) - want) / abs(want) < 5e-2, (H, W)
+            model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+            assert len([k for k in model._plans.plans if str(k[0]).startswith("train")]) <= PlanCache.MAX_TRAIN_PLANS
+        del out
+        torch.cuda.synchronize()
+        peak.append(torch.cuda.memory_allocated())
+    print("allocated after cycle 1 / 2: %.1f / %.1f MB" % (peak[0] / 2**20, peak[1] / 2**20))
+    print("first build vs rebuild (s):", {k: [round(t, 2) for t in v] for k, v in build_s.items()})
+    assert peak[1] <= peak[0] * 1.02 + (8 << 20)
+    # sizes[0] and sizes[1] were evicted during cycle 1 and rebuilt in cycle 2 from the persisted tuner choices
+    assert build_s[sizes[0]][1] < 0.5 * build_s[sizes[0]][0]
+    assert (tmp_path / "tune.json").exists()

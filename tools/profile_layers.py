@@ -18,14 +18,21 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--mode", default="off_pipe", choices=["off_pipe", "on_pipe"],
+                    help="on_pipe: the streaming plan (one frame per step; BASELINE.json configs[4] with --batch 1 --dtype fp16)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = sy.build_model(a.model).to(dev).eval().set_compute_dtype(a.dtype)
     x = synth_frames(a.batch, 600, 960).to(dev)
-    plan = model._plans.inference(model.backbone, model.head, "off_pipe", x, owner=model)
+    if a.mode == "on_pipe":
+        x = x[:, 0:3].contiguous()
+    plan = model._plans.inference(model.backbone, model.head, a.mode, x, owner=model)
     with torch.no_grad():
         for _ in range(2):
-            plan.run(x)
+            if a.mode == "on_pipe":
+                plan.run_stream(x, first=True)
+            else:
+                plan.run(x)
     rows = {}
     for it in range(a.iters):
         for i, op in enumerate(plan.ops):
@@ -41,7 +48,7 @@ def main():
         ms = sorted(s.elapsed_time(e) for s, e in rows[i])[len(rows[i]) // 2]
         if op.kind == "conv":
             fl = 2.0 * op.x.C * op.y.C * op.k * op.k * op.y.pixels
-            shape = "N%d %dx%d %d->%d k%d s%d" % (op.x.N, op.y.H, op.y.W, op.x.C, op.y.C, op.k, op.stride)
+            shape = "N%d %dx%d %d->%d k%d s%d t%s" % (op.x.N, op.y.H, op.y.W, op.x.C, op.y.C, op.k, op.stride, op._tiles.get("fwd"))
             tag = op.tag
         else:
             fl, shape, tag = 0.0, "", op.kind
