@@ -14,6 +14,12 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    # no single test may eat the GPU box's budget: a hang becomes a failure after 5 minutes (pytest-timeout); the SIMT-emulator
+    # runs of the CPU suite are slower by nature
+    limit = 300 if torch.cuda.is_available() else 1200
+    for it in items:
+        if it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(limit))
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

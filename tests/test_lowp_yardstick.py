@@ -125,7 +125,6 @@ def test_headline_batch_l_8x600x960_exact_mode_vs_oracle():
     from streamyolo_amd import _lib
     _lib.use_library(_lib.DEFAULT_PATH)
     dev = torch.device("cuda:0")
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
     cfg, sd, x, lab, sup, ref, rgrads = _oracle_grads("l", 8, 600, 960, 16)
     want = np.array([float(ref[k]) for k in NAMES])
     model = sy.build_model("l")
@@ -182,7 +181,10 @@ def test_30_sgd_steps_bf16_tracks_fp32():
     from streamyolo_amd import _lib
     _lib.use_library(_lib.DEFAULT_PATH)
     dev = torch.device("cuda:0")
-    lr = float(os.environ.get("STREAMYOLO_TEST_LR", "1.25e-4"))          # basic_lr_per_img 0.001 / 64 x batch 8 (cfgs/l_*.py)
+    # basic_lr_per_img 0.001 / 64 x batch 8 (cfgs/l_*.py).  Measured (tools/sgd_curves.py, profiles/r03/b_sgd_curves.txt): two fp32
+    # runs of this loop differ by up to 1.6 % from each other (SimOTA re-assignments amplify run-to-run atomics noise), bf16
+    # stays within 1.6 % of fp32; at lr 1e-3: 3.1 % / 2.5 %; at lr 1e-5: 1.5 % / 2.0 %.
+    lr = float(os.environ.get("STREAMYOLO_TEST_LR", "1.25e-4"))
     steps = 30
     c32 = _run_curve("l", 8, 600, 960, "fp32", steps, lr, dev)
     torch.cuda.empty_cache()

@@ -27,7 +27,7 @@ for task in "$@"; do
     IFS=: read -r kind a b c <<< "$task"
     t0=$(date +%s)
     case $kind in
-        tests) (timeout 1500 python -m pytest tests -m gpu -q ${a//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
+        tests) (timeout 900 python -m pytest tests -m gpu -q --durations=12 ${a//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
                grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
         smoke) (timeout 600 python __graft_entry__.py smoke 2>&1 | grep -vE "$noise" | tail -2) > $O/smoke.log 2>&1; cat $O/smoke.log ;;
         bench) (timeout 900 python bench.py ${b//,/ } 2>$O/bench_$a.err | tail -1) > $O/bench_$a.json
