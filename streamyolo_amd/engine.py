@@ -90,6 +90,9 @@ class FocusOp:
 # ------------------------------------------------------------------------------------------------
 # network builders
 # ------------------------------------------------------------------------------------------------
+TWO_STREAM_HEAD = os.environ.get("STREAMYOLO_STREAM_HEAD_FORK", "1") != "0"
+
+
 class MergedConv:
     """Two BaseConvs that read the SAME input (CSPLayer conv2 / conv1, the first cls / reg tower conv of a head level) as ONE
     launch with their output channels stacked: one read of the input, twice the GEMM N on the narrowest layers, one launch
@@ -336,6 +339,7 @@ class InferencePlan:
         self.decode = decode
         self.cache = ParamCache(self.dtype, device)
         self._stream_tape, self._tape_param_list = None, None
+        self._rec, self._side = None, None           # open native tape (run_stream_taped) / its side stream
         b = _Builder(self.dtype, device)
         b.merge_siblings = os.environ.get("STREAMYOLO_MERGE_SIBLINGS", "1") != "0"
         self.b = b
@@ -367,6 +371,14 @@ class InferencePlan:
             self.nc = head.num_classes
             self.out = torch.empty((B, self.A, 5 + self.nc), dtype=torch.float32, device=device)
         self.ops = b.ops
+        lvl = 0
+        for op in self.ops[self.n_backbone_ops:]:                 # head ops: per-level towers end with their PredOp
+            op.level = lvl
+            lvl += 1 if op.kind == "pred" else 0
+
+    def _mark(self, kind, arg=None):
+        if self._rec is not None:
+            self._rec.mark(kind, arg)
 
     # -- execution --------------------------------------------------------------------------------
     def _run_op(self, op):
@@ -486,15 +498,27 @@ class InferencePlan:
             raise ValueError("run_stream_taped needs a FramePairsU8 or a contiguous fp32 frame (no conversion kernels on the tape)")
         sig = self._tape_signature(x, check_params)
         prog = self._stream_tape
+        from . import _lib
         if prog is None or prog[0] != sig or prog[1] is not post:
-            from . import _lib
-            with _lib.record() as tape:
-                out = self.run_stream(x)
-                res = post(out) if post is not None else out
+            # native tape (csrc/tape.hip): the launches are recorded inside the library and replayed by ONE C call; the head's
+            # levels fan out over two streams there (level 0 beside levels 1-2), which a hipGraph capture of this plan cannot
+            # do on this ROCm build
+            tape = _lib.NativeTape()
+            with tape:
+                self._rec = tape
+                try:
+                    out = self.run_stream(x)
+                    res = post(out) if post is not None else out
+                finally:
+                    self._rec = None
             self._stream_tape = (sig, post, tape, res)
             return res
-        from . import _lib
-        _lib.replay(prog[2], ops.stream_of(self.out))
+        main_h, side_h = ops.stream_of(self.out), None
+        if self.out.is_cuda and TWO_STREAM_HEAD:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side_h = ops.C.c_void_p(self._side.cuda_stream)
+        prog[2].replay(main_h, side_h)
         return prog[3]
 
     def export_buffer(self):
@@ -503,8 +527,17 @@ class InferencePlan:
         return tuple(p.buf.clone().permute(0, 3, 1, 2) for p in self.cur_pans)
 
     def run_head(self):
-        for op in self.ops[self.n_backbone_ops:]:
-            self._run_op(op)
+        head = self.ops[self.n_backbone_ops:]
+        self._mark("fork")                                        # (tape marks: no-ops outside run_stream_taped's recording)
+        for op in head:
+            if op.level == 0:
+                self._run_op(op)
+        self._mark("side_nw")                                     # levels 1-2 beside level 0 on the side stream
+        for op in head:
+            if op.level != 0:
+                self._run_op(op)
+        self._mark("main")
+        self._mark("join")
         if not self.decode:
             # decode_in_inference=False (tal_head.py:220-223): boxes stay raw, obj/cls are still sigmoids
             self.out[..., 4].sigmoid_()
