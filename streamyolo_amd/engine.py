@@ -90,7 +90,9 @@ class FocusOp:
 # ------------------------------------------------------------------------------------------------
 # network builders
 # ------------------------------------------------------------------------------------------------
-TWO_STREAM_HEAD = os.environ.get("STREAMYOLO_STREAM_HEAD_FORK", "1") != "0"
+# streaming launch tape: head level 0 beside levels 1-2 on a second stream.  Measured on MI355X (profiles/r03/c_*): 1.883 vs
+# 1.849 ms per frame on one stream — at batch 1 the frame is bound by dispatch, not by idle CUs; off by default.
+TWO_STREAM_HEAD = os.environ.get("STREAMYOLO_STREAM_HEAD_FORK", "0") != "0"
 
 
 class MergedConv:

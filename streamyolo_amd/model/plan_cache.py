@@ -59,11 +59,16 @@ class PlanCache:
         kind = "train" if str(key[0]).startswith("train") else "inf"
         bound = self.MAX_TRAIN_PLANS if kind == "train" else self.MAX_INFER_PLANS
         same = [k for k in self.plans if ("train" if str(k[0]).startswith("train") else "inf") == kind]
-        for k in same[:max(0, len(same) - bound)]:
+        evicted = same[:max(0, len(same) - bound)]
+        for k in evicted:
             old = self.plans.pop(k)
             release = getattr(old, "release", None)
             if release is not None:
                 release()
+            del old
+        if evicted:
+            import gc
+            gc.collect()                      # plans are webs of closures / views: return their buffers to the allocator now
         return plan
 
     def shared_scratch(self, name, nbytes, device):

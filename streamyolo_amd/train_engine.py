@@ -388,9 +388,13 @@ class TrainPlan:
         self.dyraw_ring = [flat[i * ring_bytes:i * ring_bytes + self.max_raw * esz].view(self.tdtype) for i in range(self.RING)]
 
     def release(self):
-        """Dropped from the plan cache (LRU): free the recorded tapes now (they hold raw pointers into buffers that go back to
-        the allocator with this object)."""
+        """Dropped from the plan cache (LRU): free the recorded tapes (they hold raw pointers into buffers that go back to the
+        allocator with this object) and break the plan <-> gradient-space reference cycle so that the buffers are freed NOW,
+        not at some later cyclic-GC pass (measured: without this, cycling through five sizes doubled the allocated memory)."""
         self.programs.clear()
+        self.grads.py = None
+        self.grads.mirror.clear()
+        self.on_bucket = None
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, x):
