@@ -86,6 +86,14 @@ typedef struct sy_conv_desc {
     int64_t x_bytes, w_bytes;           /* bytes addressable from x / w (buffer bounds of the fast gather; 0 = unknown) */
     const void* wfrag;                  /* optional: weights re-packed in MFMA-fragment order (SY_TILE_WR variants) */
     int64_t wfrag_bytes;
+    /* optional INPUT transform x' = silu(in_scale[c] * x + in_shift[c]) applied to the operand tile after it has landed in LDS
+       (tiles 117 / 118 only): the producer's BatchNorm + SiLU normalisation done by the CONSUMER, so the producer's raw output
+       is this launch's operand and its bn_silu_apply pass (nn.BatchNorm2d + nn.SiLU of the producing BaseConv) is not needed.
+       Arrays [in_segments][Cin] fp32, segment of image n = n / (N / in_segments); NULL = no transform.  Padding stays zero. */
+    const float* in_scale;
+    const float* in_shift;
+    int32_t in_segments;
+    int32_t reserved;
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.

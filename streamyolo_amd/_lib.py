@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("xbs", C.c_int64), ("ybs", C.c_int64), ("rbs", C.c_int64),
         ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
         ("accumulate", C.c_int32), ("dec_stride", C.c_float), ("stat_copies", C.c_int32), ("stat_segments", C.c_int32), ("tile", C.c_int32), ("x_bytes", C.c_int64), ("w_bytes", C.c_int64), ("wfrag", C.c_void_p), ("wfrag_bytes", C.c_int64),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_segments", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

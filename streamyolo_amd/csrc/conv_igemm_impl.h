@@ -59,6 +59,9 @@ struct ConvArgs {
     unsigned x_extent, w_extent; // bytes addressable from x / w (FAST loader's buffer bounds)
     const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
     unsigned wfrag_extent;
+    const float* in_scale;      // optional input normalisation (conv3x3_halo2_kernel NORM): [segments][Cin]
+    const float* in_shift;
+    int in_seg_N;               // images per normalisation segment (0: no input transform)
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads, 8 = no statistics atomics, 16 = no cross-lane statistics reduction
 };
 

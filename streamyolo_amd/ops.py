@@ -118,7 +118,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None, segments=1):
+           cout=None, tile=0, wfrag=None, segments=1, in_affine=None, in_segments=1):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -151,6 +151,8 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.w_bytes = w.numel() * w.element_size()
     if wfrag is not None:
         d.wfrag, d.wfrag_bytes = wfrag.data_ptr(), wfrag.numel() * wfrag.element_size()
+    if in_affine is not None:           # x is the producer's RAW output: normalise it in LDS (tiles 117 / 118), see the header
+        d.in_scale, d.in_shift, d.in_segments = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_segments)
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
