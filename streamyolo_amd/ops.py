@@ -524,13 +524,15 @@ def _time_launches(run, device, launches=4, rounds=2):
     return best
 
 
-def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False):
+def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False, only=None):
     """Fastest sy_conv2d variant for this problem shape (H, W = INPUT size of the launch), or 0 (the
-    library's static heuristic) when tuning is off.  Measured with HIP events on dummy tensors."""
+    library's static heuristic) when tuning is off.  Measured with HIP events on dummy tensors.
+    only: restrict the choice to these tile codes (launches that need a particular kernel family)."""
     if not autotune_enabled(device):
-        return 0
+        return 0 if only is None else only[-1]
     _tune_store.load(device)
-    key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats), str(device))
+    key = (mode, dtype_code(dtype), N, H, W, Cin, Cout, k, stride, bool(with_stats)) + \
+        (() if only is None else (",".join(str(t) for t in only),)) + (str(device),)
     hit = _tile_cache.get(key)
     if hit is not None:
         return hit
@@ -560,7 +562,9 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     if k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256, 512, 1024, 2048) and code != DT_F32:
         # whole-K burst kernel (csrc/conv1x1_tile.h): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px (Cin <= 256)
         cands += [t for t in TILE_1X1K if not (t == 122 and Cout > 64) and not (t == 123 and Cin > 256) and not (t != 121 and Cin > 512)]
-    best, best_t = 0, float("inf")
+    if only is not None:
+        cands = list(only)
+    best, best_t = (0 if only is None else only[-1]), float("inf")
     for t in cands:
         if t >= TILE_WR and wf is None:
             continue

@@ -213,6 +213,7 @@ class StagedWeights:
 
 CSP_FORK = os.environ.get("STREAMYOLO_CSP_FORK", "1") != "0"
 MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
+NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "1") != "0"
 
 
 def _csp_role(tag):
@@ -331,11 +332,13 @@ class TrainPlan:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
         self.cache = StagedWeights(self.ops, self.dtype, device)
+        self._find_norm_consumers()
         self.loss_ws = None
         self.run_table = None
         self.grads = _GradSpace()
         self.grads.py = self._py
         self.programs, self._rec, self._param_sig = {}, None, None
+        self._side_region = False
 
         # ---- flat gradient arena in parameter layout ------------------------------------------------
         # Parameter order of the arena = model.parameters() order, except that the parts of a merged convolution sit side by
@@ -371,6 +374,49 @@ class TrainPlan:
             if head is not None else None
         self.pred_ws = torch.empty(int(ops._lib.lib().sy_pred_grad_fold_workspace_floats(self.nc)), dtype=torch.float32,
                                    device=device) if head is not None else None
+
+    # ---- producer BatchNorm.SiLU applied by the 3x3 consumer in LDS ------------------------------------------------------------
+    # A BaseConv whose activated output is read ONLY by 3x3 stride-1 convolutions (Bottleneck conv1 -> conv2, head stem ->
+    # first tower convs -> second tower convs) does not need that output in the forward pass: the consumer's halo kernel
+    # normalises the producer's RAW output tile in LDS (sy_conv_desc in_scale / in_shift; measured free, profiles/r03/d_*:
+    # 56.8 vs 56.3 us with / without on 75x120 128->128).  The producer's bn_silu_apply still runs — the backward pass reads
+    # the activated tensor (weight gradient of the consumer) — but on the SIDE stream, off the forward critical path.
+    def _find_norm_consumers(self):
+        for op in self.ops:
+            op.norm_src, op.defer_apply = None, False
+        if not NORM_IN_CONSUMER:
+            return
+
+        def key(v):
+            return (id(v.root[0]), v.root[1]) if v.root is not None else id(v.buf)
+        readers = {}
+        for op in self.ops:
+            if op.kind == "conv":
+                readers.setdefault(key(op.x), []).append((op.x, op, "x"))
+                if op.res is not None:
+                    readers.setdefault(key(op.res), []).append((op.res, op, "res"))
+            elif op.kind == "pred":
+                for v in (op.reg_x, op.cls_x):
+                    readers.setdefault(key(v), []).append((v, op, "pred"))
+            elif op.kind == "resize":
+                readers.setdefault(key(op.src), []).append((op.src, op, "resize"))
+            elif op.kind == "spp":
+                readers.setdefault(key(op.v), []).append((op.v, op, "spp"))
+        fused_keys = {key(f) for f in self.fused} if self.parts == "backbone" else set()
+        epc = 16 // torch.empty(0, dtype=self.tdtype).element_size()
+        for p_ in self.ops:
+            if p_.kind != "conv" or p_.res is not None or key(p_.y) in fused_keys:
+                continue
+            lo, hi = p_.y.c_off, p_.y.c_off + p_.y.C
+            rd = [(v, op, how) for v, op, how in readers.get(key(p_.y), []) if v.c_off < hi and v.c_off + v.C > lo]
+            ok = bool(rd) and all(how == "x" and op.kind == "conv" and op.k == 3 and op.stride == 1
+                                  and lo <= v.c_off and v.c_off + v.C <= hi and v.C % (4 * epc) == 0
+                                  and (v.N, v.H, v.W) == (p_.y.N, p_.y.H, p_.y.W) for v, op, how in rd)
+            if not ok:
+                continue
+            p_.defer_apply = True
+            for v, op, _ in rd:
+                op.norm_src = (p_, v.c_off - lo)          # producer, first channel of the consumer's slice inside it
 
     def _bind_scratch(self):
         """Split-K workspace and raw-gradient ring: shared with the module's other plans (multi-scale training keeps several
@@ -472,9 +518,11 @@ class TrainPlan:
             if op.level == 0:
                 self._forward_op(op)
         self._mark("side_nw")
+        self._side_region = True                                 # levels 1-2 already run on the side stream
         for op in self.ops[self.n_head_start:]:
             if op.level != 0:
                 self._forward_op(op)
+        self._side_region = False
         self._mark("main", None)
         self._mark("join")
 
@@ -499,21 +547,42 @@ class TrainPlan:
         """BaseConv of the shared per-frame network on both frames: conv (+ per-frame statistics), finalize, BN+SiLU."""
         gamma, beta, eps, mom = self._bn_params(a)
         x2, raw2, y2 = a.x.pair(), a.yraw.pair(), a.y.pair()
-        t = a._tiles.get("fwd_stats2")
-        if t is None:
-            t = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride, self.device,
-                               with_stats=True)
-            a._tiles["fwd_stats2"] = t
         u_sum, u_sq, _, (scale, shift, mean, invstd) = a.unit
+        in_aff = None
+        if a.norm_src is not None:                              # operand = the producer's RAW output, normalised in LDS
+            prod, c0 = a.norm_src
+            assert c0 == 0 and a.x.C == prod.y.C and not _FUSED_FINALIZE
+            x2, in_aff = prod.yraw.pair(), (prod.unit[3][0], prod.unit[3][1])
+            t = a._tiles.get("fwd_stats2n")
+            if t is None:
+                t = a._tiles["fwd_stats2n"] = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride,
+                                                             self.device, with_stats=True, only=(117, 118))
+        else:
+            t = a._tiles.get("fwd_stats2")
+            if t is None:
+                t = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride, self.device,
+                                   with_stats=True)
+                a._tiles["fwd_stats2"] = t
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
-                   wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
+                   wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2,
+                   in_affine=in_aff, in_segments=2)
         if _FUSED_FINALIZE:
             ops.bn_finalize_apply(u_sum, u_sq, a.y.pixels, gamma, beta, eps, scale, shift, mean, invstd, raw2, y2,
                                   res=None if a.res is None else a.res.pair(), nseg=2)
         else:
             ops.bn_finalize(u_sum, u_sq, a.y.pixels, gamma, beta, eps, mom, None, None, scale, shift, mean, invstd,
                             nseg=2)
-            ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
+            self._apply(a, lambda: ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2))
+
+    def _apply(self, op, launch):
+        """The BatchNorm.SiLU apply pass of `op`: inline, or — when every reader of the activated output normalises the raw
+        output itself (op.defer_apply) — on the side stream: only the backward pass needs the result."""
+        if op.defer_apply and not self._side_region and not _FUSED_FINALIZE:
+            self._mark("side")
+            launch()
+            self._mark("main", None)
+        else:
+            launch()
 
     # ---- launch programs ------------------------------------------------------------------------------------
     # Step 1 runs the Python wrappers directly (kernel variants get tuned).  Step 2 runs them again under
@@ -578,9 +647,20 @@ class TrainPlan:
         if k == "conv":
             gamma, beta, eps, mom = self._bn_params(op)
             w = self.cache.conv_weight(op.mod)
-            t = op.tile("fwd_stats")
-            ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
-                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
+            x, in_aff = op.x, None
+            if op.norm_src is not None:                         # operand = (a channel slice of) the producer's RAW output
+                prod, c0 = op.norm_src
+                assert not _FUSED_FINALIZE
+                x = prod.yraw.slice(c0, op.x.C)
+                in_aff = (prod.aff[0][c0:c0 + op.x.C], prod.aff[1][c0:c0 + op.x.C])
+                t = op._tiles.get("fwd_statsn")
+                if t is None:
+                    t = op._tiles["fwd_statsn"] = ops.tuned_tile(ops.CONV_FWD, x.dtype, x.N, x.H, x.W, x.C, op.y.C, op.k, op.stride,
+                                                                 self.device, with_stats=True, only=(117, 118))
+            else:
+                t = op.tile("fwd_stats")
+            ops.conv2d(x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
+                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None, in_affine=in_aff)
             scale, shift, mean, invstd = op.aff
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
@@ -590,7 +670,7 @@ class TrainPlan:
             else:
                 ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, gamma, beta, eps, mom,
                                 None, None, scale, shift, mean, invstd)
-                ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
+                self._apply(op, lambda: ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res))
         elif k == "resize":
             ops.resize_nearest(op.src, op.dst)
         elif k == "spp":
