@@ -290,20 +290,28 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
         }
     }
 
-    // NORM: the input affine [Cin] x {scale, shift} of this image's segment behind the two halo buffers
-    float* const aff = reinterpret_cast<float*>(smem + 2 * BUF);
-    if constexpr (NORM) {
-        const int seg = n / p.in_seg_N;
-        for (int c = tid; c < p.Cin; c += NW * 64) {
-            aff[c] = p.in_scale[(long long)seg * p.Cin + c];
-            aff[p.Cin + c] = p.in_shift[(long long)seg * p.Cin + c];
-        }
-        sy_wait_vmcnt<0>();
-        sy_barrier();
-    }
-
     sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, 0); });
     sy_static_for<0, 9>([&](auto t_) { fetch(t_, 0); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
+    // NORM: the input affine [Cin] x {scale, shift} of this image's segment is parked behind the two halo buffers.  Its global
+    // loads are issued AFTER the first slab's DMA pieces and fragment fetches (they ride in the same in-order VMEM queue, so
+    // the workgroup does not pay a serial load latency in front of its first slab — that cost ~7 us per launch in situ).
+    float* const aff = reinterpret_cast<float*>(smem + 2 * BUF);
+    if constexpr (NORM) {
+        const float* const gs = p.in_scale + (long long)(n / p.in_seg_N) * p.Cin;
+        const float* const gh = p.in_shift + (long long)(n / p.in_seg_N) * p.Cin;
+        float4 va[2], vb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (tid + i * NW * 64) * 4;
+            if (c < p.Cin) { va[i] = *reinterpret_cast<const float4*>(gs + c); vb[i] = *reinterpret_cast<const float4*>(gh + c); }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (tid + i * NW * 64) * 4;
+            if (c < p.Cin) { *reinterpret_cast<float4*>(aff + c) = va[i]; *reinterpret_cast<float4*>(aff + p.Cin + c) = vb[i]; }
+        }
+        __syncthreads();                          // LDS writes visible to every wave (waits lgkmcnt as well)
+    }
     for (int cs = 0; cs < ncs; ++cs) {
         sy_wait_vmcnt<(9 - NI) * 2 * TC>();      // the slab's DMA pieces (older than the last (9 - NI) taps of fragment loads)
         sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
                 __builtin_memcpy(&v, e, 16);
                 *reinterpret_cast<uint4*>(a) = v;
             }
-            sy_barrier();
+            __syncthreads();                      // the rewritten tile is visible to every wave (LDS writes drained, then barrier)
         }
         uint4 b[BD][TP];
         auto read_step = [&](auto s_) {

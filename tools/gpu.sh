@@ -6,7 +6,7 @@
 #   gpurun --timeout 900 -- 'bash tools/gpu.sh a tests smoke bench:train_l bench:train_l_b4:--batch,4,--no-cpu-baseline prof'
 #
 # tasks
-#   tests[:PYTEST_ARGS]          pytest tests -m gpu -q [args]                          -> pytest_gpu.log
+#   tests[:K_EXPR[:ARGS]]        pytest tests -m gpu -q [-k "K_EXPR" with + for spaces] [args] -> pytest_gpu.log
 #   smoke                        __graft_entry__.smoke()                                -> smoke.log
 #   bench:NAME[:ARGS]            python bench.py ARGS                                   -> bench_NAME.json
 #   benv:NAME:K=V,K=V[:ARGS]     same with environment variables (A/B switches)         -> bench_NAME.json
@@ -27,7 +27,8 @@ for task in "$@"; do
     IFS=: read -r kind a b c <<< "$task"
     t0=$(date +%s)
     case $kind in
-        tests) (timeout 900 python -m pytest tests -m gpu -q --durations=12 ${a//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
+        tests) if [ -n "$a" ]; then kexpr=(-k "${a//+/ }"); else kexpr=(); fi
+               (timeout 900 python -m pytest tests -m gpu -q --durations=12 "${kexpr[@]}" ${b//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
                grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
         smoke) (timeout 600 python __graft_entry__.py smoke 2>&1 | grep -vE "$noise" | tail -2) > $O/smoke.log 2>&1; cat $O/smoke.log ;;
         bench) (timeout 900 python bench.py ${b//,/ } 2>$O/bench_$a.err | tail -1) > $O/bench_$a.json
