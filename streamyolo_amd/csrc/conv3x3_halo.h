@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
                 typename T::elem e[EPC];
                 __builtin_memcpy(e, &v, 16);
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) e[j] = T::from_f32(sy_silu(sc[j] * T::to_f32(e[j]) + sh[j]));
+                for (int j = 0; j < EPC; ++j) e[j] = T::from_f32(sy_silu(T::to_f32(e[j]) * sc[j] + sh[j]));     // bn_silu_apply_kernel's expression
                 __builtin_memcpy(&v, e, 16);
                 *reinterpret_cast<uint4*>(a) = v;
             }

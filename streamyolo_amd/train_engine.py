@@ -213,7 +213,12 @@ class StagedWeights:
 
 CSP_FORK = os.environ.get("STREAMYOLO_CSP_FORK", "1") != "0"
 MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
-NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "1") != "0"
+# VERDICT r02 "next" #3, measured NEGATIVE (profiles/r03/e_*): with the producer's BatchNorm.SiLU applied by the 3x3 consumer in
+# LDS the l step takes 24.90-24.93 ms against 24.10 ms on the same box — the normalising halo kernel costs 12-22 us more per
+# launch than the plain one (+20-30 %: the extra LDS round trip and barrier per channel slab are not hidden), about what the
+# apply pass it would replace costs (tools/norm_probe.py: -0.12 ms over the 48 candidate launches), and the apply pass is
+# still needed by the backward pass.  Off by default; the kernel, its parity test and the probe stay.
+NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
 def _csp_role(tag):
@@ -378,9 +383,10 @@ class TrainPlan:
     # ---- producer BatchNorm.SiLU applied by the 3x3 consumer in LDS ------------------------------------------------------------
     # A BaseConv whose activated output is read ONLY by 3x3 stride-1 convolutions (Bottleneck conv1 -> conv2, head stem ->
     # first tower convs -> second tower convs) does not need that output in the forward pass: the consumer's halo kernel
-    # normalises the producer's RAW output tile in LDS (sy_conv_desc in_scale / in_shift; measured free, profiles/r03/d_*:
-    # 56.8 vs 56.3 us with / without on 75x120 128->128).  The producer's bn_silu_apply still runs — the backward pass reads
-    # the activated tensor (weight gradient of the consumer) — but on the SIDE stream, off the forward critical path.
+    # normalises the producer's RAW output tile in LDS (sy_conv_desc in_scale / in_shift).  The producer's bn_silu_apply still
+    # runs — the backward pass reads the activated tensor (weight gradient of the consumer) — but on the SIDE stream, off the
+    # forward critical path.  (A first probe without the LDS-write drain before the barrier showed the transform "for free" —
+    # profiles/r03/d_* — it was racing; with the wait in place it costs 12-22 us per launch, profiles/r03/e_*.)
     def _find_norm_consumers(self):
         for op in self.ops:
             op.norm_src, op.defer_apply = None, False

@@ -385,7 +385,10 @@ def test_conv3x3_input_normalised_in_lds_equals_apply_then_conv(backend, tile, d
         return yv.nchw().cpu(), ssum.cpu(), ssq.cpu()
     y1, s1, q1 = run(True)
     y0, s0, q0 = run(False)
-    assert _rel(y1, y0) < 1e-6 and _rel(s1, s0) < 1e-5 and _rel(q1, q0) < 1e-5
+    # bf16: identical.  fp16 on the GPU: the two kernels' fp32 affine differs in the last bit for a few elements (instruction
+    # selection around the fp16 -> fp32 conversion), which flips ~1e-4 of the fp16 roundings of the operand: 3e-4 .. 7e-4 measured
+    tol = 1e-6 if dt == "bf16" else 2e-3
+    assert _rel(y1, y0) < tol and _rel(s1, s0) < max(tol, 1e-5) and _rel(q1, q0) < max(tol, 1e-5)
     # and against torch: silu(bn) -> zero padding -> conv
     sc = torch.cat([scale[0].cpu().expand(N // 2, cin), scale[1].cpu().expand(N // 2, cin)])[:, :, None, None]
     sh = torch.cat([shift[0].cpu().expand(N // 2, cin), shift[1].cpu().expand(N // 2, cin)])[:, :, None, None]
