@@ -218,6 +218,7 @@ MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
 # launch than the plain one (+20-30 %: the extra LDS round trip and barrier per channel slab are not hidden), about what the
 # apply pass it would replace costs (tools/norm_probe.py: -0.12 ms over the 48 candidate launches), and the apply pass is
 # still needed by the backward pass.  Off by default; the kernel, its parity test and the probe stay.
+FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "0") != "0"
 NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
@@ -500,7 +501,17 @@ class TrainPlan:
         statistics segment per frame — the reference's two backbone passes, dfp_pafpn.py:120-165); after the DFP
         fusion the three head levels fan out over the two streams."""
         nf = self.n_frame_ops
-        for i in range(nf):
+        if FWD_SPLIT_FRAMES and nf:
+            # experiment: the two frames as two independent chains, current frame on the main stream, support frame on the side
+            # stream, issued alternately (half-size launches, but one chain's tails and BatchNorm passes fill the other's gaps)
+            self._mark("fork")
+            for i in range(nf):
+                self._forward_op(self.ops[i])
+                self._mark("side_nw")
+                self._forward_op(self.ops[nf + i])
+                self._mark("main", None)
+            self._mark("join")
+        for i in range(nf if not (FWD_SPLIT_FRAMES and nf) else 0):
             a, b2 = self.ops[i], self.ops[nf + i]
             if a.kind == "conv":
                 # CSPLayer: conv2(x) only meets the bottleneck chain conv1(x) -> m(...) again in conv3(cat[...]) —
