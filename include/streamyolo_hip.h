@@ -270,8 +270,9 @@ SY_API int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldd
                                  int copies, int64_t pixels, int C, int dtype, int nseg, void* stream);
 /* apply: dy = gamma*invstd*(dz - S0/M - xhat*S1/M) with S = sums folded over its `copies` replicas
  * ([copies][2][C]); optionally dgamma += S1, dbeta += S0.  dres (optional): the gradient view of the residual input of
- * y = silu(bn(conv)) + res (Bottleneck shortcut, DFP add): dres = da, or dres += da when dres_accumulate — the same
- * pass that already reads da (replaces a separate sy_view_copy). */
+ * y = silu(bn(conv)) + res (Bottleneck shortcut, DFP add): dres = da, or dres += da when (dres_accumulate & 1) — the same
+ * pass that already reads da (replaces a separate sy_view_copy).  dres_accumulate & 2: dgamma / dbeta are accumulated with
+ * atomics even for nseg == 1 (the two frames of a pair go through separate launches on different streams). */
 SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                 const float* shift, const float* mean, const float* invstd,
                                 const float* gamma, const float* sums, int copies, void* dy, int lddy,
@@ -337,13 +338,22 @@ enum { SY_TAPE_END = -1, SY_TAPE_LAUNCH = 0,
        SY_TAPE_ACQUIRE = 5,  /* main waits for the event of ring slot `arg` (if one is pending)               */
        SY_TAPE_JOIN = 6,     /* main waits for everything issued on side                                      */
        SY_TAPE_BREAK = 7,    /* return to the caller (host-side snippet `arg` runs there)                     */
-       SY_TAPE_BUCKET = 8    /* gradient bucket `arg` is final on both streams                                */ };
+       SY_TAPE_BUCKET = 8,   /* gradient bucket `arg` is final on every stream                                */
+       /* plans with more than two chains (sy_tape_replay_n: streams[0] = main, [1] = side, [2..] = further chains) */
+       SY_TAPE_CUR = 9,      /* cursor -> stream `arg`, no new dependency                                     */
+       SY_TAPE_DEP = 10,     /* stream (arg >> 4) records an event, stream (arg & 15) waits for it            */
+       SY_TAPE_SLOT_DONE = 11,   /* event on the CURRENT stream = "ring slot `arg` is free again"             */
+       SY_TAPE_ACQUIRE_CUR = 12  /* the CURRENT stream waits for ring slot `arg` (the slot stays marked)      */ };
 SY_API void* sy_tape_begin(void);
 SY_API int sy_tape_mark(int kind, int arg);
 SY_API void* sy_tape_end(void);
 SY_API int sy_tape_size(const void* tape, int* n_entries, int* n_launches);
 SY_API int sy_tape_replay(void* tape, void* main_stream, void* side_stream, int* pos, int stop_buckets, int* stop_kind,
                           int* stop_arg, int* stop_on_side);
+/* the same over n_streams (1..8) streams; *stop_stream = index of the cursor stream at a BREAK / BUCKET return.  A chain index
+ * beyond n_streams (or a NULL entry) runs on streams[0]: a three-chain tape replays correctly on one or two streams. */
+SY_API int sy_tape_replay_n(void* tape, void* const* streams, int n_streams, int* pos, int stop_buckets, int* stop_kind,
+                            int* stop_arg, int* stop_stream);
 SY_API void sy_tape_free(void* tape);
 
 SY_API const char* sy_version(void);

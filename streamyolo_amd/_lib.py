@@ -116,6 +116,8 @@ SIGNATURES = {
     "sy_tape_end": (_P, []),
     "sy_tape_size": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sy_tape_replay": (_I, [_P, _P, _P, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sy_tape_replay_n": (_I, [_P, C.POINTER(C.c_void_p), _I, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.POINTER(C.c_int)]),
     "sy_tape_free": (None, [_P]),
     "sy_version": (C.c_char_p, []),
     "sy_abi_version": (_I, []),
@@ -211,8 +213,10 @@ def replay(tape, stream):
 # runs, at gradient-bucket marks.
 TAPE_END, TAPE_LAUNCH, TAPE_SIDE, TAPE_FORK, TAPE_SIDE_NW, TAPE_MAIN, TAPE_ACQUIRE, TAPE_JOIN, TAPE_BREAK, TAPE_BUCKET = \
     -1, 0, 1, 2, 3, 4, 5, 6, 7, 8
+TAPE_CUR, TAPE_DEP, TAPE_SLOT_DONE, TAPE_ACQUIRE_CUR = 9, 10, 11, 12
 TAPE_MARKS = {"side": TAPE_SIDE, "fork": TAPE_FORK, "side_nw": TAPE_SIDE_NW, "main": TAPE_MAIN, "acquire": TAPE_ACQUIRE,
-              "join": TAPE_JOIN, "bucket": TAPE_BUCKET}
+              "join": TAPE_JOIN, "bucket": TAPE_BUCKET, "cur": TAPE_CUR, "dep": TAPE_DEP, "slot_done": TAPE_SLOT_DONE,
+              "acquire_cur": TAPE_ACQUIRE_CUR}
 
 
 class NativeTape:
@@ -237,6 +241,8 @@ class NativeTape:
         return False
 
     def mark(self, name, arg=None):
+        if name == "dep":                                         # arg = (from, to)
+            arg = arg[0] * 16 + arg[1]
         check(self._lib.sy_tape_mark(TAPE_MARKS[name], -1 if arg is None else int(arg)), "sy_tape_mark")
 
     def snippet(self, fn):
@@ -249,15 +255,19 @@ class NativeTape:
         check(self._lib.sy_tape_size(self.handle, C.byref(n), C.byref(l)), "sy_tape_size")
         return n.value, l.value
 
-    def replay(self, main, side=None, on_snippet=None, on_bucket=None):
-        """main / side: raw hipStream_t (ctypes c_void_p or int).  on_snippet(fn, on_side) runs a recorded snippet (default:
-        fn()); on_bucket(k): called at gradient-bucket marks (None: the marks are skipped inside the library)."""
-        fn, h = self._lib.sy_tape_replay, self.handle
+    def replay(self, main, side=None, on_snippet=None, on_bucket=None, more=()):
+        """main / side (/ more...): raw hipStream_t (ctypes c_void_p or int) of chains 0 / 1 (/ 2...).  on_snippet(fn, k) runs a
+        recorded snippet (default: fn()) — k = index of the cursor stream; on_bucket(k): called at gradient-bucket marks
+        (None: the marks are skipped inside the library)."""
+        fn, h = self._lib.sy_tape_replay_n, self.handle
         pos, kind, arg, ons = self._pos, self._kind, self._arg, self._side
         pos.value = 0
         stop_b = 0 if on_bucket is None else 1
+        lst = [main] + ([side] if side is not None else []) + (list(more) if side is not None else [])
+        arr = (C.c_void_p * len(lst))(*[s.value if isinstance(s, C.c_void_p) else s for s in lst])
+        nst = len(lst)
         while True:
-            rc = fn(h, main, side, C.byref(pos), stop_b, C.byref(kind), C.byref(arg), C.byref(ons))
+            rc = fn(h, arr, nst, C.byref(pos), stop_b, C.byref(kind), C.byref(arg), C.byref(ons))
             if rc != 0:
                 check(rc, "sy_tape_replay")
             k = kind.value
@@ -268,7 +278,7 @@ class NativeTape:
                 if on_snippet is None:
                     f()
                 else:
-                    on_snippet(f, ons.value != 0)
+                    on_snippet(f, ons.value)
             else:
                 on_bucket(arg.value)
 

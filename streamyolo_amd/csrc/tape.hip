@@ -11,6 +11,11 @@
 //   JOIN          the main stream waits for everything issued on the side stream
 //   BREAK(id)     return to the caller (a torch snippet of the plan runs there), resume with the returned position
 //   BUCKET(k)     gradient bucket k is final: returns to the caller only when `stop_buckets` (data-parallel runs)
+// and, for plans that run more than two chains (sy_tape_replay_n, streams[0] = main, [1] = side, [2..] = further chains):
+//   CUR(k)        cursor to stream k, no new dependency
+//   DEP(a, b)     stream a records an event, stream b waits for it (arg = a * 16 + b)
+//   SLOT_DONE(s)  event on the CURRENT stream = "ring slot s is free again"
+//   ACQUIRE_CUR(s) the CURRENT stream waits for that event (the slot stays marked: several chains may wait for it)
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
 
@@ -23,13 +28,14 @@ struct Entry {
     std::function<void(void*)> fn;
 };
 
-constexpr int kMaxSlots = 32;
+constexpr int kMaxSlots = 32, kMaxStreams = 8;
 
 struct Tape {
     std::vector<Entry> entries;
     int launches = 0;
     // replay state (persists across the BREAK / BUCKET returns of one pass)
     bool on_side = false;
+    int cur_k = 0;                       // index of the cursor stream (0 = main, 1 = side, ...)
     int ei = 0;
     int ring_done[kMaxSlots];
 #ifndef SY_EMU
@@ -66,8 +72,10 @@ extern "C" void* sy_tape_begin(void) {
 }
 
 extern "C" int sy_tape_mark(int kind, int arg) {
-    if (g_rec == nullptr || kind <= SY_TAPE_LAUNCH || kind > SY_TAPE_BUCKET) return SY_ERR_ARG;
-    if ((kind == SY_TAPE_MAIN || kind == SY_TAPE_ACQUIRE) && arg >= kMaxSlots) return SY_ERR_ARG;
+    if (g_rec == nullptr || kind <= SY_TAPE_LAUNCH || kind > SY_TAPE_ACQUIRE_CUR) return SY_ERR_ARG;
+    if ((kind == SY_TAPE_MAIN || kind == SY_TAPE_ACQUIRE || kind == SY_TAPE_SLOT_DONE || kind == SY_TAPE_ACQUIRE_CUR) && arg >= kMaxSlots)
+        return SY_ERR_ARG;
+    if ((kind == SY_TAPE_SLOT_DONE || kind == SY_TAPE_ACQUIRE_CUR || kind == SY_TAPE_CUR || kind == SY_TAPE_DEP) && arg < 0) return SY_ERR_ARG;
     g_rec->entries.push_back(Entry{kind, arg, nullptr});
     return SY_OK;
 }
@@ -90,23 +98,30 @@ extern "C" void sy_tape_free(void* tape) {
     if (tape != nullptr && tape != g_rec) delete (Tape*)tape;
 }
 
-extern "C" int sy_tape_replay(void* tape, void* main_stream, void* side_stream, int* pos, int stop_buckets, int* stop_kind,
-                              int* stop_arg, int* stop_on_side) {
-    if (tape == nullptr || pos == nullptr || stop_kind == nullptr || stop_arg == nullptr || g_rec != nullptr) return SY_ERR_ARG;
+extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams, int* pos, int stop_buckets, int* stop_kind,
+                                int* stop_arg, int* stop_stream) {
+    if (tape == nullptr || pos == nullptr || stop_kind == nullptr || stop_arg == nullptr || g_rec != nullptr || streams == nullptr ||
+        n_streams < 1 || n_streams > kMaxStreams)
+        return SY_ERR_ARG;
     Tape* t = (Tape*)tape;
     const int n = (int)t->entries.size();
     int i = *pos;
     if (i < 0 || i > n) return SY_ERR_ARG;
     if (i == 0) {
         t->on_side = false;
+        t->cur_k = 0;
         t->ei = 0;
         for (int s = 0; s < kMaxSlots; ++s) t->ring_done[s] = -1;
     }
+    void* const main_stream = streams[0];
+    void* const side_stream = n_streams > 1 ? streams[1] : nullptr;
     const bool two = side_stream != nullptr && side_stream != main_stream;
+    // a chain index the caller gave no stream for runs on the main stream (one- / two-stream replay of a three-chain tape)
+    auto stream_of = [&](int k) -> void* { return (two && k >= 0 && k < n_streams && streams[k] != nullptr) ? streams[k] : main_stream; };
 #ifndef SY_EMU
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
 #endif
-    void* cur = (t->on_side && two) ? side_stream : main_stream;
+    void* cur = stream_of(t->cur_k);
     for (; i < n; ++i) {
         Entry& e = t->entries[i];
         switch (e.kind) {
@@ -119,7 +134,7 @@ extern "C" int sy_tape_replay(void* tape, void* main_stream, void* side_stream, 
                 *pos = i + 1;
                 *stop_kind = e.kind;
                 *stop_arg = e.arg;
-                if (stop_on_side != nullptr) *stop_on_side = (t->on_side && two) ? 1 : 0;
+                if (stop_stream != nullptr) *stop_stream = two ? t->cur_k : 0;
                 return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
             case SY_TAPE_SIDE:
             case SY_TAPE_FORK:
@@ -131,11 +146,11 @@ extern "C" int sy_tape_replay(void* tape, void* main_stream, void* side_stream, 
                         return SY_ERR_LAUNCH;
                 }
 #endif
-                if (e.kind == SY_TAPE_SIDE) { cur = side_stream; t->on_side = true; }
+                if (e.kind == SY_TAPE_SIDE) { cur = side_stream; t->cur_k = 1; }
                 break;
             case SY_TAPE_SIDE_NW:
                 if (!two) break;
-                cur = side_stream; t->on_side = true;
+                cur = side_stream; t->cur_k = 1;
                 break;
             case SY_TAPE_MAIN:
                 if (!two) break;
@@ -146,7 +161,7 @@ extern "C" int sy_tape_replay(void* tape, void* main_stream, void* side_stream, 
                     t->ring_done[e.arg] = t->ei - 1;
                 }
 #endif
-                cur = main_stream; t->on_side = false;
+                cur = main_stream; t->cur_k = 0;
                 break;
             case SY_TAPE_ACQUIRE:
                 if (!two) break;
@@ -167,6 +182,41 @@ extern "C" int sy_tape_replay(void* tape, void* main_stream, void* side_stream, 
                 }
 #endif
                 break;
+            case SY_TAPE_CUR:
+                if (!two) break;
+                t->cur_k = e.arg;
+                cur = stream_of(e.arg);
+                break;
+            case SY_TAPE_DEP: {
+                if (!two) break;
+                void* const from = stream_of(e.arg >> 4);
+                void* const to = stream_of(e.arg & 15);
+                if (from == to) break;
+#ifndef SY_EMU
+                hipEvent_t ev = t->next_event();
+                if (ev == nullptr || hipEventRecord(ev, (hipStream_t)from) != hipSuccess ||
+                    hipStreamWaitEvent((hipStream_t)to, ev, 0) != hipSuccess)
+                    return SY_ERR_LAUNCH;
+#endif
+                break;
+            }
+            case SY_TAPE_SLOT_DONE:
+                if (!two) break;
+#ifndef SY_EMU
+                {
+                    hipEvent_t ev = t->next_event();
+                    if (ev == nullptr || hipEventRecord(ev, (hipStream_t)cur) != hipSuccess) return SY_ERR_LAUNCH;
+                    t->ring_done[e.arg] = t->ei - 1;
+                }
+#endif
+                break;
+            case SY_TAPE_ACQUIRE_CUR:
+                if (!two) break;
+#ifndef SY_EMU
+                if (t->ring_done[e.arg] >= 0 && hipStreamWaitEvent((hipStream_t)cur, t->pool[t->ring_done[e.arg]], 0) != hipSuccess)
+                    return SY_ERR_LAUNCH;
+#endif
+                break;
             default:
                 return SY_ERR_ARG;
         }
@@ -174,6 +224,12 @@ extern "C" int sy_tape_replay(void* tape, void* main_stream, void* side_stream, 
     *pos = n;
     *stop_kind = SY_TAPE_END;
     *stop_arg = 0;
-    if (stop_on_side != nullptr) *stop_on_side = 0;
+    if (stop_stream != nullptr) *stop_stream = 0;
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+extern "C" int sy_tape_replay(void* tape, void* main_stream, void* side_stream, int* pos, int stop_buckets, int* stop_kind,
+                              int* stop_arg, int* stop_on_side) {
+    void* const streams[2] = {main_stream, side_stream};
+    return sy_tape_replay_n(tape, streams, side_stream != nullptr ? 2 : 1, pos, stop_buckets, stop_kind, stop_arg, stop_on_side);
 }

@@ -617,9 +617,10 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
     }
     __syncthreads();
     if (blockIdx.x == 0 && dgamma != nullptr) {
-        if (gridDim.y == 1) {                           // launches on one stream are ordered: plain += is race free
+        if (gridDim.y == 1 && !(dres_acc & 2)) {        // launches on one stream are ordered: plain += is race free
             for (int c = threadIdx.x; c < C; c += kBlock) { dbeta[c] += s_fold[c]; dgamma[c] += s_fold[C + c]; }
-        } else {                                        // the segments (frames) share gamma / beta
+        } else {                                        // the segments (frames) share gamma / beta (bit 1 of dres_acc: the two
+                                                        // frames' launches run on different streams: atomics as well)
             for (int c = threadIdx.x; c < C; c += kBlock) { atomicAdd(dbeta + c, s_fold[c]); atomicAdd(dgamma + c, s_fold[C + c]); }
         }
     }
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         o.store(dy + pix * lddy + c0);
         if (dres != nullptr) {          // y = silu(bn(conv)) + res: the residual branch receives da unchanged (view_copy fused)
             typename T::elem* dst = dres + pix * lddres + c0;
-            if (dres_acc) {
+            if (dres_acc & 1) {
                 Chunk<T> r = Chunk<T>::load(dst);
 #pragma unroll
                 for (int j = 0; j < T::kEPC; ++j) gv.e[j] = T::from_f32(T::to_f32(gv.e[j]) + T::to_f32(r.e[j]));

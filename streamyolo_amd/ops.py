@@ -342,14 +342,15 @@ def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums, nseg=1):
 
 
 def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None, nseg=1,
-                      dres=None, dres_accumulate=False):
+                      dres=None, dres_accumulate=False, atomic_param_grads=False):
     """dres: gradient View of the residual input (y = silu(bn(conv)) + res): written (or accumulated) with da in this pass."""
     assert dres is None or (dres.C == y.C and dres.pixels == y.pixels)
     check(_lib.lib().sy_bn_silu_bwd_apply(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
                                           sums.numel() // (2 * y.C * nseg), dy.ptr(), dy.ld, y.pixels // nseg, y.C,
                                           _p(dgamma), _p(dbeta), None if dres is None else dres.ptr(),
-                                          0 if dres is None else dres.ld, 1 if dres_accumulate else 0, y.dtype, nseg,
+                                          0 if dres is None else dres.ld,
+                                          (1 if dres_accumulate else 0) | (2 if atomic_param_grads else 0), y.dtype, nseg,
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 

@@ -218,7 +218,14 @@ MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
 # launch than the plain one (+20-30 %: the extra LDS round trip and barrier per channel slab are not hidden), about what the
 # apply pass it would replace costs (tools/norm_probe.py: -0.12 ms over the 48 candidate launches), and the apply pass is
 # still needed by the backward pass.  Off by default; the kernel, its parity test and the probe stay.
-FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "0") != "0"
+# The two frames of a pair as two stream-parallel chains in the forward pass (current frame on the main stream, support frame on
+# the side stream, half-size launches issued alternately): one chain's HBM-bound BatchNorm passes and kernel tails fill the
+# other's MFMA-bound convolutions.  Measured (profiles/r03/f_*): 23.18-23.24 vs 24.02 ms per l step at 8 pairs, 14.75 vs 15.28
+# at 4 — although the half-size kernels are individually slower (kernel sum 18.9 vs 18.0 ms).
+FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "1") != "0"
+# ... and in the backward pass: BatchNorm backward + data gradient of the two frames as chains on streams 0 and 2, the (paired)
+# weight gradient of the layer on stream 1 behind both.
+BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "1") != "0"
 NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
@@ -331,6 +338,7 @@ class TrainPlan:
         self._bind_scratch()
         self.ring_i = 0
         self.side = torch.cuda.Stream(device=device) if (device.type == "cuda" and self.STREAMS > 1) else None
+        self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and BWD_SPLIT_FRAMES) else None
         self.tuned = False                    # the first step (autotuning) runs on one stream
         self.force_serial = False             # profile(): per-kernel durations without overlap
         self._ev_pool = []
@@ -639,24 +647,26 @@ class TrainPlan:
     def _interpret(self, tape):
         """Replay a recorded pass: ONE library call walks the launches, stream switches and event pairs (csrc/tape.hip);
         Python is re-entered only for the recorded torch snippets and, in data-parallel runs, at the bucket marks."""
-        side = self.side
+        side, side2 = self.side, self.side2
         if self.device.type == "cuda":
             main = torch.cuda.current_stream(self.device)
             main_h = C.c_void_p(main.cuda_stream)
             side_h = C.c_void_p(side.cuda_stream) if side is not None else None
+            more = [C.c_void_p(side2.cuda_stream)] if side2 is not None else []
         else:
-            main, main_h, side_h = None, C.c_void_p(0), None
+            main, main_h, side_h, more = None, C.c_void_p(0), None, []
+        chains = [main, side, side2]
 
-        def snippet(fn, on_side):
-            if on_side:
-                with torch.cuda.stream(side):
+        def snippet(fn, k):
+            if k and chains[k] is not None:
+                with torch.cuda.stream(chains[k]):
                     fn()
             else:
                 fn()
         on_bucket = None
         if self.on_bucket is not None:
-            on_bucket = lambda k: self.on_bucket(k, main, side)      # noqa: E731
-        tape.replay(main_h, side_h, snippet, on_bucket)
+            on_bucket = lambda k: self.on_bucket(k, main, [s_ for s_ in (side, side2) if s_ is not None])      # noqa: E731
+        tape.replay(main_h, side_h, snippet, on_bucket, more=more)
 
     def _forward_op(self, op):
         nch = 5 + self.nc
@@ -787,7 +797,10 @@ class TrainPlan:
                 # read THIS call's seed at replay time: the recorded snippet must not bind the recording call's tensors
                 self._py(lambda gv=gv, i=i: gv.set_nchw(self._seed[i]))
         self._bucket_marks(-1)                                   # ranges no kernel writes (unused parameters)
+        split = BWD_SPLIT_FRAMES and nf > 0
         for pos, a in enumerate(self._backward_sequence()):      # head, DFP fusion, then the per-frame network
+            if split and pos == len(self.ops) - 2 * nf:
+                self._mark("dep", (0, 2))                        # the support-frame chain starts behind the head / fusion backward
             if pos < len(self.ops) - 2 * nf:
                 if a.kind == "pred":
                     self._pred_backward(a, d_raw)
@@ -796,15 +809,23 @@ class TrainPlan:
             else:                                                # layer i of both frames together
                 b2 = self.ops[nf + (len(self.ops) - 2 * nf) + nf - 1 - pos]
                 if a.kind == "conv":
-                    self._conv_pair_backward(a, b2)
+                    if split:
+                        self._conv_pair_backward_split(a, b2)
+                    else:
+                        self._conv_pair_backward(a, b2)
                 else:
                     for op in (b2, a):
+                        if split:
+                            self._mark("cur", 2 if op is b2 else 0)
                         if op.kind == "resize":
                             dsrc, acc = G.target(op.src)
                             ops.resize_nearest_bwd(G.view(op.dst), dsrc, acc)
                         elif op.kind == "spp":
                             ops.spp_pool_bwd(G.view(op.v), op.argmax)
             self._bucket_marks(pos)
+        if split:
+            self._mark("cur", 0)
+            self._mark("dep", (2, 0))
         self._mark("join")
 
     # ---- weight gradients off the critical path -------------------------------------------------------------
@@ -924,6 +945,42 @@ class TrainPlan:
             ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
                        mode=CONV_DGRAD, accumulate=acca, tile=t,
                        wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
+
+    def _conv_pair_backward_split(self, a, b2):
+        """Layer i of the two frames as two chains: BatchNorm backward + data gradient of the current frame on stream 0, of the
+        support frame on stream 2 (separate half-size launches: one chain's HBM-bound passes run beside the other's MFMA-bound
+        data gradient), the weight gradient ONCE over both frames on stream 1 behind both chains' raw gradients."""
+        G = self.grads
+        N, H, W, C = a.y.N, a.y.H, a.y.W, a.y.C
+        self.ring_i = (self.ring_i + 1) % self.RING
+        slot = self.ring_i
+        full = self.dyraw_ring[slot][:2 * N * H * W * C].view(2 * N, H, W, C)
+        dy2 = View(full, 2 * N, H, W, C)
+        dys = (View(full[:N], N, H, W, C), View(full[N:], N, H, W, C))
+        gamma = self._bn_params(a)[0]
+        dgamma, dbeta = self._bn_grads(a)
+        for k, (op, dyr) in enumerate(zip((a, b2), dys)):            # BatchNorm / SiLU backward, frame by frame
+            self._mark("cur", 2 * k)
+            self._mark("acquire_cur", slot)                          # the wgrad that last read this slot has retired
+            dres, acc = (None, False) if op.res is None else G.target(op.res)
+            scale, shift, mean, invstd = op.aff
+            ops.bn_silu_bwd_reduce(op.yraw, G.view(op.y), scale, shift, mean, invstd, op.bsum)
+            ops.bn_silu_bwd_apply(op.yraw, G.view(op.y), scale, shift, mean, invstd, gamma, op.bsum, dyr, dgamma, dbeta,
+                                  dres=dres, dres_accumulate=acc, atomic_param_grads=True)
+        self._mark("dep", (0, 1))
+        self._mark("dep", (2, 1))
+        self._mark("cur", 1)
+        self._wgrad(a, a.x.pair(), dy2)
+        self._mark("slot_done", slot)
+        if a.need_dx:
+            t = a.tile("dgrad")
+            for k, (op, dyr) in enumerate(zip((a, b2), dys)):
+                self._mark("cur", 2 * k)
+                dx, acc = G.target(op.x)
+                ops.conv2d(dyr, self.cache.conv_weight(a.mod, transpose=True), dx, a.k, a.stride, mode=CONV_DGRAD,
+                           accumulate=acc, tile=t,
+                           wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
+        self._mark("cur", 0)
 
     def _conv_backward(self, op):
         G = self.grads
@@ -1219,8 +1276,9 @@ class TrainStep:
             if self.comm is None:
                 self.comm = torch.cuda.Stream(device=self.plan.device)
             self.comm.wait_stream(main)
-            if side is not None:
-                self.comm.wait_stream(side)
+            for s_ in (side if isinstance(side, (list, tuple)) else [side]):
+                if s_ is not None:
+                    self.comm.wait_stream(s_)
             with torch.cuda.stream(self.comm):
                 self._works.append(self.dist.all_reduce(view, async_op=True))
         else:
