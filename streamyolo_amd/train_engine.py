@@ -653,6 +653,10 @@ class TrainPlan:
             main_h = C.c_void_p(main.cuda_stream)
             side_h = C.c_void_p(side.cuda_stream) if side is not None else None
             more = [C.c_void_p(side2.cuda_stream)] if side2 is not None else []
+            if torch.cuda.is_current_stream_capturing():
+                # hipGraph capture (TrainStep(graph=True)): forks across more than two streams segfault inside capture_end on
+                # this ROCm build — chain 2 folds back onto the main stream there (sy_tape_replay_n's fallback)
+                more = []
         else:
             main, main_h, side_h, more = None, C.c_void_p(0), None, []
         chains = [main, side, side2]
