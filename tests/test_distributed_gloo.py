@@ -75,7 +75,10 @@ def _worker(rank, world, port, emu_lib, out_dir):
     ddp = torch.nn.parallel.DistributedDataParallel(m2, broadcast_buffers=False)
     out = ddp(x, (lab, sup))
     out["total_loss"].backward()
-    flat = torch.cat([p.grad.reshape(-1) for p in m2.parameters()])
+    # `mean` is in ARENA order (the parts of stacked sibling convolutions sit side by side there): same order for the DDP grads
+    name_of = {id(p): n for n, p in m1.named_parameters()}
+    named2 = dict(m2.named_parameters())
+    flat = torch.cat([named2[name_of[id(p)]].grad.reshape(-1) for p in s1.plan.params])
     err_ddp = float((flat - mean).abs().max() / mean.abs().max())
     torch.save({"err_fast": err_fast, "err_ddp": err_ddp, "nonzero": bool(mean.abs().max() > 0)},
                os.path.join(out_dir, "rank%d.pt" % rank))
