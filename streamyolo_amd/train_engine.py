@@ -225,7 +225,10 @@ MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
 FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "1") != "0"
 # ... and in the backward pass: BatchNorm backward + data gradient of the two frames as chains on streams 0 and 2, the (paired)
 # weight gradient of the layer on stream 1 behind both.
-BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "1") != "0"
+# Measured (profiles/r03/g_*, j_*): l at 8 pairs 22.7-23.0 vs 23.36 ms, l at 4 pairs 14.79 vs 14.75, m 15.45 (both) vs 15.83 (none),
+# s 8.05 vs 7.96 — it pays once a frame's layers are big enough to keep the chip busy in half-size launches: "auto" turns it on
+# for B * H * W * width^2 >= 2e6 (l from 4 pairs, m from 8 at 600x960; not s).  "1" / "0" force it.
+BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "auto")
 NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
@@ -338,7 +341,9 @@ class TrainPlan:
         self._bind_scratch()
         self.ring_i = 0
         self.side = torch.cuda.Stream(device=device) if (device.type == "cuda" and self.STREAMS > 1) else None
-        self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and BWD_SPLIT_FRAMES) else None
+        w_ = float(getattr(pafpn, "width", 1.0)) if pafpn is not None else 0.0
+        self.bwd_split = (BWD_SPLIT_FRAMES == "1") or (BWD_SPLIT_FRAMES == "auto" and B * H * W * w_ * w_ >= 2.0e6)
+        self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and self.bwd_split) else None
         self.tuned = False                    # the first step (autotuning) runs on one stream
         self.force_serial = False             # profile(): per-kernel durations without overlap
         self._ev_pool = []
@@ -801,7 +806,7 @@ class TrainPlan:
                 # read THIS call's seed at replay time: the recorded snippet must not bind the recording call's tensors
                 self._py(lambda gv=gv, i=i: gv.set_nchw(self._seed[i]))
         self._bucket_marks(-1)                                   # ranges no kernel writes (unused parameters)
-        split = BWD_SPLIT_FRAMES and nf > 0
+        split = self.bwd_split and nf > 0
         for pos, a in enumerate(self._backward_sequence()):      # head, DFP fusion, then the per-frame network
             if split and pos == len(self.ops) - 2 * nf:
                 self._mark("dep", (0, 2))                        # the support-frame chain starts behind the head / fusion backward

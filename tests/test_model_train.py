@@ -395,3 +395,32 @@ def test_submodule_training_steps_follow_changing_inputs(backend):
         ref = {n: p.grad.detach().cpu() for n, p in fused.named_parameters()}
         worst, name, _ = _per_param_l2(split, ref)
         assert worst < 1e-3, "step %d: %s off by %.3e (split vs fused plan)" % (step, name, worst)
+
+
+def test_frames_as_stream_parallel_chains_match_the_paired_launches(backend, golden_dir, monkeypatch):
+    """The two frames of a pair as separate chains (forward: half-size launches on two streams; backward: BatchNorm backward +
+    data gradient per frame on streams 0 / 2, ONE weight gradient per layer behind both) against one launch per layer over
+    both frames: same loss, gradients and running statistics, through direct steps, the recorded step and tape replays."""
+    from streamyolo_amd import train_engine
+    from streamyolo_amd.train_engine import TrainStep
+    res = {}
+    for mode, fwd, bwd in (("paired", False, "0"), ("chains", True, "1")):
+        monkeypatch.setattr(train_engine, "FWD_SPLIT_FRAMES", fwd)
+        monkeypatch.setattr(train_engine, "BWD_SPLIT_FRAMES", bwd)
+        z, model, x, targets = _setup("nano", "nano_train_2x64x96", golden_dir, backend, "fp32")
+        st = TrainStep(model, graph=False)
+        assert st._ensure(x).bwd_split == (bwd == "1")
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        for _ in range(3):                                       # direct, recorded, replayed
+            model.load_state_dict(state0)
+            out = st.step(x, targets)
+        res[mode] = (float(out["total_loss"]), st.plan.arena.clone(), {id(p): n for n, p in model.named_parameters()},
+                     st.plan, {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
+    (la, ga, na, pa, ra), (lb, gb, nb, pb, rb) = res["paired"], res["chains"]
+    assert abs(la - lb) / abs(la) < 1e-6
+    by_name = lambda plan, names, arena: {names[id(p)]: plan.gview[id(p)] for p in plan.params}      # noqa: E731
+    A, Bm = by_name(pa, na, ga), by_name(pb, nb, gb)
+    for k in A:
+        assert _rel(Bm[k].cpu(), A[k].cpu()) < 1e-5, k
+    for k in ra:
+        assert _rel(rb[k], ra[k]) < 1e-6, k
