@@ -443,15 +443,17 @@ class TrainPlan:
         plans alive; these two are pure scratch, 256 MB + RING x the largest raw gradient) or plan-owned without a pool."""
         esz = torch.empty(0, dtype=self.tdtype).element_size()
         ring_bytes = -(-self.max_raw * esz // 256) * 256
+        # one tensor PER SLOT: the kernels address an operand through a 32-bit buffer extent measured to the end of its
+        # allocation, so a single flat ring (RING x ~300 MB for l at 8 pairs) must not grow past 2 GiB
         if self.pool is not None:
             self.wgrad_ws = self.pool.shared_scratch("wgrad_ws", self.WGRAD_WS_BYTES, self.device)
-            flat = self.pool.shared_scratch("dyraw_ring", ring_bytes * self.RING, self.device)
+            slots = [self.pool.shared_scratch("dyraw_ring_%d" % i, ring_bytes, self.device) for i in range(self.RING)]
             self._scratch_gen = self.pool.scratch_gen
         else:
             self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device)
-            flat = torch.empty(ring_bytes * self.RING, dtype=torch.uint8, device=self.device)
+            slots = [torch.empty(ring_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.RING)]
             self._scratch_gen = 0
-        self.dyraw_ring = [flat[i * ring_bytes:i * ring_bytes + self.max_raw * esz].view(self.tdtype) for i in range(self.RING)]
+        self.dyraw_ring = [t[:self.max_raw * esz].view(self.tdtype) for t in slots]
 
     def release(self):
         """Dropped from the plan cache (LRU): free the recorded tapes (they hold raw pointers into buffers that go back to the
