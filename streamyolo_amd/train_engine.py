@@ -229,6 +229,10 @@ FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "1") != "0"
 # s 8.05 vs 7.96 — it pays once a frame's layers are big enough to keep the chip busy in half-size launches: "auto" turns it on
 # for B * H * W * width^2 >= 2e6 (l from 4 pairs, m from 8 at 600x960; not s).  "1" / "0" force it.
 BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "auto")
+# experiments on the same machinery: head levels 1-2 backward as a chain of their own (stream 2) beside level 0; weight gradients
+# alternating between two streams (1 and 3, a split-K workspace each) so that one layer's fold runs beside the next layer's wgrad
+HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "0") != "0"
+DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "0") != "0"
 NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
@@ -343,7 +347,9 @@ class TrainPlan:
         self.side = torch.cuda.Stream(device=device) if (device.type == "cuda" and self.STREAMS > 1) else None
         w_ = float(getattr(pafpn, "width", 1.0)) if pafpn is not None else 0.0
         self.bwd_split = (BWD_SPLIT_FRAMES == "1") or (BWD_SPLIT_FRAMES == "auto" and B * H * W * w_ * w_ >= 2.0e6)
-        self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and self.bwd_split) else None
+        self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and (self.bwd_split or HEAD_BWD_CHAINS)) else None
+        self.side3 = torch.cuda.Stream(device=device) if (self.side is not None and DUAL_WGRAD) else None
+        self._chain, self._wg_stream, self._wg_flip = 0, 1, 0
         self.tuned = False                    # the first step (autotuning) runs on one stream
         self.force_serial = False             # profile(): per-kernel durations without overlap
         self._ev_pool = []
@@ -454,6 +460,12 @@ class TrainPlan:
             slots = [torch.empty(ring_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.RING)]
             self._scratch_gen = 0
         self.dyraw_ring = [t[:self.max_raw * esz].view(self.tdtype) for t in slots]
+        self.wgrad_ws_by = {1: self.wgrad_ws}
+        if DUAL_WGRAD:
+            self.wgrad_ws_by[3] = (self.pool.shared_scratch("wgrad_ws3", self.WGRAD_WS_BYTES, self.device) if self.pool is not None
+                                   else torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device))
+            if self.pool is not None:
+                self._scratch_gen = self.pool.scratch_gen
 
     def release(self):
         """Dropped from the plan cache (LRU): free the recorded tapes (they hold raw pointers into buffers that go back to the
@@ -654,19 +666,21 @@ class TrainPlan:
     def _interpret(self, tape):
         """Replay a recorded pass: ONE library call walks the launches, stream switches and event pairs (csrc/tape.hip);
         Python is re-entered only for the recorded torch snippets and, in data-parallel runs, at the bucket marks."""
-        side, side2 = self.side, self.side2
+        side, side2, side3 = self.side, self.side2, self.side3
         if self.device.type == "cuda":
             main = torch.cuda.current_stream(self.device)
             main_h = C.c_void_p(main.cuda_stream)
             side_h = C.c_void_p(side.cuda_stream) if side is not None else None
-            more = [C.c_void_p(side2.cuda_stream)] if side2 is not None else []
+            more = [C.c_void_p(st_.cuda_stream) if st_ is not None else None for st_ in (side2, side3)]
+            while more and more[-1] is None:
+                more.pop()
             if torch.cuda.is_current_stream_capturing():
                 # hipGraph capture (TrainStep(graph=True)): forks across more than two streams segfault inside capture_end on
                 # this ROCm build — chain 2 folds back onto the main stream there (sy_tape_replay_n's fallback)
                 more = []
         else:
             main, main_h, side_h, more = None, C.c_void_p(0), None, []
-        chains = [main, side, side2]
+        chains = [main, side, side2, side3]
 
         def snippet(fn, k):
             if k and chains[k] is not None:
@@ -676,7 +690,7 @@ class TrainPlan:
                 fn()
         on_bucket = None
         if self.on_bucket is not None:
-            on_bucket = lambda k: self.on_bucket(k, main, [s_ for s_ in (side, side2) if s_ is not None])      # noqa: E731
+            on_bucket = lambda k: self.on_bucket(k, main, [s_ for s_ in (side, side2, side3) if s_ is not None])      # noqa: E731
         tape.replay(main_h, side_h, snippet, on_bucket, more=more)
 
     def _forward_op(self, op):
@@ -809,10 +823,24 @@ class TrainPlan:
                 self._py(lambda gv=gv, i=i: gv.set_nchw(self._seed[i]))
         self._bucket_marks(-1)                                   # ranges no kernel writes (unused parameters)
         split = self.bwd_split and nf > 0
+        self._chain, self._wg_flip = 0, 0
+        head_chain = HEAD_BWD_CHAINS and self.head is not None and self.side2 is not None
+        n_head = len(self.ops) - self.n_head_start               # the backward walk starts with the head's ops, last level first
+        if head_chain:
+            self._mark("dep", (0, 2))                            # d_raw / dpad are ready on the main stream
         for pos, a in enumerate(self._backward_sequence()):      # head, DFP fusion, then the per-frame network
+            if head_chain and pos == n_head:
+                self._chain = 0
+                self._mark("cur", 0)
+                self._mark("dep", (2, 0))                        # the fusion backward reads every level's feature gradient
             if split and pos == len(self.ops) - 2 * nf:
                 self._mark("dep", (0, 2))                        # the support-frame chain starts behind the head / fusion backward
             if pos < len(self.ops) - 2 * nf:
+                if head_chain and pos < n_head:                  # levels 1-2 as a chain of their own beside level 0
+                    k = 2 if a.level != 0 else 0
+                    if k != self._chain:
+                        self._chain = k
+                        self._mark("cur", k)
                 if a.kind == "pred":
                     self._pred_backward(a, d_raw)
                 else:
@@ -844,17 +872,36 @@ class TrainPlan:
     # stream, ordered after the main-stream kernels that produced its raw gradient, and the main stream goes
     # straight on to the data gradient of the same layer.
     def _scratch(self, numel):
-        """Next raw-gradient slot of the ring (the main stream first waits for the wgrad that last read it)."""
+        """Next raw-gradient slot of the ring (the current chain first waits for the wgrad that last read it)."""
         self.ring_i = (self.ring_i + 1) % self.RING
         self._slot = self.ring_i
-        self._mark("acquire", self._slot)
+        self._mark("acquire_cur", self._slot)
         return self.dyraw_ring[self._slot][:numel]
 
-    def _on_side(self, fn, slot=None):
-        """fn's launches go to the side stream, after everything issued so far on the main stream."""
-        self._mark("side")
+    def _wgrad_stream(self, fixed=None):
+        """Stream the next weight gradient goes to: 1, or 1 / 3 alternately (DUAL_WGRAD)."""
+        if fixed is not None or not DUAL_WGRAD:
+            return 1 if fixed is None else fixed
+        self._wg_flip ^= 1
+        return 3 if self._wg_flip else 1
+
+    def _on_side(self, fn, slot=None, chains=None, stream=None):
+        """fn's launches (a weight gradient + fold) go to a weight-gradient stream, after everything issued so far on the
+        chain(s) that produced its raw gradient; the ring slot is marked free behind them."""
+        chains = (self._chain,) if chains is None else chains
+        w = self._wgrad_stream(stream)
+        for k in chains:
+            self._mark("dep", (k, w))
+        self._mark("cur", w)
+        self._wg_stream = w
         fn()
-        self._mark("main", slot)
+        self._wg_stream = 1
+        if slot is not None:
+            self._mark("slot_done", slot)
+        self._mark("cur", self._chain)
+
+    def _ws(self):
+        return self.wgrad_ws_by[self._wg_stream]
 
     def _pred_backward(self, op, d_raw):
         G = self.grads
@@ -876,10 +923,10 @@ class TrainPlan:
         def wg():
             # two MFMA weight-gradient launches into the (zero) scratch, then one fold: weight gradients += scratch rows,
             # bias gradients += column sums of this level's d_raw rows — all C-ABI launches, nothing for the host to do
-            ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1, workspace=self.wgrad_ws)
-            ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1, workspace=self.wgrad_ws)
+            ops.conv2d_wgrad(op.reg_x, d_ro, sc[0], 1, 1, workspace=self._ws())
+            ops.conv2d_wgrad(op.cls_x, d_c, sc[1], 1, 1, workspace=self._ws())
             ops.pred_grad_fold(d_raw, op.a0, hwk, nc, sc, cin, g_reg, g_obj, g_cls, gb_r, gb_o, gb_c, self.pred_ws)
-        self._on_side(wg)
+        self._on_side(wg, stream=1)                                  # one scratch for the three levels: always stream 1
 
     def _bn_backward(self, op, dyraw):
         """Residual fan-in + BatchNorm/SiLU backward of one BaseConv call: fills `dyraw` (grad of the raw conv
@@ -909,13 +956,13 @@ class TrainPlan:
                 wt = (wt[0], cap)
             op._tiles[key] = wt
         if w.shape[1] == x.C:
-            ops.conv2d_wgrad(x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
+            ops.conv2d_wgrad(x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self._ws(),
                              tile=wt[0], target_blocks=wt[1])
         else:                                                        # Focus stem: 12 real + 4 zero-padded channels
             if self.stem_scratch is None:
                 self.stem_scratch = torch.zeros((w.shape[0], x.C, op.k, op.k), dtype=torch.float32, device=self.device)
             sc, gw = self.stem_scratch, self.gview[id(w)]                # scratch zero between uses (cleared by the fold)
-            ops.conv2d_wgrad(x, dyraw, sc, op.k, op.stride, oihw=True, workspace=self.wgrad_ws,
+            ops.conv2d_wgrad(x, dyraw, sc, op.k, op.stride, oihw=True, workspace=self._ws(),
                              tile=wt[0], target_blocks=wt[1])
             kk = op.k * op.k
             ops.rows_add_f32(gw, sc, w.shape[0], w.shape[1] * kk, w.shape[1] * kk, x.C * kk, zero_src=True)
@@ -978,11 +1025,8 @@ class TrainPlan:
             ops.bn_silu_bwd_reduce(op.yraw, G.view(op.y), scale, shift, mean, invstd, op.bsum)
             ops.bn_silu_bwd_apply(op.yraw, G.view(op.y), scale, shift, mean, invstd, gamma, op.bsum, dyr, dgamma, dbeta,
                                   dres=dres, dres_accumulate=acc, atomic_param_grads=True)
-        self._mark("dep", (0, 1))
-        self._mark("dep", (2, 1))
-        self._mark("cur", 1)
-        self._wgrad(a, a.x.pair(), dy2)
-        self._mark("slot_done", slot)
+        self._chain = 0
+        self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot, chains=(0, 2))
         if a.need_dx:
             t = a.tile("dgrad")
             for k, (op, dyr) in enumerate(zip((a, b2), dys)):

@@ -7,6 +7,7 @@
 #
 # tasks
 #   tests[:K_EXPR[:ARGS]]        pytest tests -m gpu -q [-k "K_EXPR" with + for spaces] [args] -> pytest_gpu.log
+#   tenv:K=V,K=V:K_EXPR          the same subset under environment switches                 -> pytest_gpu_env.log
 #   smoke                        __graft_entry__.smoke()                                -> smoke.log
 #   bench:NAME[:ARGS]            python bench.py ARGS                                   -> bench_NAME.json
 #   benv:NAME:K=V,K=V[:ARGS]     same with environment variables (A/B switches)         -> bench_NAME.json
@@ -30,6 +31,8 @@ for task in "$@"; do
         tests) if [ -n "$a" ]; then kexpr=(-k "${a//+/ }"); else kexpr=(); fi
                (timeout 900 python -m pytest tests -m gpu -q --durations=12 "${kexpr[@]}" ${b//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
                grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
+        tenv)  (env ${a//,/ } timeout 900 python -m pytest tests -m gpu -q -k "${b//+/ }" 2>&1 | grep -vE "$noise") > $O/pytest_gpu_env.log 2>&1
+               grep -E "passed|failed|error" $O/pytest_gpu_env.log | tail -3 ;;
         smoke) (timeout 600 python __graft_entry__.py smoke 2>&1 | grep -vE "$noise" | tail -2) > $O/smoke.log 2>&1; cat $O/smoke.log ;;
         bench) (timeout 900 python bench.py ${b//,/ } 2>$O/bench_$a.err | tail -1) > $O/bench_$a.json
                python tools/bench_line.py $O/bench_$a.json ;;
