@@ -229,10 +229,11 @@ FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "1") != "0"
 # s 8.05 vs 7.96 — it pays once a frame's layers are big enough to keep the chip busy in half-size launches: "auto" turns it on
 # for B * H * W * width^2 >= 2e6 (l from 4 pairs, m from 8 at 600x960; not s).  "1" / "0" force it.
 BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "auto")
-# experiments on the same machinery: head levels 1-2 backward as a chain of their own (stream 2) beside level 0; weight gradients
-# alternating between two streams (1 and 3, a split-K workspace each) so that one layer's fold runs beside the next layer's wgrad
-HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "0") != "0"
-DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "0") != "0"
+# On the same machinery: head levels 1-2 backward as a chain of their own (stream 2) beside level 0; weight gradients alternating
+# between two streams (1 and 3, a split-K workspace each) so that one layer's fold runs beside the next layer's wgrad.  Measured
+# on one box (profiles/r03/l_*): 22.66-22.77 (neither) / 22.73 (head chain) / 22.54 (two wgrad streams) / 22.27 ms (both).
+HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "1") != "0"
+DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "1") != "0"
 NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
