@@ -234,6 +234,7 @@ BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "auto")
 # on one box (profiles/r03/l_*): 22.66-22.77 (neither) / 22.73 (head chain) / 22.54 (two wgrad streams) / 22.27 ms (both).
 HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "1") != "0"
 DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "1") != "0"
+WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD_STREAMS", "2")) if DUAL_WGRAD else 1))]
 NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
@@ -349,7 +350,8 @@ class TrainPlan:
         w_ = float(getattr(pafpn, "width", 1.0)) if pafpn is not None else 0.0
         self.bwd_split = (BWD_SPLIT_FRAMES == "1") or (BWD_SPLIT_FRAMES == "auto" and B * H * W * w_ * w_ >= 2.0e6)
         self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and (self.bwd_split or HEAD_BWD_CHAINS)) else None
-        self.side3 = torch.cuda.Stream(device=device) if (self.side is not None and DUAL_WGRAD) else None
+        self.side_w = {k: torch.cuda.Stream(device=device) for k in WGRAD_STREAMS[1:]} if self.side is not None else {}
+        self.side3 = self.side_w.get(3)
         self._chain, self._wg_stream, self._wg_flip = 0, 1, 0
         self.tuned = False                    # the first step (autotuning) runs on one stream
         self.force_serial = False             # profile(): per-kernel durations without overlap
@@ -462,11 +464,11 @@ class TrainPlan:
             self._scratch_gen = 0
         self.dyraw_ring = [t[:self.max_raw * esz].view(self.tdtype) for t in slots]
         self.wgrad_ws_by = {1: self.wgrad_ws}
-        if DUAL_WGRAD:
-            self.wgrad_ws_by[3] = (self.pool.shared_scratch("wgrad_ws3", self.WGRAD_WS_BYTES, self.device) if self.pool is not None
-                                   else torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device))
-            if self.pool is not None:
-                self._scratch_gen = self.pool.scratch_gen
+        for k in WGRAD_STREAMS[1:]:                              # one split-K workspace per weight-gradient stream
+            self.wgrad_ws_by[k] = (self.pool.shared_scratch("wgrad_ws%d" % k, self.WGRAD_WS_BYTES, self.device)
+                                   if self.pool is not None else torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device))
+        if self.pool is not None:
+            self._scratch_gen = self.pool.scratch_gen
 
     def release(self):
         """Dropped from the plan cache (LRU): free the recorded tapes (they hold raw pointers into buffers that go back to the
@@ -667,12 +669,13 @@ class TrainPlan:
     def _interpret(self, tape):
         """Replay a recorded pass: ONE library call walks the launches, stream switches and event pairs (csrc/tape.hip);
         Python is re-entered only for the recorded torch snippets and, in data-parallel runs, at the bucket marks."""
-        side, side2, side3 = self.side, self.side2, self.side3
+        side, side2 = self.side, self.side2
+        extra = [self.side_w.get(k) for k in (3, 4, 5)]
         if self.device.type == "cuda":
             main = torch.cuda.current_stream(self.device)
             main_h = C.c_void_p(main.cuda_stream)
             side_h = C.c_void_p(side.cuda_stream) if side is not None else None
-            more = [C.c_void_p(st_.cuda_stream) if st_ is not None else None for st_ in (side2, side3)]
+            more = [C.c_void_p(st_.cuda_stream) if st_ is not None else None for st_ in [side2] + extra]
             while more and more[-1] is None:
                 more.pop()
             if torch.cuda.is_current_stream_capturing():
@@ -681,7 +684,7 @@ class TrainPlan:
                 more = []
         else:
             main, main_h, side_h, more = None, C.c_void_p(0), None, []
-        chains = [main, side, side2, side3]
+        chains = [main, side, side2] + extra
 
         def snippet(fn, k):
             if k and chains[k] is not None:
@@ -691,7 +694,7 @@ class TrainPlan:
                 fn()
         on_bucket = None
         if self.on_bucket is not None:
-            on_bucket = lambda k: self.on_bucket(k, main, [s_ for s_ in (side, side2, side3) if s_ is not None])      # noqa: E731
+            on_bucket = lambda k: self.on_bucket(k, main, [s_ for s_ in [side, side2] + extra if s_ is not None])      # noqa: E731
         tape.replay(main_h, side_h, snippet, on_bucket, more=more)
 
     def _forward_op(self, op):
@@ -880,11 +883,11 @@ class TrainPlan:
         return self.dyraw_ring[self._slot][:numel]
 
     def _wgrad_stream(self, fixed=None):
-        """Stream the next weight gradient goes to: 1, or 1 / 3 alternately (DUAL_WGRAD)."""
-        if fixed is not None or not DUAL_WGRAD:
-            return 1 if fixed is None else fixed
-        self._wg_flip ^= 1
-        return 3 if self._wg_flip else 1
+        """Stream the next weight gradient goes to: round robin over WGRAD_STREAMS (1, 3, ...)."""
+        if fixed is not None:
+            return fixed
+        self._wg_flip = (self._wg_flip + 1) % len(WGRAD_STREAMS)
+        return WGRAD_STREAMS[self._wg_flip]
 
     def _on_side(self, fn, slot=None, chains=None, stream=None):
         """fn's launches (a weight gradient + fold) go to a weight-gradient stream, after everything issued so far on the
