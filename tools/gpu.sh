@@ -17,6 +17,7 @@
 #   layers                       per-layer kernel times (tools/profile_train.py)         -> train_l_layer_profile.txt
 #   host[:MODEL]                 host-side launch profile (tools/host_profile.py)        -> host_profile_train_MODEL.txt
 #   py:NAME:SCRIPT[:ARGS]        python SCRIPT ARGS                                      -> NAME.txt
+#   tunecache                    copy the tuner cache the runs above wrote (lib/tune_cache.json) -> tune_cache.json
 STAGE=$1; shift
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
@@ -46,9 +47,12 @@ for task in "$@"; do
         traffic) w=${a:-train}; m=${b:-l}
                (timeout 1200 python tools/pmc_traffic.py --out $O/traffic_${w}_$m.json -- --workload $w --model $m 2>&1 | tail -20) > $O/traffic_${w}_$m.txt 2>&1
                tail -20 $O/traffic_${w}_$m.txt ;;
-        mfma)  (timeout 900 python tools/pmc_mfma_util.py 2>&1 | tail -40) > $O/mfma_util_train_l.txt 2>&1; tail -30 $O/mfma_util_train_l.txt ;;
+        mfma)  rm -rf /tmp/pmc_m_$STAGE
+               (cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_m_$STAGE -- python $OLDPWD/bench.py --workload train --model l --steps 2 --warmup 4 --no-cpu-baseline --extras 0 > /dev/null 2>&1)
+               python tools/pmc_mfma_util.py /tmp/pmc_m_$STAGE > $O/mfma_util_train_l.txt 2>&1; tail -30 $O/mfma_util_train_l.txt ;;
         layers) (timeout 900 python tools/profile_train.py ${a//,/ } 2>&1 | grep -vE "$noise") > $O/train_l_layer_profile.txt 2>&1; tail -12 $O/train_l_layer_profile.txt ;;
         host)  m=${a:-l}; (timeout 600 python tools/host_profile.py $m 2>&1 | grep -v "^$" | tail -40) > $O/host_profile_train_$m.txt 2>&1; tail -12 $O/host_profile_train_$m.txt ;;
+        tunecache) cp streamyolo_amd/lib/tune_cache.json $O/tune_cache.json 2>/dev/null; ls -la $O/tune_cache.json ;;
         py)    (timeout 1200 python $b ${c//,/ } 2>&1 | grep -vE "$noise") > $O/$a.txt 2>&1; tail -40 $O/$a.txt ;;
         *) echo "unknown task $task" ;;
     esac

@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--commit", default=None, help="tree the counters were taken on (default: tools/.head_commit, written before gpurun)")
     ap.add_argument("bench", nargs=argparse.REMAINDER)
     a = ap.parse_args()
-    bench_args = [x for x in a.bench if x != "--"] + ["--steps", str(a.steps), "--warmup", "3", "--no-cpu-baseline"]
+    bench_args = [x for x in a.bench if x != "--"] + ["--steps", str(a.steps), "--warmup", "3", "--no-cpu-baseline", "--extras", "0"]
     commit = a.commit
     if commit is None:
         try:
