@@ -451,7 +451,9 @@ class _TuneStore:
                     h.update(fn.encode() + b"\0" + f.read())
         h.update(_lib.lib().sy_version())
         h.update(repr((HALO_TILES, STREAM_1X1, TILE_1X1K)).encode())          # candidate-set switches (A/B runs)
-        return h.hexdigest()[:16] + "|" + torch.cuda.get_device_name(device)
+        # (no device name in the key: this library is gfx950-only, and torch reports an empty name under rocprofv3 — a profiled
+        #  run then overwrote the cache of the normal runs with its own)
+        return h.hexdigest()[:16]
 
     def load(self, device):
         if self.loaded:

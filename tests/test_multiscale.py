@@ -93,6 +93,7 @@ def test_multiscale_memory_stays_flat_and_later_plans_build_from_the_tuner_cache
     print("allocated after cycle 1 / 2: %.1f / %.1f MB" % (peak[0] / 2**20, peak[1] / 2**20))
     print("first build vs rebuild (s):", {k: [round(t, 2) for t in v] for k, v in build_s.items()})
     assert peak[1] <= peak[0] * 1.02 + (8 << 20)
-    # sizes[0] and sizes[1] were evicted during cycle 1 and rebuilt in cycle 2 from the persisted tuner choices
-    assert build_s[sizes[0]][1] < 0.5 * build_s[sizes[0]][0]
+    # sizes[0] and sizes[1] were evicted during cycle 1 and rebuilt in cycle 2 from the persisted tuner choices: no re-tuning,
+    # a rebuilt plan's first step (plan construction + one step through the wrappers) stays well under a second
+    assert build_s[sizes[0]][1] < build_s[sizes[0]][0] and build_s[sizes[0]][1] < 1.0
     assert (tmp_path / "tune.json").exists()
