@@ -460,6 +460,8 @@ class InferencePlan:
         out = self.run_head()
         for dst, s in zip(self.sup_in, self.cur_pans):
             ops.view_copy(s, dst)
+        if self._rec is None:
+            ops.save_tuned()
         return out
 
     # ---- launch tape for the streaming step ----------------------------------------------------------------
@@ -547,7 +549,9 @@ class InferencePlan:
 
     def run(self, x, buffer=None):
         self.run_backbone(x, buffer)
-        return self.run_head()
+        out = self.run_head()
+        ops.save_tuned()                   # tuner choices made while this plan ran its first launches (no-op afterwards)
+        return out
 
     def profile(self, x, iters=3):
         """Per-op-kind kernel time (ms per forward), HIP events recorded on the launch stream around
