@@ -1,6 +1,9 @@
 // simt_emu.cpp — runtime of the test-only SIMT emulator (see simt_emu.h).
 #include "simt_emu.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 
 namespace emu {
@@ -49,7 +52,24 @@ static void fiber_main() {
 
 static constexpr size_t kStack = 192 * 1024;
 
-static void run_block(Block& blk, std::vector<unsigned char>& stacks) {
+// Fiber stacks and dynamic LDS of one worker thread: allocated once per thread and reused by every launch, UNINITIALISED (a
+// zero-filled vector of (threads + 1) x 192 KiB per worker per launch — 50-200 MB — was ~95 % of the emulator's run time, all
+// of it page faults in the kernel).
+struct Scratch {
+    std::unique_ptr<unsigned char[]> stacks, smem;
+    size_t stacks_n = 0, smem_n = 0;
+    unsigned char* stack_base(size_t n) {
+        if (n > stacks_n) { stacks.reset(new unsigned char[n]); stacks_n = n; }
+        return stacks.get();
+    }
+    unsigned char* smem_base(size_t n) {
+        if (n > smem_n) { smem.reset(new unsigned char[n]); smem_n = n; }
+        return smem.get();
+    }
+};
+static thread_local Scratch t_scratch;
+
+static void run_block(Block& blk, unsigned char* stacks) {
     const unsigned nthr = blk.bdim.x * blk.bdim.y * blk.bdim.z;
     blk.fibers.assign(nthr, Fiber());
     blk.waves.assign((nthr + 63) / 64, Wave());
@@ -62,7 +82,7 @@ static void run_block(Block& blk, std::vector<unsigned char>& stacks) {
     for (unsigned i = 0; i < nthr; ++i) {
         Fiber& f = blk.fibers[i];
         f.tid = dim3(i % blk.bdim.x, (i / blk.bdim.x) % blk.bdim.y, i / (blk.bdim.x * blk.bdim.y));
-        unsigned char* top = stacks.data() + (size_t)(i + 1) * kStack;
+        unsigned char* top = stacks + (size_t)(i + 1) * kStack;
         top = (unsigned char*)((uintptr_t)top & ~(uintptr_t)15);
         void** sp = (void**)top;
         *--sp = nullptr;                       // fake return address of fiber_main (keeps rsp%16==8 at entry)
@@ -90,6 +110,62 @@ static void run_block(Block& blk, std::vector<unsigned char>& stacks) {
     g_blk = nullptr;
 }
 
+// Persistent worker pool: the threads (and their thread-local scratch) live for the process; a launch hands them one job.
+namespace {
+struct Pool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable wake, done;
+    const std::function<void()>* job = nullptr;
+    unsigned long long gen = 0;
+    unsigned active = 0, pending = 0;
+    bool stop = false;
+
+    void loop(unsigned idx) {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            wake.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            if (idx >= active) continue;
+            const std::function<void()>* j = job;
+            lk.unlock();
+            (*j)();
+            lk.lock();
+            if (--pending == 0) done.notify_all();
+        }
+    }
+    void run(unsigned n, const std::function<void()>& fn) {
+        std::unique_lock<std::mutex> lk(m);
+        while (threads.size() < n) {
+            const unsigned idx = (unsigned)threads.size();
+            threads.emplace_back([this, idx] { loop(idx); });
+        }
+        job = &fn;
+        active = n;
+        pending = n;
+        ++gen;
+        wake.notify_all();
+        done.wait(lk, [&] { return pending == 0; });
+        job = nullptr;
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
+Pool& pool() {
+    static Pool p;
+    return p;
+}
+std::mutex g_launch_mutex;      // one emulated launch at a time per process (launches from several host threads serialise)
+}  // namespace
+
 void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body) {
     const unsigned long long nblocks = (unsigned long long)grid.x * grid.y * grid.z;
     if (nblocks == 0) return;
@@ -99,14 +175,14 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>&
     if (nworkers < 1) nworkers = 1;
     if (nworkers > nblocks) nworkers = (unsigned)nblocks;
     std::atomic<unsigned long long> next{0};
-    auto worker = [&]() {
-        std::vector<unsigned char> stacks((size_t)(nthr + 1) * kStack);
-        std::vector<unsigned char> smem(dyn_smem + 64);
+    const std::function<void()> worker = [&]() {
+        unsigned char* const stacks = t_scratch.stack_base((size_t)(nthr + 1) * kStack);
+        unsigned char* const smem = t_scratch.smem_base(dyn_smem + 64);
         Block blk;
         blk.bdim = block;
         blk.gdim = grid;
         blk.body = &body;
-        blk.dyn_smem = (unsigned char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
+        blk.dyn_smem = (unsigned char*)(((uintptr_t)smem + 63) & ~(uintptr_t)63);
         for (;;) {
             unsigned long long b = next.fetch_add(1);
             if (b >= nblocks) break;
@@ -115,9 +191,8 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>&
         }
     };
     if (nworkers == 1) { worker(); return; }
-    std::vector<std::thread> pool;
-    for (unsigned i = 0; i < nworkers; ++i) pool.emplace_back(worker);
-    for (auto& t : pool) t.join();
+    std::lock_guard<std::mutex> lk(g_launch_mutex);
+    pool().run(nworkers, worker);
 }
 
 }  // namespace emu

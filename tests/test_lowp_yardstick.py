@@ -209,8 +209,8 @@ def test_sgd_steps_track_across_modes_on_the_emulator(backend):
     this learning rate — measured here: 0, 2e-6, 2e-4, 7e-2 — so only the first steps are compared tightly.)"""
     if str(backend) != "cpu":
         pytest.skip("emulator-sized variant")
-    a = _run_curve("nano", 2, 64, 96, "fp32", 5, 5e-4, backend)
-    b = _run_curve("nano", 2, 64, 96, "fp32", 5, 5e-4, backend)
+    a = _run_curve("nano", 1, 32, 64, "fp32", 4, 5e-4, backend)
+    b = _run_curve("nano", 1, 32, 64, "fp32", 4, 5e-4, backend)
     assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
     assert len(set(np.round(a, 5))) == len(a), "the loss does not move: replayed steps do not see the updated weights"
     assert np.abs(a[:3] - b[:3]).max() / np.abs(a).max() < 1e-4

@@ -368,7 +368,7 @@ def test_submodule_training_calls_compose_like_the_reference(backend, golden_dir
 def test_submodule_training_steps_follow_changing_inputs(backend):
     """the stand-alone DFPPAFPN training plan must seed its backward with THIS call's feature gradients on
     every step — steps 3+ replay a launch tape, whose recorded torch snippets must not hold on to the recording call's
-    tensors.  Four steps on different inputs: split path (backbone -> head through autograd) vs the fused YOLOX.forward."""
+    tensors.  Three steps on different inputs: split path (backbone -> head through autograd) vs the fused YOLOX.forward."""
     cfg = O.OracleConfig.named("nano")
     sd = synth_state_dict(O.param_shapes(cfg), seed=0)
 
@@ -379,9 +379,9 @@ def test_submodule_training_steps_follow_changing_inputs(backend):
         m.head.use_l1 = True
         return m
     split, fused = fresh(), fresh()
-    for step in range(4):
-        x = synth_frames(2, 64, 96, seed=20 + step).to(backend)
-        lab, sup = synth_labels(2, 64, 96, cfg.num_classes, num_gt=6, seed=30 + step)
+    for step in range(3):                                        # call 3 is the first tape REPLAY of the split path
+        x = synth_frames(2, 32, 64, seed=20 + step).to(backend)
+        lab, sup = synth_labels(2, 32, 64, cfg.num_classes, num_gt=4, seed=30 + step)
         targets = (lab.to(backend), sup.to(backend))
         for m in (split, fused):
             for p in m.parameters():
@@ -404,10 +404,18 @@ def test_frames_as_stream_parallel_chains_match_the_paired_launches(backend, gol
     from streamyolo_amd import train_engine
     from streamyolo_amd.train_engine import TrainStep
     res = {}
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    x = synth_frames(2, 32, 64, seed=2).to(backend)
+    lab, sup = synth_labels(2, 32, 64, cfg.num_classes, num_gt=4, seed=3)
+    targets = (lab.to(backend), sup.to(backend))
     for mode, fwd, bwd in (("paired", False, "0"), ("chains", True, "1")):
         monkeypatch.setattr(train_engine, "FWD_SPLIT_FRAMES", fwd)
         monkeypatch.setattr(train_engine, "BWD_SPLIT_FRAMES", bwd)
-        z, model, x, targets = _setup("nano", "nano_train_2x64x96", golden_dir, backend, "fp32")
+        model = sy.build_model("nano")
+        model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        model = model.to(backend).train().set_compute_dtype("fp32")
+        model.head.use_l1 = True
         st = TrainStep(model, graph=False)
         assert st._ensure(x).bwd_split == (bwd == "1")
         state0 = {k: v.clone() for k, v in model.state_dict().items()}
