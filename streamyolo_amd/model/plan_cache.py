@@ -59,7 +59,9 @@ class PlanCache:
         kind = "train" if str(key[0]).startswith("train") else "inf"
         bound = self.MAX_TRAIN_PLANS if kind == "train" else self.MAX_INFER_PLANS
         same = [k for k in self.plans if ("train" if str(k[0]).startswith("train") else "inf") == kind]
-        evicted = same[:max(0, len(same) - bound)]
+        # never evict a plan whose forward has run but whose backward is still pending (its autograd node holds it)
+        over = max(0, len(same) - bound)
+        evicted = [k for k in same[:-1] if getattr(self.plans[k], "pending", 0) == 0][:over]
         for k in evicted:
             old = self.plans.pop(k)
             release = getattr(old, "release", None)

@@ -367,6 +367,7 @@ class TrainPlan:
         self.grads.py = self._py
         self.programs, self._rec, self._param_sig = {}, None, None
         self._side_region = False
+        self.pending = 0                      # forwards of the drop-in autograd node whose backward has not run yet
 
         # ---- flat gradient arena in parameter layout ------------------------------------------------
         # Parameter order of the arena = model.parameters() order, except that the parts of a merged convolution sit side by
@@ -1131,6 +1132,9 @@ class _PlanFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, x, labels, support, *params):
         ctx.plan = plan
+        ctx.counted = any(ctx.needs_input_grad)         # False under no_grad: no backward will come
+        if ctx.counted:
+            plan.pending += 1              # the plan cache must not evict (release) it before this node's backward ran
         plan.forward(x)
         out, d_raw = plan.loss(labels, support)
         ctx.d_raw = d_raw
@@ -1141,6 +1145,9 @@ class _PlanFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_stats):
         plan = ctx.plan
+        if ctx.counted:
+            plan.pending = max(0, plan.pending - 1)
+            ctx.counted = False
         arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
         return (None, None, None, None) + _arena_views(arena, plan.params)
 
