@@ -84,7 +84,10 @@ __device__ __forceinline__ void wgrad_epilogue(const WgradArgs& p, f32x16 (&acc)
                 const float v0 = acc[t][u][q * 4 + 0], v1 = acc[t][u][q * 4 + 1], v2 = acc[t][u][q * 4 + 2],
                             v3 = acc[t][u][q * 4 + 3];
                 if (p.splits > 1) {
-                    float* dst = p.part + ((long long)split * p.Cout + co) * p.K + kb;
+                    // slab layout [split][K / 4][Cout][4]: the 32 lanes of a half-wave hold 32 consecutive output channels, so
+                    // their float4 stores are one contiguous 512-byte run (the [Cout][K] layout scattered 16-byte pieces over
+                    // 32 rows per store instruction); wgrad_fold_kernel walks the slabs in this order
+                    float* dst = p.part + (((long long)split * (p.K >> 2) + (kb >> 2)) * p.Cout + co) * 4;
                     *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
                 } else if (p.oihw) {
                     const int tap = kb / p.Cin;
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
             const int kb = t * p.Cin + ci;
             const float v0 = acc[t][q * 4 + 0], v1 = acc[t][q * 4 + 1], v2 = acc[t][q * 4 + 2], v3 = acc[t][q * 4 + 3];
             if (p.splits > 1) {
-                *reinterpret_cast<float4*>(p.part + ((long long)bid.z * p.Cout + co) * p.K + kb) = make_float4(v0, v1, v2, v3);
+                *reinterpret_cast<float4*>(p.part + (((long long)bid.z * (p.K >> 2) + (kb >> 2)) * p.Cout + co) * 4) = make_float4(v0, v1, v2, v3);
             } else if (p.oihw) {
                 float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
                 row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9b_kernel(WgradArgs p) {
             const int kb = t * p.Cin + ci;
             const float v0 = acc[I][q * 4 + 0], v1 = acc[I][q * 4 + 1], v2 = acc[I][q * 4 + 2], v3 = acc[I][q * 4 + 3];
             if (p.splits > 1) {
-                *reinterpret_cast<float4*>(p.part + ((long long)bid.z * p.Cout + co) * p.K + kb) = make_float4(v0, v1, v2, v3);
+                *reinterpret_cast<float4*>(p.part + (((long long)bid.z * (p.K >> 2) + (kb >> 2)) * p.Cout + co) * 4) = make_float4(v0, v1, v2, v3);
             } else if (p.oihw) {
                 float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
                 row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
@@ -766,7 +769,9 @@ __global__ __launch_bounds__(512) void conv_wgrad9b_kernel(WgradArgs p) {
     });
 }
 
-// dW (+)= sum over splits of the partial slabs; also applies the packed -> OIHW layout change.
+// dW (+)= sum over splits of the partial slabs; also applies the slab -> packed / OIHW layout change.
+// Slabs are [split][K / 4][Cout][4] (coalesced stores in the weight-gradient kernels); the fold walks them in that order —
+// coalesced reads of the `splits` x larger side — and scatters its single read-modify-write of dW.
 // A workgroup = (256 / ZL) consecutive elements x ZL split lanes: many-split folds of small weight tensors are
 // latency bound, so the split loop is spread over ZL threads per element and combined through LDS.
 template <int ZL>
@@ -776,6 +781,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
     __shared__ float red[256];
     const long long total = (long long)Cout * K;
     const int e = threadIdx.x % E, zl = threadIdx.x / E;
+    const long long row4 = (long long)Cout * 4;
     for (long long base = (long long)blockIdx.x * E; base < total; base += (long long)gridDim.x * E) {
         const long long i = base + e;
         float v = 0.0f;
@@ -791,9 +797,11 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
             __syncthreads();
         }
         if (zl == 0 && i < total) {
-            long long o = i;
+            const long long kq = i / row4;
+            const int rem = (int)(i - kq * row4);
+            const int co = rem >> 2, k = (int)(kq * 4) + (rem & 3);
+            long long o = (long long)co * K + k;
             if (oihw) {
-                const int co = (int)(i / K), k = (int)(i - (long long)co * K);
                 const int tap = k / Cin, ci = k - tap * Cin;
                 o = (long long)co * K + (long long)ci * taps + tap;
             }
@@ -843,7 +851,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     const int max_splits = (slabs_total + 7) / 8;
     if (splits > max_splits) splits = max_splits;
     const long long slab_bytes = (long long)a.Cout * a.K * 4;
-    if (a.part == nullptr) splits = 1;
+    if (a.part == nullptr || (a.K & 3)) splits = 1;               // the slab layout is in float4 groups along K
     else if ((long long)splits * slab_bytes > ws_bytes) splits = (int)(ws_bytes / slab_bytes);
     if (splits < 1) splits = 1;
     a.slabs_per_split = (slabs_total + splits - 1) / splits;
