@@ -18,6 +18,7 @@
 // caller's workspace (plain 16-byte stores) and a fold kernel sums the slabs INTO dW (+=), which is
 // how the current-frame and support-frame passes of the shared backbone weights add up
 // (SURVEY.md §8(e)); the caller zeroes the gradient arena once per step.  Deterministic: no atomics.
+#include <stdlib.h>
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
 
@@ -34,13 +35,32 @@ struct WgradArgs {
     int oihw;                   // 1: dW laid out [Cout][Cin][KH][KW] (the nn.Parameter layout), 0: [Cout][tap][Cin]
     int tile, target_blocks;    // tuning knobs: 0 = heuristics
     unsigned x_extent, dy_extent; // bytes addressable from x / dy (0: 64-bit pointer loads)
-    float* part;                // split > 1: partial tiles [splits][Cout][K] (packed layout), folded by wgrad_fold_kernel
+    float* part;                // split > 1: partial slabs [splits][K / 4][Cout][4], folded by wgrad_fold_kernel
     int splits;
+    int part_bf16;              // slabs stored as bf16 (bf16 compute mode): half the slab traffic of the kernels and of the fold
     int ablate;                 // profiling only (tools/wgrad_probe.py): 1 = no x loads, 2 = no dy loads
 };
 
 constexpr int kPitchT = 72;
 constexpr int kThreadsW = 256;
+
+// One float4 of a split's partial slab, layout [split][K / 4][Cout][4]: the 32 lanes of a half-wave hold 32 consecutive output
+// channels, so their stores are one contiguous run (the former [Cout][K] layout scattered 16-byte pieces over 32 rows per store
+// instruction: -0.3 ms per l step, profiles/r03/q_*); wgrad_fold_kernel walks the slabs in this order.  bf16 mode stores the
+// partial sums as bf16 (the final sum over the splits is fp32): the reference's own autocast returns the whole weight gradient
+// of a bf16 convolution rounded to bf16 (torch conv backward under autocast), so this is no coarser than the reference.
+__device__ __forceinline__ void wgrad_store_slab(const WgradArgs& p, int split, int co, int kb, float v0, float v1, float v2,
+                                                 float v3) {
+    const long long g = ((long long)split * (p.K >> 2) + (kb >> 2)) * p.Cout + co;
+    if (p.part_bf16) {
+        uint2 u;
+        u.x = BF16::pack2(v0, v1);
+        u.y = BF16::pack2(v2, v3);
+        reinterpret_cast<uint2*>(p.part)[g] = u;
+    } else {
+        reinterpret_cast<float4*>(p.part)[g] = make_float4(v0, v1, v2, v3);
+    }
+}
 
 struct PixelCursor {            // (n, ho, wo) of one output pixel, advanced slab by slab
     int n, ho, wo, m;
@@ -84,11 +104,7 @@ __device__ __forceinline__ void wgrad_epilogue(const WgradArgs& p, f32x16 (&acc)
                 const float v0 = acc[t][u][q * 4 + 0], v1 = acc[t][u][q * 4 + 1], v2 = acc[t][u][q * 4 + 2],
                             v3 = acc[t][u][q * 4 + 3];
                 if (p.splits > 1) {
-                    // slab layout [split][K / 4][Cout][4]: the 32 lanes of a half-wave hold 32 consecutive output channels, so
-                    // their float4 stores are one contiguous 512-byte run (the [Cout][K] layout scattered 16-byte pieces over
-                    // 32 rows per store instruction); wgrad_fold_kernel walks the slabs in this order
-                    float* dst = p.part + (((long long)split * (p.K >> 2) + (kb >> 2)) * p.Cout + co) * 4;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+                    wgrad_store_slab(p, split, co, kb, v0, v1, v2, v3);
                 } else if (p.oihw) {
                     const int tap = kb / p.Cin;
                     const int ci = kb - tap * p.Cin;
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
             const int kb = t * p.Cin + ci;
             const float v0 = acc[t][q * 4 + 0], v1 = acc[t][q * 4 + 1], v2 = acc[t][q * 4 + 2], v3 = acc[t][q * 4 + 3];
             if (p.splits > 1) {
-                *reinterpret_cast<float4*>(p.part + (((long long)bid.z * (p.K >> 2) + (kb >> 2)) * p.Cout + co) * 4) = make_float4(v0, v1, v2, v3);
+                wgrad_store_slab(p, bid.z, co, kb, v0, v1, v2, v3);
             } else if (p.oihw) {
                 float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
                 row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
@@ -755,7 +771,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9b_kernel(WgradArgs p) {
             const int kb = t * p.Cin + ci;
             const float v0 = acc[I][q * 4 + 0], v1 = acc[I][q * 4 + 1], v2 = acc[I][q * 4 + 2], v3 = acc[I][q * 4 + 3];
             if (p.splits > 1) {
-                *reinterpret_cast<float4*>(p.part + (((long long)bid.z * (p.K >> 2) + (kb >> 2)) * p.Cout + co) * 4) = make_float4(v0, v1, v2, v3);
+                wgrad_store_slab(p, bid.z, co, kb, v0, v1, v2, v3);
             } else if (p.oihw) {
                 float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
                 row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9b_kernel(WgradArgs p) {
 // coalesced reads of the `splits` x larger side — and scatters its single read-modify-write of dW.
 // A workgroup = (256 / ZL) consecutive elements x ZL split lanes: many-split folds of small weight tensors are
 // latency bound, so the split loop is spread over ZL threads per element and combined through LDS.
-template <int ZL>
+template <int ZL, bool BF>
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, float* dw, int Cout, int K, int Cin, int taps,
                                                          int splits, int oihw) {
     constexpr int E = 256 / ZL;
@@ -786,7 +802,8 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
         const long long i = base + e;
         float v = 0.0f;
         if (i < total)
-            for (int z = zl; z < splits; z += ZL) v += part[(long long)z * total + i];
+            for (int z = zl; z < splits; z += ZL)
+                v += BF ? BF16::to_f32(reinterpret_cast<const unsigned short*>(part)[(long long)z * total + i]) : part[(long long)z * total + i];
         if (ZL > 1) {
             red[threadIdx.x] = v;
             __syncthreads();
@@ -808,6 +825,27 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
             dw[o] += v;
         }
     }
+}
+
+
+// fold launch: ZL split lanes per element by split count, slab element type by mode
+static int launch_fold(const WgradArgs& a, int splits, int taps, void* stream) {
+    const long long work = (long long)a.Cout * a.K;
+    auto grid_for = [&](int e) { long long b = (work + e - 1) / e; return (int)(b > 4096 ? 4096 : b); };
+#define SY_FOLD(ZL, E)                                                                                                       \
+    do {                                                                                                                     \
+        if (a.part_bf16)                                                                                                     \
+            SY_LAUNCH((wgrad_fold_kernel<ZL, true>), dim3(grid_for(E)), dim3(256), 0, stream, (const float*)a.part, a.dw,    \
+                      a.Cout, a.K, a.Cin, taps, splits, a.oihw);                                                             \
+        else                                                                                                                 \
+            SY_LAUNCH((wgrad_fold_kernel<ZL, false>), dim3(grid_for(E)), dim3(256), 0, stream, (const float*)a.part, a.dw,   \
+                      a.Cout, a.K, a.Cin, taps, splits, a.oihw);                                                             \
+    } while (0)
+    if (splits >= 64) SY_FOLD(16, 16);
+    else if (splits >= 16) SY_FOLD(4, 64);
+    else SY_FOLD(1, 256);
+#undef SY_FOLD
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
 template <typename T, int WR, int WC, int TR, int TC, int STG, int LIN>
@@ -870,19 +908,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
         SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
     }
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
-    if (splits > 1) {
-        const long long work = (long long)a.Cout * a.K;
-        auto grid_for = [&](int e) { long long b = (work + e - 1) / e; return (int)(b > 4096 ? 4096 : b); };
-        if (splits >= 64)
-            SY_LAUNCH(wgrad_fold_kernel<16>, dim3(grid_for(16)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
-                      a.Cin, a.KH * a.KW, splits, a.oihw);
-        else if (splits >= 16)
-            SY_LAUNCH(wgrad_fold_kernel<4>, dim3(grid_for(64)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
-                      a.Cin, a.KH * a.KW, splits, a.oihw);
-        else
-            SY_LAUNCH(wgrad_fold_kernel<1>, dim3(grid_for(256)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
-                      a.Cin, a.KH * a.KW, splits, a.oihw);
-    }
+    if (splits > 1) return launch_fold(a, splits, a.KH * a.KW, stream);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
@@ -922,19 +948,7 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
             SY_LAUNCH((conv_wgrad9_kernel<T, STG>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
         }
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
-        if (splits > 1) {
-            const long long work = (long long)a.Cout * a.K;
-            auto grid_for = [&](int e) { long long b = (work + e - 1) / e; return (int)(b > 4096 ? 4096 : b); };
-            if (splits >= 64)
-                SY_LAUNCH(wgrad_fold_kernel<16>, dim3(grid_for(16)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
-                          a.Cin, 9, splits, a.oihw);
-            else if (splits >= 16)
-                SY_LAUNCH(wgrad_fold_kernel<4>, dim3(grid_for(64)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
-                          a.Cin, 9, splits, a.oihw);
-            else
-                SY_LAUNCH(wgrad_fold_kernel<1>, dim3(grid_for(256)), dim3(256), 0, stream, (const float*)a.part, a.dw, a.Cout, a.K,
-                          a.Cin, 9, splits, a.oihw);
-        }
+        if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
     }
 }
@@ -992,6 +1006,8 @@ extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
     a.target_blocks = d->target_blocks;
     a.part = (float*)d->workspace;
     a.splits = 1;
+    static const bool slab_bf16 = [] { const char* e = getenv("SY_WGRAD_SLAB_BF16"); return e == nullptr || atoi(e) != 0; }();
+    a.part_bf16 = (d->dtype == SY_DT_BF16 && slab_bf16) ? 1 : 0;
     const long long wsb = d->workspace != nullptr ? (long long)d->workspace_bytes : 0;
     switch (d->dtype) {
         case SY_DT_BF16: return launch_wgrad_typed<BF16>(a, wsb, stream);

@@ -256,7 +256,9 @@ def test_wgrad_all_taps_kernel(backend, tile, N, cin, cout, H, W):
     ops.conv2d_wgrad(xv, dyv, dw3, 3, 1, workspace=ws, tile=17, target_blocks=8)
     dw4 = torch.zeros(cout, 9 * cin, device=backend)
     ops.conv2d_wgrad(xv, dyv, dw4, 3, 1, workspace=ws, tile=tile, target_blocks=8)
-    assert _rel(dw4.cpu(), dw3.cpu()) < 1e-4
+    # the two kernels cut the pixel range into different splits, and in bf16 mode the split-K slabs are stored as bf16 (fp32
+    # fold): they agree to the slab rounding (2^-9 per partial sum), both within the bf16 bound of the torch reference above
+    assert _rel(dw4.cpu(), dw3.cpu()) < 1e-2
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W", [(64, 72, 2, 7, 9), (128, 160, 4, 5, 13), (256, 128, 2, 9, 11), (128, 64, 2, 16, 33)])
