@@ -793,59 +793,45 @@ __global__ __launch_bounds__(512) void conv_wgrad9b_kernel(WgradArgs p) {
 template <int ZL, bool BF>
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, float* dw, int Cout, int K, int Cin, int taps,
                                                          int splits, int oihw) {
-    // one thread = one float4 GROUP of the slab order (4 consecutive k of one output channel): 16-byte (8-byte in bf16 mode) loads
-    // per split instead of 4-byte (2-byte) ones — the fold moves `splits` x the weight tensor and is purely bandwidth bound
     constexpr int E = 256 / ZL;
-    __shared__ float4 red[256];
-    const long long groups = ((long long)Cout * K) >> 2;
+    __shared__ float red[256];
+    const long long total = (long long)Cout * K;
     const int e = threadIdx.x % E, zl = threadIdx.x / E;
-    for (long long base = (long long)blockIdx.x * E; base < groups; base += (long long)gridDim.x * E) {
-        const long long g = base + e;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (g < groups)
-            for (int z = zl; z < splits; z += ZL) {
-                if (BF) {
-                    const uint2 u = reinterpret_cast<const uint2*>(part)[(long long)z * groups + g];
-                    v.x += BF16::to_f32((unsigned short)(u.x & 0xffffu)); v.y += BF16::to_f32((unsigned short)(u.x >> 16));
-                    v.z += BF16::to_f32((unsigned short)(u.y & 0xffffu)); v.w += BF16::to_f32((unsigned short)(u.y >> 16));
-                } else {
-                    const float4 u = reinterpret_cast<const float4*>(part)[(long long)z * groups + g];
-                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
-            }
+    const long long row4 = (long long)Cout * 4;
+    for (long long base = (long long)blockIdx.x * E; base < total; base += (long long)gridDim.x * E) {
+        const long long i = base + e;
+        float v = 0.0f;
+        if (i < total)
+            for (int z = zl; z < splits; z += ZL)
+                v += BF ? BF16::to_f32(reinterpret_cast<const unsigned short*>(part)[(long long)z * total + i]) : part[(long long)z * total + i];
         if (ZL > 1) {
             red[threadIdx.x] = v;
             __syncthreads();
             if (zl == 0) {
 #pragma unroll
-                for (int k = 1; k < ZL; ++k) {
-                    const float4 u = red[k * E + e];
-                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
+                for (int k = 1; k < ZL; ++k) v += red[k * E + e];
             }
             __syncthreads();
         }
-        if (zl == 0 && g < groups) {
-            const long long kq = g / Cout;
-            const int co = (int)(g - kq * Cout), k = (int)(kq * 4);
-            if (oihw) {                                             // the four k share one tap (Cin % 4 == 0)
+        if (zl == 0 && i < total) {
+            const long long kq = i / row4;
+            const int rem = (int)(i - kq * row4);
+            const int co = rem >> 2, k = (int)(kq * 4) + (rem & 3);
+            long long o = (long long)co * K + k;
+            if (oihw) {
                 const int tap = k / Cin, ci = k - tap * Cin;
-                float* row = dw + (long long)co * K + (long long)ci * taps + tap;
-                row[0] += v.x; row[taps] += v.y; row[2 * taps] += v.z; row[3 * taps] += v.w;
-            } else {
-                float4* d = reinterpret_cast<float4*>(dw + (long long)co * K + k);
-                float4 o = *d;
-                o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-                *d = o;
+                o = (long long)co * K + (long long)ci * taps + tap;
             }
+            dw[o] += v;
         }
     }
 }
 
+
 // fold launch: ZL split lanes per element by split count, slab element type by mode
 static int launch_fold(const WgradArgs& a, int splits, int taps, void* stream) {
-    const long long work = ((long long)a.Cout * a.K) >> 2;                  // float4 groups
-    auto grid_for = [&](int e) { long long b = (work + e - 1) / e; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+    const long long work = (long long)a.Cout * a.K;
+    auto grid_for = [&](int e) { long long b = (work + e - 1) / e; return (int)(b > 4096 ? 4096 : b); };
 #define SY_FOLD(ZL, E)                                                                                                       \
     do {                                                                                                                     \
         if (a.part_bf16)                                                                                                     \
