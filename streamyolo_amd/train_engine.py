@@ -126,7 +126,9 @@ class StagedWeights:
     exps/train_utils/double_trainer.py:114-119 — so nothing here is cached across steps).  Same lookup surface as
     engine.ParamCache: conv_weight / conv_weight_frag / pred."""
 
-    def __init__(self, plan_ops, dtype, device):
+    def __init__(self, plan_ops, dtype, device, early_ops=0):
+        """early_ops: the first `early_ops` ops of the plan get their weights from a separate (small) table, staged on the
+        critical path; the rest ("late") may be staged beside them on another stream (TrainPlan._forward_ops)."""
         from . import _lib
         self.dtype, self.device = dtype, device
         tdt = ops.TORCH_DTYPE[dtype]
@@ -151,7 +153,10 @@ class StagedWeights:
             return None if t is None else t.data_ptr()
 
         self.bn = {}                     # id(MergedConv) -> (gamma stack, beta stack) fp32, refreshed with the weights
-        for op in plan_ops:
+        n_early_rows = 0
+        for op_i, op in enumerate(plan_ops):
+            if op_i == early_ops:
+                n_early_rows = len(rows)
             if op.kind == "conv" and id(op.mod) not in self.conv:
                 parts = base_convs(op.mod)                                 # one BaseConv, or the stacked parts of a MergedConv
                 w0 = parts[0].conv.weight
@@ -188,17 +193,27 @@ class StagedWeights:
                 entry(op.reg_mod.bias, b_ro, None, None, None, 4, 1, 1, 0, 5, 5, 1, ops.DTYPE_NAME["fp32"])
                 entry(op.obj_mod.bias, b_ro, None, None, None, 1, 1, 1, 4, 5, 5, 1, ops.DTYPE_NAME["fp32"])
                 self.preds[id(op)] = (w_ro, b_ro, w_c, op.cls_mod.bias, w_ro_t, w_c_t)
-        arr, self.total_tiles = _lib.pack_table(rows)
-        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        if early_ops >= len(plan_ops):
+            n_early_rows = len(rows)
+        self.tables = []                 # [(device table, entries, tiles)]: early part, late part
+        for part in ((rows[:n_early_rows], rows[n_early_rows:]) if 0 < n_early_rows < len(rows) else (rows,)):
+            arr, tiles = _lib.pack_table(part)
+            self.tables.append((torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(part), tiles))
         self.n = len(rows)
         self.sig = tuple(t.data_ptr() for t in self.sources)
 
     def valid(self):
         return self.sig == tuple(t.data_ptr() for t in self.sources)
 
-    def refresh(self):
-        ops.check(ops._lib.lib().sy_pack_weights(self.table.data_ptr(), self.n, self.total_tiles, ops.stream_of(self.table)),
-                  "sy_pack_weights")
+    @property
+    def has_late(self):
+        return len(self.tables) > 1
+
+    def refresh(self, part=None):
+        """Stage the weights: part None = everything, 0 = the early table, 1 = the late table."""
+        for i, (table, n, tiles) in enumerate(self.tables):
+            if part is None or part == i:
+                ops.check(ops._lib.lib().sy_pack_weights(table.data_ptr(), n, tiles, ops.stream_of(table)), "sy_pack_weights")
 
     def conv_weight(self, mod, transpose=False):
         return self.conv[id(mod)][1 if transpose else 0]
@@ -223,6 +238,9 @@ MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
 # other's MFMA-bound convolutions.  Measured (profiles/r03/f_*): 23.18-23.24 vs 24.02 ms per l step at 8 pairs, 14.75 vs 15.28
 # at 4 — although the half-size kernels are individually slower (kernel sum 18.9 vs 18.0 ms).
 FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "1") != "0"
+# sy_pack_weights (0.25 ms for l, on the critical path in front of the stem) split in two: stem + dark2 weights at once, the rest
+# on an idle stream beside those layers' forward
+LATE_WEIGHT_STAGING = os.environ.get("STREAMYOLO_LATE_WEIGHT_STAGING", "1") != "0"
 # ... and in the backward pass: BatchNorm backward + data gradient of the two frames as chains on streams 0 and 2, the (paired)
 # weight gradient of the layer on stream 1 behind both.
 # Measured (profiles/r03/g_*, j_*): l at 8 pairs 22.7-23.0 vs 23.36 ms, l at 4 pairs 14.79 vs 14.75, m 15.45 (both) vs 15.83 (none),
@@ -359,7 +377,7 @@ class TrainPlan:
         for op in self.ops:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
-        self.cache = StagedWeights(self.ops, self.dtype, device)
+        self.cache = StagedWeights(self.ops, self.dtype, device, early_ops=self._early_ops())
         self._find_norm_consumers()
         self.loss_ws = None
         self.run_table = None
@@ -494,8 +512,9 @@ class TrainPlan:
             self._param_sig = sig
             self.programs.clear()                                # the tapes hold raw pointers
             if not self.cache.valid():
-                self.cache = StagedWeights(self.ops, self.dtype, self.device)
-        self.cache.refresh()                                     # this step's weights -> MFMA operand layouts
+                self.cache = StagedWeights(self.ops, self.dtype, self.device, early_ops=self._early_ops())
+        # this step's weights -> MFMA operand layouts: the first layers' now, the rest beside them (inside the forward pass)
+        self.cache.refresh(0 if (self.cache.has_late and LATE_WEIGHT_STAGING) else None)
         self.stat_arena.zero_()
         if self.parts == "head":                                 # x = the three fused FPN features (NCHW-shaped tensors)
             for v, t in zip(self.fused, x):
@@ -527,21 +546,46 @@ class TrainPlan:
             torch._foreach_add_(list(ts), list(cs))
         return self.raw if self.head is not None else self.fused
 
+    def _early_ops(self):
+        """Number of leading plan ops whose weights are staged on the critical path: stem + dark2 of the frame network (a few
+        hundred thousand parameters, ~10 us); everything else is staged on another stream while those layers run."""
+        if not LATE_WEIGHT_STAGING or self.n_frame_ops == 0:
+            return len(self.ops)
+        n = 0
+        for op in self.ops[:self.n_frame_ops]:
+            if op.kind == "conv" and not (op.tag == "stem" or op.tag.startswith("dark2")):
+                break
+            n += 1
+        return n
+
     def _forward_ops(self):
         """The op loop in launch order.  The per-frame network runs ONCE over both frames (2B images per launch, one
         statistics segment per frame — the reference's two backbone passes, dfp_pafpn.py:120-165); after the DFP
         fusion the three head levels fan out over the two streams."""
         nf = self.n_frame_ops
+        late = self.cache.has_late and LATE_WEIGHT_STAGING
+        n_early = self._early_ops() if late else 0
+        ws = WGRAD_STREAMS[-1] if len(WGRAD_STREAMS) > 1 else 2          # a stream that idles during the forward pass
+        if late:
+            self._mark("dep", (0, ws))
+            self._mark("cur", ws)
+            self.cache.refresh(1)                                    # the bulk of the weights, beside stem + dark2
+            self._mark("cur", 0)
         if FWD_SPLIT_FRAMES and nf:
-            # experiment: the two frames as two independent chains, current frame on the main stream, support frame on the side
-            # stream, issued alternately (half-size launches, but one chain's tails and BatchNorm passes fill the other's gaps)
+            # the two frames as two independent chains, current frame on the main stream, support frame on the side stream,
+            # issued alternately (half-size launches, but one chain's tails and BatchNorm passes fill the other's gaps)
             self._mark("fork")
             for i in range(nf):
+                if late and i == n_early:
+                    self._mark("dep", (ws, 0))
+                    self._mark("dep", (ws, 1))
                 self._forward_op(self.ops[i])
                 self._mark("side_nw")
                 self._forward_op(self.ops[nf + i])
                 self._mark("main", None)
             self._mark("join")
+        elif late:
+            self._mark("dep", (ws, 0))                               # paired launches: no overlap window, wait at once
         for i in range(nf if not (FWD_SPLIT_FRAMES and nf) else 0):
             a, b2 = self.ops[i], self.ops[nf + i]
             if a.kind == "conv":
