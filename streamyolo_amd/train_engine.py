@@ -239,8 +239,8 @@ MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
 # at 4 — although the half-size kernels are individually slower (kernel sum 18.9 vs 18.0 ms).
 FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "1") != "0"
 # sy_pack_weights (0.25 ms for l, on the critical path in front of the stem) split in two: stem + dark2 weights at once, the rest
-# on an idle stream beside those layers' forward
-LATE_WEIGHT_STAGING = os.environ.get("STREAMYOLO_LATE_WEIGHT_STAGING", "1") != "0"
+# on an idle stream beside those layers' forward.  Measured neutral (22.45-22.55 vs 22.48-22.50 ms, profiles/r03/t_*): off.
+LATE_WEIGHT_STAGING = os.environ.get("STREAMYOLO_LATE_WEIGHT_STAGING", "0") != "0"
 # ... and in the backward pass: BatchNorm backward + data gradient of the two frames as chains on streams 0 and 2, the (paired)
 # weight gradient of the layer on stream 1 behind both.
 # Measured (profiles/r03/g_*, j_*): l at 8 pairs 22.7-23.0 vs 23.36 ms, l at 4 pairs 14.79 vs 14.75, m 15.45 (both) vs 15.83 (none),

@@ -428,7 +428,10 @@ def test_frames_as_stream_parallel_chains_match_the_paired_launches(backend, gol
     assert abs(la - lb) / abs(la) < 1e-6
     by_name = lambda plan, names, arena: {names[id(p)]: plan.gview[id(p)] for p in plan.params}      # noqa: E731
     A, Bm = by_name(pa, na, ga), by_name(pb, nb, gb)
+    # the emulator's float atomics are ordered; on the GPU the BatchNorm statistics of the two schedules are summed in different
+    # orders and the difference is amplified down to the stem (1.7e-4 measured on its weight gradient, fp32 mode)
+    tol = 1e-5 if str(backend) == "cpu" else 1e-3
     for k in A:
-        assert _rel(Bm[k].cpu(), A[k].cpu()) < 1e-5, k
+        assert _rel(Bm[k].cpu(), A[k].cpu()) < tol, k
     for k in ra:
-        assert _rel(rb[k], ra[k]) < 1e-6, k
+        assert _rel(rb[k], ra[k]) < (1e-6 if str(backend) == "cpu" else 1e-5), k
