@@ -9,6 +9,12 @@ from test_lowp_yardstick import _oracle_grads, NAMES
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 cfg, sd, x, lab, sup, ref, rgrads = _oracle_grads("l", B, 600, 960, 16)
+if os.environ.get("DIRTY"):
+    # fill the caching allocator's free blocks with a poison value: every torch.empty buffer of the plan then starts dirty
+    poison = float(os.environ["DIRTY"])
+    junk = [torch.full((1 << 28,), poison, device=dev) for _ in range(40)]      # 40 GiB
+    junk += [torch.full((1 << 22,), poison, device=dev) for _ in range(256)]
+    del junk
 model = sy.build_model("l"); model.load_state_dict(sd, strict=True)
 model = model.to(dev).train().set_compute_dtype("fp32"); model.head.use_l1 = True
 for it in range(2):
