@@ -125,8 +125,8 @@ def test_16bit_step_within_2x_of_the_references_own_autocast_error(golden_dir, n
 def test_headline_batch_l_8x600x960_exact_mode_vs_oracle():
     """BASELINE.json configs[2]'s own batch — StreamYOLO-l, EIGHT 600x960 frame pairs: 8 images x 2 frames per statistics
     segment, a full SimOTA batch — in the exact-fp32 mode against the oracle's autograd on the host cores: the loss dict within
-    1e-3 (north_star's bound), the parameter gradients within 1e-2 of their own norms in the bulk (median, 95th percentile 2e-2)
-    and every gradient norm within 2e-3 of the largest."""
+    1e-3 (north_star's bound), the SimOTA foreground mask equal to the oracle's up to anchors at a rounding-level tie, and —
+    with identical assignments — every parameter gradient within 2e-2 of its own norm."""
     from streamyolo_amd import _lib
     _lib.use_library(_lib.DEFAULT_PATH)
     dev = torch.device("cuda:0")
@@ -147,14 +147,24 @@ def test_headline_batch_l_8x600x960_exact_mode_vs_oracle():
     for e_, n_ in errs[-24:]:
         print("    %.3e  %s" % (e_, n_))
     assert lerr < 1e-3
-    # 393 parameters; the median is 3e-3 and on most boxes the worst is < 1e-2, but a single small BatchNorm-gamma gradient (a sum
-    # of 2 x 18 240 cancelling terms, accumulated through order-dependent fp32 atomics) reached 7.7e-2 once: bound the bulk
-    # tightly, the tail loosely, and the gradient norms like the batch-1 test does
+    # SimOTA's dynamic-k matching is a discrete decision: of ~1000 matched anchors in this batch, one whose cost sits within fp32
+    # rounding of the k-th best can flip between two runs of the SAME code (atomics-order noise in the BatchNorm statistics), and the
+    # gradients of ~170 backbone parameters then move by 1-8 % while the loss moves by 1e-6 (tools/diag_steps.py: step-to-step
+    # differences of 7.7e-2 in 2 of 5 identical runs, 4e-3 otherwise).  So: compare OUR foreground mask with the oracle's; with
+    # identical assignments every gradient must be within 2e-2 of its own norm (measured worst 5e-3); with a flipped anchor the bulk
+    # still must (median), the tail is bounded loosely, and at most a handful of anchors may differ.
+    plan = next(p_ for k_, p_ in model._plans.plans.items() if str(k_[0]).startswith("train"))
+    fg_ours = plan.loss_ws.fg.cpu().numpy() != 0
+    fg_ref = np.asarray(ref["_fg_mask"].numpy() if torch.is_tensor(ref["_fg_mask"]) else np.stack([m.numpy() for m in ref["_fg_mask"]])) != 0
+    flips = int((fg_ours.reshape(fg_ref.shape) != fg_ref).sum())
     vals = np.array([e for e, _ in errs])
-    assert np.median(vals) < 1e-2 and vals[int(0.95 * (len(vals) - 1))] < 2e-2 and vals[-1] < 0.25, (vals[-5:], errs[-1])
+    print("    foreground anchors: ours %d, oracle %d, differing %d" % (int(fg_ours.sum()), int(fg_ref.sum()), flips))
+    assert flips <= 4
+    assert np.median(vals) < 1e-2
+    assert vals[-1] < (2e-2 if flips == 0 else 0.25), (flips, errs[-3:])
     gn = np.array([float(p.grad.detach().double().norm()) for _, p in model.named_parameters()])
     rn = np.array([float(rgrads[n].norm()) for n, _ in model.named_parameters()])
-    assert np.abs(gn - rn).max() / rn.max() < 2e-3
+    assert np.abs(gn - rn).max() / rn.max() < (2e-3 if flips == 0 else 2e-2)
     # bf16 at the same batch: the benchmarked mode produces the same loss dict to the bound asserted at batch 1
     model.set_compute_dtype("bf16")
     for p in model.parameters():
