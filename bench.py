@@ -201,6 +201,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and args.path == "dropin":
+        raise SystemExit("bench.py: --path dropin times the single-process boundary; the multi-GPU measurement is the default path "
+                         "(the drop-in path under DDP is covered by tests/test_distributed_gloo.py)")
     dist = None
     if EMU_SELFTEST:
         from streamyolo_amd import _lib
@@ -468,7 +471,7 @@ def main():
                                                  "GPUs) per-GPU load, the 1-GPU denominator of its weak-scaling efficiency"}
 
     comm = None
-    if workload == "train" and world > 1:
+    if workload == "train" and world > 1 and stepper.plan is not None:
         pl = stepper.plan
         comm = {"backend": "gloo (emulator self-test)" if EMU_SELFTEST else "nccl (RCCL over xGMI)",
                 "allreduce_bytes_per_step": int(pl.arena.numel()) * 4, "buckets": len(pl.buckets),
