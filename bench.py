@@ -69,6 +69,8 @@ def parse():
                     help="stream: 'all' = random-init weights as they are — EVERY one of the 11 850 anchors passes conf 0.01, the NMS "
                          "worst case; 'realistic' = the objectness biases are shifted (calibrated on the synthetic frame, before the "
                          "timed region) so that ~1 %% of the anchors pass, as with a trained checkpoint")
+    ap.add_argument("--split-k", type=int, default=1,
+                    help="stream: split-K for the deep small-map 3x3 layers (16-bit modes; tuned per layer, off where it does not pay)")
     ap.add_argument("--extras", type=int, default=1,
                     help="train, 1 GPU, default path: after the timed region also time (a) the drop-in boundary "
                          "(model(x, targets)['total_loss'].backward(), the unchanged trainer's call sequence) and (b) the same "
@@ -299,6 +301,7 @@ def main():
             raw = raw.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
             frame = FramePairsU8(raw, None, (args.height, args.width), decimate=2)
         plan = model._plans.inference(model.backbone, model.head, "on_pipe", frame, owner=model)
+        plan.allow_split_k = bool(args.split_k) and args.dtype != "fp32"       # what StreamingDetector does in the 16-bit modes
         graph = None
         n_candidates = None
         if args.candidates == "realistic":
@@ -469,6 +472,29 @@ def main():
                                          "host_launch_ms_per_step": round(hst, 3),
                                          "what": "same step at 4 frame pairs / GPU: BASELINE.json configs[3] (global batch 32 on 8 "
                                                  "GPUs) per-GPU load, the 1-GPU denominator of its weak-scaling efficiency"}
+
+    if workload == "stream" and world == 1 and args.extras and plan.allow_split_k:
+        # the same step with every layer on its single-pass kernel: what split-K buys at batch 1 (same process, same box)
+        chosen = [(op.x.H, op.x.W, op.x.C, op.y.C) + tuple(op._tiles["splitk"]) for op in plan.ops
+                  if op.kind == "conv" and op._tiles.get("splitk", (1,))[0] > 1]
+        extras = {"split_k_layers": [{"H": h, "W": w_, "Cin": ci, "Cout": co, "splits": s_, "tile": t_} for h, w_, ci, co, s_, t_ in chosen]}
+        if chosen:
+            plan.allow_split_k = False
+            plan._stream_tape = None
+            if args.graph == 1:
+                with torch.no_grad():
+                    plan.run_stream(frame, first=True)
+                for _ in range(2):
+                    eager()
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    eager()
+            ks = max(20, args.steps // 2)
+            el, hst, _ = timed(step, 5, ks)
+            extras["single_pass"] = {"ms_per_step": el / ks * 1e3, "steps": ks,
+                                     "what": "same step, --split-k 0 (every 3x3 layer as one pass over its input channels)"}
+            plan.allow_split_k = True
 
     comm = None
     if workload == "train" and world > 1 and stepper.plan is not None:

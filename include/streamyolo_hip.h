@@ -93,7 +93,11 @@ typedef struct sy_conv_desc {
     const float* in_scale;
     const float* in_shift;
     int32_t in_segments;
-    int32_t reserved;
+    /* k_splits S > 1 (tiles 117 / 118, forward, y_f32 = 1, SY_EPI_LINEAR, no scale / shift / res / statistics): the channel slabs
+       of the contraction are cut into S ranges, one per gridDim.z; split z writes its fp32 PARTIAL sums as images [z*N, (z+1)*N) of
+       y (which must hold S*N images, batch stride ybs).  sy_splitk_epilogue sums the partials and applies the epilogue.  For the
+       deep small-map layers of the batch-1 streaming step: 36-72 workgroups become 144-288. */
+    int32_t k_splits;
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.
@@ -304,6 +308,12 @@ SY_API int sy_resize_nearest_bwd(const void* dout, int N, int Ho, int Wo, int C,
 /* backward of sy_spp_pool: dbuf holds grads of the 4 slices; routes pooled grads to their arg-max into slice 0 */
 SY_API int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int W, int C, int ld, int64_t bs,
                     int dtype, void* stream);
+
+/* Second half of a split-K convolution (sy_conv_desc::k_splits): y[p][c] = act(scale[c] * sum_z part[z][p][c] + shift[c]) (+ res),
+ * part = fp32 [splits][pixels][C] dense, act per `epilogue` (SY_EPI_LINEAR | SY_EPI_SILU), y / res views in `dtype` with pixel
+ * strides ldy / ldr.  The partials are summed in split order (deterministic). */
+SY_API int sy_splitk_epilogue(const float* part, int splits, int64_t pixels, int C, const float* scale, const float* shift,
+                              const void* res, int ldr, void* y, int ldy, int dtype, int epilogue, void* stream);
 
 /* ---- small fp32 helpers of the backward plan ---------------------------------------------------------------------
  * sy_rows_add_f32: dst[r][0..cols) += src[r][0..cols) for r < rows (row pitches in elements); zero_src != 0 zeroes the

@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
         ("xbs", C.c_int64), ("ybs", C.c_int64), ("rbs", C.c_int64),
         ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
         ("accumulate", C.c_int32), ("dec_stride", C.c_float), ("stat_copies", C.c_int32), ("stat_segments", C.c_int32), ("tile", C.c_int32), ("x_bytes", C.c_int64), ("w_bytes", C.c_int64), ("wfrag", C.c_void_p), ("wfrag_bytes", C.c_int64),
-        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_segments", C.c_int32), ("reserved", C.c_int32),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_segments", C.c_int32), ("k_splits", C.c_int32),
     ]
 
 
@@ -108,6 +108,7 @@ SIGNATURES = {
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),
+    "sy_splitk_epilogue": (_I, [_P, _I, _L, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sy_rows_add_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
     "sy_pred_grad_fold_workspace_floats": (_L, [_I]),
     "sy_pred_grad_fold": (_I, [_P, _I, _L, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

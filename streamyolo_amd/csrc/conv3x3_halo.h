@@ -240,7 +240,13 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
         voff[i] = ok ? (unsigned)((((long long)n * p.xbs + ((long long)h * p.W + w) * p.ldx) + chunk * EPC) * ESZ) : 0xFFFFFFFFu;
     }
     const sy_lds_base_t lds0 = sy_lds_base(smem);
-    const int ncs = p.Cin / BK;
+    // split-K (p.ksplit > 1): this workgroup contracts channel slabs [cs_begin, ncs) of the layer only (gridDim.z ranges) and
+    // writes fp32 partial sums; `ncs` below is the END of its range
+    const int ncs_all = p.Cin / BK;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int kz = ksplit > 1 ? bid.z : 0;
+    const int cs_begin = sy_uniform((kz * ncs_all) / ksplit);
+    const int ncs = sy_uniform(((kz + 1) * ncs_all) / ksplit);
     auto issue_piece = [&](auto i_, int cslab) {           // piece I of slab `cslab` (out of range past the last slab)
         constexpr int I = decltype(i_)::value;
         const unsigned s_x = (unsigned)(cslab * BK * ESZ);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
 #pragma unroll
     for (int t = 0; t < TC; ++t) {
         const int ct = bid.x * (CT / 32) + wc * TC + t;
-        foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
+        foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs_all * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
     }
     uint4 fr[9][TC][2];
     auto fetch = [&](auto tap_, int cslab) {               // fragments of tap TAP of slab `cslab` into their slot
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
         }
     }
 
-    sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, 0); });
-    sy_static_for<0, 9>([&](auto t_) { fetch(t_, 0); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
+    sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, cs_begin); });
+    sy_static_for<0, 9>([&](auto t_) { fetch(t_, cs_begin); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
     // NORM: the input affine [Cin] x {scale, shift} of this image's segment is parked behind the two halo buffers.  Its global
     // loads are issued AFTER the first slab's DMA pieces and fragment fetches (they ride in the same in-order VMEM queue, so
     // the workgroup does not pay a serial load latency in front of its first slab — that cost ~7 us per launch in situ).
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
         }
         __syncthreads();                          // LDS writes visible to every wave (waits lgkmcnt as well)
     }
-    for (int cs = 0; cs < ncs; ++cs) {
+    for (int cs = cs_begin; cs < ncs; ++cs) {
         sy_wait_vmcnt<(9 - NI) * 2 * TC>();      // the slab's DMA pieces (older than the last (9 - NI) taps of fragment loads)
         sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
         const unsigned hbo = (unsigned)((cs & 1) * BUF);
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
     sy_barrier();
 
     SY_LATE_ARGS(ConvArgs, p);
-    int e_bx = bid.x, e_n = n, e_h0 = h0, e_w0 = w0, e_by = bid.y;
+    int e_bx = bid.x, e_n = n + kz * p.N, e_h0 = h0, e_w0 = w0, e_by = bid.y;      // split z: partial "images" [z*N, (z+1)*N)
     SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_n); SY_LAUNDER_INT(e_h0); SY_LAUNDER_INT(e_w0); SY_LAUNDER_INT(e_by);
     TilePixels mp;
     mp.n = e_n; mp.h0 = e_h0; mp.w0 = e_w0; mp.Ho = p_late.Ho; mp.Wo = p_late.Wo; mp.rep = e_by;
@@ -403,7 +409,8 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     constexpr size_t smem_s = (size_t)WP * CT * 8;            // statistics scratch of the un-staged epilogue
     constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
     const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
-    dim3 grid((a.Cout + CT - 1) / CT, tiles, 1);
+    if (a.ksplit > 1 && (GEN != 2 || a.ksplit > a.Cin / (4 * T::kEPC))) return SY_ERR_UNSUPPORTED;
+    dim3 grid((a.Cout + CT - 1) / CT, tiles, a.ksplit > 1 ? a.ksplit : 1);
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {

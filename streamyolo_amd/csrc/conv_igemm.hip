@@ -47,6 +47,13 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
         if ((d->tile & 0xff) != 117 && (d->tile & 0xff) != 118) return SY_ERR_UNSUPPORTED;   // operand-in-LDS kernels only
         a.in_seg_N = d->N / segs;
     }
+    a.ksplit = 0;
+    if (d->k_splits > 1) {
+        if (((d->tile & 0xff) != 117 && (d->tile & 0xff) != 118) || d->mode != SY_CONV_FWD || !d->y_f32 || d->epilogue != SY_EPI_LINEAR ||
+            d->scale != nullptr || d->shift != nullptr || d->res != nullptr || d->stat_sum != nullptr || d->accumulate || d->k_splits > 16)
+            return SY_ERR_UNSUPPORTED;
+        a.ksplit = d->k_splits;
+    }
     a.tile = d->tile & 0xff;
     a.ablate = (d->tile >> 8) & 31;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;

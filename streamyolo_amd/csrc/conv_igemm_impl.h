@@ -62,6 +62,7 @@ struct ConvArgs {
     const float* in_scale;      // optional input normalisation (conv3x3_halo2_kernel NORM): [segments][Cin]
     const float* in_shift;
     int in_seg_N;               // images per normalisation segment (0: no input transform)
+    int ksplit;                 // > 1: split-K over channel-slab ranges (conv3x3_halo2_kernel), gridDim.z splits, fp32 partial outputs
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads, 8 = no statistics atomics, 16 = no cross-lane statistics reduction
 };
 

@@ -171,3 +171,55 @@ extern "C" int sy_view_copy(const void* in, int ldi, void* out, int ldo, int64_t
                                        (long long)pixels, C, accumulate));
 }
 
+
+// ---- second half of a split-K convolution (sy_conv_desc::k_splits) ---------------------------------------------------------
+// One thread = one 16-byte output chunk: sums its channels' fp32 partials over the splits in split order, then applies the
+// convolution epilogue's arithmetic (acc * scale + shift -> SiLU -> + residual, rounded once).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void splitk_epilogue_kernel(const float* part, int splits, long long pixels, int C,
+                                                                 const float* scale, const float* shift,
+                                                                 const typename T::elem* res, int ldr, typename T::elem* y,
+                                                                 int ldy, int silu) {
+    constexpr int E = T::kEPC;
+    const int cpp = C / E;
+    const long long total = pixels * cpp;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const long long p = i / cpp;
+        const int c0 = (int)(i - p * cpp) * E;
+        float v[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) v[j] = 0.0f;
+        for (int z = 0; z < splits; ++z) {
+            const float4* src = reinterpret_cast<const float4*>(part + ((long long)z * pixels + p) * C + c0);
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) {
+                const float4 u = src[q];
+                v[4 * q + 0] += u.x; v[4 * q + 1] += u.y; v[4 * q + 2] += u.z; v[4 * q + 3] += u.w;
+            }
+        }
+        Chunk<T> r, o;
+        if (res != nullptr) r = Chunk<T>::load(res + p * ldr + c0);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            float t = v[j] * (scale != nullptr ? scale[c0 + j] : 1.0f) + (shift != nullptr ? shift[c0 + j] : 0.0f);
+            if (silu) t = sy_silu(t);
+            if (res != nullptr) t += T::to_f32(r.e[j]);
+            o.e[j] = T::from_f32(t);
+        }
+        o.store(y + p * ldy + c0);
+    }
+}
+}  // namespace
+
+extern "C" int sy_splitk_epilogue(const float* part, int splits, int64_t pixels, int C, const float* scale, const float* shift,
+                                  const void* res, int ldr, void* y, int ldy, int dtype, int epilogue, void* stream) {
+    if (part == nullptr || y == nullptr || splits < 1 || pixels <= 0 || C <= 0) return SY_ERR_ARG;
+    if (epilogue != SY_EPI_LINEAR && epilogue != SY_EPI_SILU) return SY_ERR_UNSUPPORTED;
+    const int e = epc_of(dtype);
+    if (C % e || ldy % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
+    const long long work = pixels * (C / e);
+    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((splitk_epilogue_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream, part, splits,
+                                       (long long)pixels, C, scale, shift, (const typename T::elem*)res, ldr,
+                                       (typename T::elem*)y, ldy, epilogue == SY_EPI_SILU ? 1 : 0));
+}

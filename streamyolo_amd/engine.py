@@ -93,6 +93,8 @@ class FocusOp:
 # streaming launch tape: head level 0 beside levels 1-2 on a second stream.  Measured on MI355X (profiles/r03/c_*): 1.883 vs
 # 1.849 ms per frame on one stream — at batch 1 the frame is bound by dispatch, not by idle CUs; off by default.
 TWO_STREAM_HEAD = os.environ.get("STREAMYOLO_STREAM_HEAD_FORK", "0") != "0"
+# test hook: "S,tile" forces a split-K decision for every eligible layer (the emulator has no tuner)
+FORCE_SPLIT_K = tuple(int(v) for v in os.environ["STREAMYOLO_FORCE_SPLIT_K"].split(",")) if os.environ.get("STREAMYOLO_FORCE_SPLIT_K") else None
 
 
 class MergedConv:
@@ -342,6 +344,10 @@ class InferencePlan:
         self.cache = ParamCache(self.dtype, device)
         self._stream_tape, self._tape_param_list = None, None
         self._rec, self._side = None, None           # open native tape (run_stream_taped) / its side stream
+        # split-K for the deep small-map 3x3 layers of the streaming step (36-72 workgroups at batch 1): opt-in, because the
+        # fp32 summation order differs from the single-pass kernel (the facade's off_pipe == chained on_pipe bit-identity is
+        # kept on the exact path); StreamingDetector / bench.py --workload stream turn it on for the 16-bit modes
+        self.allow_split_k, self._in_stream, self._splitk_ws = False, False, None
         b = _Builder(self.dtype, device)
         b.merge_siblings = os.environ.get("STREAMYOLO_MERGE_SIBLINGS", "1") != "0"
         self.b = b
@@ -382,11 +388,39 @@ class InferencePlan:
         if self._rec is not None:
             self._rec.mark(kind, arg)
 
+    def _split_decision(self, op, t):
+        """(splits, tile) of a streaming-step conv: (1, t) = the ordinary single-pass launch."""
+        if not (self.allow_split_k and op.k == 3 and op.stride == 1 and op.y.bs_ is None and (op.res is None or op.res.bs_ is None)):
+            return (1, t)
+        dec = op._tiles.get("splitk")
+        if dec is None:
+            dec = FORCE_SPLIT_K or ops.tuned_splitk(op.x.dtype, op.x.N, op.x.H, op.x.W, op.x.C, op.y.C, self.device, t)
+            if dec[0] > 1 and op.x.C // (16 if op.x.dtype == ops.DT_F32 else 32) < dec[0]:
+                dec = (1, t)
+            op._tiles["splitk"] = dec
+        return dec
+
+    def _ensure_tuned(self):
+        """Make every tuner decision of the streaming step now: the tuners time dummy launches, which must not land on a tape
+        that is being recorded."""
+        for op in self.ops:
+            if op.kind == "conv":
+                self._split_decision(op, op.tile("fwd"))
+
     # -- execution --------------------------------------------------------------------------------
     def _run_op(self, op):
         if op.kind == "conv":
             w, scale, shift = self.cache.conv_eval(op.mod)
             t = op.tile("fwd")
+            dec = self._split_decision(op, t) if self._in_stream else (1, t)
+            if dec[0] > 1:
+                need = dec[0] * op.y.pixels * op.y.C
+                if self._splitk_ws is None or self._splitk_ws.numel() < need:
+                    self._splitk_ws = torch.empty(max(need, 4 << 20), dtype=torch.float32, device=self.device)
+                    self._stream_tape = None                            # recorded pointers are stale
+                ops.conv2d_splitk(op.x, w, op.y, op.k, op.stride, scale, shift, self._splitk_ws, dec[0], res=op.res,
+                                  epilogue=EPI_SILU, tile=dec[1], wfrag=self.cache.conv_weight_frag(op.mod))
+                return
             ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
         elif op.kind == "resize":
@@ -450,14 +484,18 @@ class InferencePlan:
         else:
             ops.focus_pack(x.float().contiguous(), 0, self.f0)
         n_fuse = 6
-        for op in self.ops[:self.n_backbone_ops - n_fuse]:
-            self._run_op(op)
-        if first:
-            for dst, s in zip(self.sup_in, self.cur_pans):
-                ops.view_copy(s, dst)
-        for op in self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]:
-            self._run_op(op)
-        out = self.run_head()
+        self._in_stream = True
+        try:
+            for op in self.ops[:self.n_backbone_ops - n_fuse]:
+                self._run_op(op)
+            if first:
+                for dst, s in zip(self.sup_in, self.cur_pans):
+                    ops.view_copy(s, dst)
+            for op in self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]:
+                self._run_op(op)
+            out = self.run_head()
+        finally:
+            self._in_stream = False
         for dst, s in zip(self.sup_in, self.cur_pans):
             ops.view_copy(s, dst)
         if self._rec is None:
@@ -507,6 +545,7 @@ class InferencePlan:
             # native tape (csrc/tape.hip): the launches are recorded inside the library and replayed by ONE C call; the head's
             # levels fan out over two streams there (level 0 beside levels 1-2), which a hipGraph capture of this plan cannot
             # do on this ROCm build
+            self._ensure_tuned()
             tape = _lib.NativeTape()
             with tape:
                 self._rec = tape

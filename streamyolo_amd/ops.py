@@ -118,7 +118,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None, segments=1, in_affine=None, in_segments=1):
+           cout=None, tile=0, wfrag=None, segments=1, in_affine=None, in_segments=1, k_splits=0):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -151,6 +151,7 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.w_bytes = w.numel() * w.element_size()
     if wfrag is not None:
         d.wfrag, d.wfrag_bytes = wfrag.data_ptr(), wfrag.numel() * wfrag.element_size()
+    d.k_splits = int(k_splits)          # > 1: fp32 partial sums per channel-slab range (see sy_splitk_epilogue)
     if in_affine is not None:           # x is the producer's RAW output: normalise it in LDS (tiles 117 / 118), see the header
         d.in_scale, d.in_shift, d.in_segments = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_segments)
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
@@ -173,6 +174,18 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, t
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")
+
+
+def conv2d_splitk(x, w, y, ksize, stride, scale, shift, part, splits, res=None, epilogue=EPI_SILU, tile=118, wfrag=None):
+    """3x3 stride-1 convolution as `splits` partial contractions (fp32 partials in `part`, >= splits * pixels * Cout floats) +
+    sy_splitk_epilogue: for layers whose pixel x channel tiling yields far fewer workgroups than the chip has CUs."""
+    assert part.dtype == torch.float32 and part.numel() >= splits * y.pixels * y.C
+    pv = View(part, splits * y.N, y.H, y.W, y.C)             # partial z = "images" [z*N, (z+1)*N) of a dense fp32 tensor
+    d = dict(y_f32=True, y_ptr=part.data_ptr(), y_ld=y.C, y_bs=y.H * y.W * y.C)
+    conv2d(x, w, pv, ksize, stride, epilogue=EPI_LINEAR, tile=tile, wfrag=wfrag, k_splits=splits, **d)
+    check(_lib.lib().sy_splitk_epilogue(part.data_ptr(), splits, y.pixels, y.C, _p(scale), _p(shift),
+                                        None if res is None else res.ptr(), 0 if res is None else res.ld, y.ptr(), y.ld, y.dtype,
+                                        epilogue, stream_of(y.buf)), "sy_splitk_epilogue")
 
 
 def focus_pack(frames, c0, out):
@@ -587,6 +600,45 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
         if dt < best_t:
             best, best_t = t, dt
     _tile_cache[key] = best
+    _tune_store.dirty = True
+    return best
+
+
+def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile):
+    """(splits, tile) for a 3x3 stride-1 EVAL convolution of a small map: the plain kernel (`base_tile`, splits = 1) against 2 / 4
+    channel-slab ranges + sy_splitk_epilogue on tiles 117 / 118, timed on dummy tensors (cached, persisted as mode 2 entries)."""
+    code = dtype_code(dtype)
+    epc = 4 if code == DT_F32 else 8
+    if not autotune_enabled(device) or Cin % (4 * epc) or N * H * W > 6000:
+        return (1, base_tile)
+    _tune_store.load(device)
+    key = ("splitk", code, N, H, W, Cin, Cout, base_tile, str(device))
+    hit = _tile_cache.get(key)
+    if hit is not None:
+        return (hit // 1000, hit % 1000) if hit >= 1000 else (1, base_tile)
+    from .model.packing import pack_conv_weight_frag
+    x = View.alloc(N, H, W, Cin, code, device, zero=True)
+    y = View.alloc(N, H, W, Cout, code, device)
+    w = torch.zeros((Cout, 9 * Cin), dtype=TORCH_DTYPE[code], device=device)
+    wf = pack_conv_weight_frag(w, 3)
+    scale, shift = torch.ones(Cout, device=device), torch.zeros(Cout, device=device)
+    part = torch.empty(4 * N * H * W * Cout, dtype=torch.float32, device=device)
+    best, best_t = (1, base_tile), _time_launches(
+        lambda: conv2d(x, w, y, 3, 1, scale, shift, epilogue=EPI_SILU, tile=base_tile, wfrag=wf if base_tile >= TILE_WR else None),
+        device, launches=8)
+    for S in (2, 4):
+        if S > Cin // (4 * epc):
+            continue
+        for t in (117, 118):
+            try:
+                run = lambda: conv2d_splitk(x, w, y, 3, 1, scale, shift, part, S, epilogue=EPI_SILU, tile=t, wfrag=wf)   # noqa: E731
+                run()
+                dt_ = _time_launches(run, device, launches=8)
+            except _lib.HipLibraryError:
+                continue
+            if dt_ < best_t:
+                best, best_t = (S, t), dt_
+    _tile_cache[key] = best[0] * 1000 + best[1] if best[0] > 1 else 1
     _tune_store.dirty = True
     return best
 

@@ -12,6 +12,7 @@ Per-pixel and per-box arithmetic is on the device (sy_frames_u8_pack, the on_pip
 Python control flow the reference also keeps in Python.  Dataset access (pycocotools) and image decoding (cv2.imread)
 stay with the caller: every function takes plain lists / arrays.
 """
+import os
 import time
 
 import numpy as np
@@ -69,6 +70,9 @@ class StreamingDetector:
         self._slot = torch.empty((1,) + self.frame_hw + (3,), dtype=torch.uint8, device=self.device)
         self._in = FramePairsU8(self._slot, None, self.canvas, self.decimate)
         self.plan = model._plans.inference(model.backbone, model.head, "on_pipe", self._in, owner=model)
+        # 16-bit speed modes: the deep small-map layers may run as split-K (different fp32 summation order than the facade's
+        # exact path); the fp32 parity mode keeps the single-pass kernels
+        self.plan.allow_split_k = str(dtype) not in ("fp32", "torch.float32") and os.environ.get("STREAMYOLO_STREAM_SPLITK", "1") != "0"
         self._first = True
         self._post = lambda out: postprocess_device(out, num_classes, conf_thre, nms_thresh)   # one object: part of the tape key
 

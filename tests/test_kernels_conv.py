@@ -396,3 +396,36 @@ def test_conv3x3_input_normalised_in_lds_equals_apply_then_conv(backend, tile, d
     sh = torch.cat([shift[0].cpu().expand(N // 2, cin), shift[1].cpu().expand(N // 2, cin)])[:, :, None, None]
     ref = F.conv2d(_q(F.silu(raw * sc + sh), dt), w, None, 1, 1)
     assert _rel(y1, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("tile", [117, 118])
+@pytest.mark.parametrize("dt,splits", [("fp16", 2), ("fp16", 4), ("bf16", 3), ("fp32", 2)])
+def test_conv3x3_split_k_equals_the_single_pass_kernel(backend, tile, dt, splits):
+    """sy_conv_desc::k_splits + sy_splitk_epilogue (the batch-1 streaming step's deep small-map layers): the channel slabs
+    cut into `splits` ranges, fp32 partials summed in split order, then the same epilogue arithmetic (affine, SiLU, residual,
+    one rounding) — against the single-pass halo kernel and against torch; ragged image edges, a residual view inside a
+    wider buffer, Cin of six channel slabs (an uneven 6 / 4 split included)."""
+    g = torch.Generator().manual_seed(tile + splits)
+    epc = 4 if dt == "fp32" else 8
+    N, cin, cout, H, W = 1, 6 * 4 * epc, 160, 7, 37
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, dt)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(backend)
+    shift = (torch.randn(cout, generator=g) * 0.3).to(backend)
+    res = _q(torch.randn(N, cout, H, W, generator=g), dt)
+    code = ops.dtype_code(dt)
+    xv = View.alloc(N, H, W, cin, dt, backend); xv.set_nchw(x.to(backend))
+    rv = View.alloc(N, H, W, cout + 16, dt, backend, zero=True).slice(16, cout); rv.set_nchw(res.to(backend))
+    wp = pack_conv_weight(w, code)
+    wf = pack_conv_weight_frag(wp, 3).to(backend)
+    wp = wp.to(backend)
+    y0 = View.alloc(N, H, W, cout, dt, backend)
+    ops.conv2d(xv, wp, y0, 3, 1, scale, shift, res=rv, epilogue=ops.EPI_SILU, tile=tile, wfrag=wf)
+    y1 = View.alloc(N, H, W, cout, dt, backend)
+    part = torch.full((splits * N * H * W * cout + 64,), float("nan"), device=backend)       # every partial must be written
+    ops.conv2d_splitk(xv, wp, y1, 3, 1, scale, shift, part, splits, res=rv, epilogue=ops.EPI_SILU, tile=tile, wfrag=wf)
+    ref = F.silu(F.conv2d(x, w, None, 1, 1) * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None]) + res
+    assert torch.isfinite(y1.nchw()).all()
+    assert _rel(y1.nchw().cpu(), ref) < TOL[dt]
+    # vs the single-pass kernel: same products, a different fp32 summation order -> a few last-bit flips of the stored type
+    assert _rel(y1.nchw().cpu(), y0.nchw().cpu()) < {"fp32": 1e-5, "fp16": 2e-3, "bf16": 1.6e-2}[dt]

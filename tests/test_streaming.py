@@ -150,3 +150,37 @@ def test_stream_tape_follows_changed_weights_and_inputs(backend):
         y = (x * 0.5).contiguous()                                        # another input buffer -> re-recorded
         plan.run_stream_taped(y, post=post)
         assert plan._stream_tape[2] is not tape1
+
+
+def test_streaming_step_with_split_k_layers(backend, monkeypatch):
+    """allow_split_k (StreamingDetector's 16-bit modes, bench.py --workload stream): the deep 3x3 layers run as channel-slab
+    ranges + sy_splitk_epilogue.  Only the fp32 summation order differs from the single-pass kernels, so the decoded outputs
+    agree to rounding; the launch tape of such a step replays bit-identically."""
+    import streamyolo_amd as sy
+    from streamyolo_amd import engine
+    from oracle import streamyolo_oracle as O
+    from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, load_bn_stats
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=load_bn_stats("nano"))
+    model = sy.build_model("nano"); model.load_state_dict(sd, strict=True)
+    model = model.to(backend).eval().set_compute_dtype("fp32")
+    frames = [synth_frames(1, 32, 64, seed=s)[:, 0:3].contiguous().to(backend) for s in (2, 3)]
+    plan = model._plans.inference(model.backbone, model.head, "on_pipe", frames[0], owner=model)
+    with torch.no_grad():
+        plan.run_stream(frames[0], first=True)
+        want = plan.run_stream(frames[1]).clone()
+        monkeypatch.setattr(engine, "FORCE_SPLIT_K", (2, 118))
+        plan.allow_split_k = True
+        plan.run_stream(frames[0], first=True)
+        got = plan.run_stream(frames[1]).clone()
+        n_split = sum(1 for op in plan.ops if op.kind == "conv" and op._tiles.get("splitk", (1,))[0] > 1)
+        assert n_split >= 4, n_split                                     # the dark-5 / PAN 3x3 layers of the nano model
+        assert not torch.equal(got, want) or backend.type == "cpu"
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+        buf = frames[1].clone()
+        plan.run_stream(frames[0], first=True)
+        rec = plan.run_stream_taped(buf).clone()                         # records
+        assert torch.equal(rec, got)
+        plan.run_stream(frames[0], first=True)
+        plan.out.zero_()
+        assert torch.equal(plan.run_stream_taped(buf), got)              # replays
