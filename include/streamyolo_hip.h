@@ -56,6 +56,24 @@ enum {
     SY_CONV_DGRAD = 1       /* out(h,w)  <- in((h + p - kh)/s, (w + p - kw)/s) when divisible  */
 };
 
+/* Training-mode BatchNorm finalisation done by the producing convolution (sy_conv_desc::fin).  All pointers are device pointers;
+ * the record itself lives in DEVICE memory.  Same arithmetic, in the same order, as sy_bn_finalize: per channel, eight float
+ * partials over the replicas k = r, r + 8, ..., summed in double; var = E[x^2] - mean^2 clamped at 0 (biased, as
+ * torch.nn.functional.batch_norm normalises in training mode); scale = gamma * invstd, shift = beta - mean * scale.
+ * ticket: segments * ceil(Cout / 32) counters, zero before the first launch; the finalising workgroup resets its counter. */
+typedef struct sy_bn_fin {
+    uint32_t* ticket;
+    const float* gamma;                 /* [Cout] (shared by the segments) */
+    const float* beta;
+    float* scale;                       /* [segments][Cout] */
+    float* shift;
+    float* mean;                        /* [segments][Cout] or NULL */
+    float* invstd;
+    double count;                       /* pixels per segment */
+    float eps;
+    int32_t reserved;
+} sy_bn_fin;
+
 typedef struct sy_conv_desc {
     /* tensors */
     const void* x;          /* input view,  [N, H, W, Cin]   */
@@ -98,6 +116,11 @@ typedef struct sy_conv_desc {
        y (which must hold S*N images, batch stride ybs).  sy_splitk_epilogue sums the partials and applies the epilogue.  For the
        deep small-map layers of the batch-1 streaming step: 36-72 workgroups become 144-288. */
     int32_t k_splits;
+    int32_t reserved;
+    /* optional (forward launches with stat_sum / stat_sq only): the workgroup that adds the LAST partial sums of a channel tile
+       also folds the replicas and emits the BatchNorm affine — what a separate sy_bn_finalize launch would do, without the
+       dependent launch on the step's critical path.  DEVICE pointer to a sy_bn_fin record that lives as long as the launch. */
+    const struct sy_bn_fin* fin;
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.

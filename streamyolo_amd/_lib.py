@@ -37,6 +37,15 @@ class ConvDesc(C.Structure):
         ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
         ("accumulate", C.c_int32), ("dec_stride", C.c_float), ("stat_copies", C.c_int32), ("stat_segments", C.c_int32), ("tile", C.c_int32), ("x_bytes", C.c_int64), ("w_bytes", C.c_int64), ("wfrag", C.c_void_p), ("wfrag_bytes", C.c_int64),
         ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_segments", C.c_int32), ("k_splits", C.c_int32),
+        ("reserved", C.c_int32), ("fin", C.c_void_p),
+    ]
+
+
+class BnFin(C.Structure):
+    """sy_bn_fin: the record of sy_conv_desc::fin (device pointers; the record itself is copied to device memory by ops.BnFinRecord)."""
+    _fields_ = [
+        ("ticket", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("mean", C.c_void_p), ("invstd", C.c_void_p), ("count", C.c_double), ("eps", C.c_float), ("reserved", C.c_int32),
     ]
 
 

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, (NS <= 4 ? 3 : 2)) void conv1x1_stream_kernel(
     const int t0 = blockIdx.y * per_wg;
     int t1 = t0 + per_wg;
     if (t1 > ntiles) t1 = ntiles;
-    if (t0 >= t1) return;
+    if (t0 >= t1) return;                            // (never taken: the launcher sizes gridDim.y so that every workgroup owns a tile)
 
     // ---- this wave's weights: 32 output channels x all of K, fragment order, straight into registers
     const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256, (NS <= 4 ? 3 : 2)) void conv1x1_stream_kernel(
                 atomicAdd(p.stat_sq + (long long)copy * p.Cout + co, b);
             }
         }
+        if (p.fin != nullptr) conv_stats_finalize<128, 256>(p, (int)blockIdx.z, c0, tid, smem);
     }
 }
 
@@ -186,6 +187,9 @@ int launch_1x1_stream_ns(const ConvArgs& a, void* stream) {
     if (gy < 1) gy = 1;
     if (gy > (ntiles + 3) / 4) gy = (ntiles + 3) / 4;
     if (gy < 1) gy = 1;
+    // no idle workgroups: with per = ceil(ntiles / gy) tiles each, ceil(ntiles / per) workgroups cover the range (sy_conv_desc::fin
+    // counts one ticket per workgroup of a channel tile)
+    gy = (ntiles + (ntiles + gy - 1) / gy - 1) / ((ntiles + gy - 1) / gy);
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {

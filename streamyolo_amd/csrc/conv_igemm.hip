@@ -47,6 +47,8 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
         if ((d->tile & 0xff) != 117 && (d->tile & 0xff) != 118) return SY_ERR_UNSUPPORTED;   // operand-in-LDS kernels only
         a.in_seg_N = d->N / segs;
     }
+    a.fin = d->fin;
+    if (d->fin != nullptr && (d->stat_sum == nullptr || d->mode != SY_CONV_FWD || d->k_splits > 1)) return SY_ERR_ARG;
     a.ksplit = 0;
     if (d->k_splits > 1) {
         if (((d->tile & 0xff) != 117 && (d->tile & 0xff) != 118) || d->mode != SY_CONV_FWD || !d->y_f32 || d->epilogue != SY_EPI_LINEAR ||

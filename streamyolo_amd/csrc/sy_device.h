@@ -165,6 +165,25 @@ template <int N> __device__ __forceinline__ void sy_wait_vmcnt() { asm volatile(
 __device__ __forceinline__ void sy_barrier() { __builtin_amdgcn_s_barrier(); }
 #endif
 
+// ---- agent-scope helpers of the "last workgroup finalises" pattern (conv_stats_finalize, conv_igemm_impl.h) -----------------
+// The statistic atomics of every workgroup are agent-scope RMWs (performed at the device's coherence point, not in one XCD's
+// L2); a ticket taken AFTER they have retired (sy_wait_vmcnt<0>) orders them before the last workgroup's agent-scope loads.
+#ifdef SY_EMU
+static inline unsigned sy_ticket_take(unsigned* t) { return reinterpret_cast<std::atomic<unsigned>*>(t)->fetch_add(1u); }
+static inline void sy_ticket_reset(unsigned* t) { reinterpret_cast<std::atomic<unsigned>*>(t)->store(0u); }
+static inline float sy_load_agent(const float* p) {
+    return reinterpret_cast<const std::atomic<float>*>(p)->load();
+}
+#else
+__device__ __forceinline__ unsigned sy_ticket_take(unsigned* t) {
+    return __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sy_ticket_reset(unsigned* t) { __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sy_load_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // ---- LDS transpose read (ds_read_b64_tr_b16) ---------------------------------------------------------
 // Per 16-lane group: lane i supplies the 8-byte-aligned address of 4 consecutive 16-bit elements (row i>>2,
 // column quad i&3 of a [4 rows][16 cols] block whose row pitch the addresses imply) and receives COLUMN i:

@@ -118,7 +118,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None, segments=1, in_affine=None, in_segments=1, k_splits=0):
+           cout=None, tile=0, wfrag=None, segments=1, in_affine=None, in_segments=1, k_splits=0, fin=None):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -154,7 +154,26 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     d.k_splits = int(k_splits)          # > 1: fp32 partial sums per channel-slab range (see sy_splitk_epilogue)
     if in_affine is not None:           # x is the producer's RAW output: normalise it in LDS (tiles 117 / 118), see the header
         d.in_scale, d.in_shift, d.in_segments = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_segments)
+    if fin is not None:                 # BnFinRecord: the last workgroup of every channel tile finalises the BatchNorm affine
+        d.fin = fin.ptr
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
+
+
+class BnFinRecord:
+    """A sy_bn_fin record in device memory (sy_conv_desc::fin): the statistics launch itself emits scale / shift / mean / invstd
+    of training-mode BatchNorm, in sy_bn_finalize's arithmetic.  ticket: zeroed int32 tensor, >= segments * ceil(C / 32)
+    counters of this layer (the finalising workgroups reset them); scale / shift / mean / invstd: fp32 [segments][C]."""
+
+    def __init__(self, ticket, gamma, beta, eps, count, scale, shift, mean=None, invstd=None):
+        assert ticket.dtype == torch.int32 and ticket.is_contiguous()
+        rec = _lib.BnFin()
+        rec.ticket, rec.gamma, rec.beta = ticket.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+        rec.scale, rec.shift, rec.mean, rec.invstd = scale.data_ptr(), shift.data_ptr(), _p(mean), _p(invstd)
+        rec.count, rec.eps = float(count), float(eps)
+        self.keep = (ticket, gamma, beta, scale, shift, mean, invstd)
+        host = torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8)
+        self.dev = host.to(ticket.device)
+        self.ptr = self.dev.data_ptr()
 
 
 def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, target_blocks=0):

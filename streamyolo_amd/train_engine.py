@@ -36,6 +36,11 @@ from .ops import View, EPI_LINEAR, CONV_DGRAD
 # (default off: kernel time 2.77 vs 2.90 ms per l step, but the step itself is not faster at 32 statistic replicas, and the 8
 # replicas that make it 0.26 ms faster break the 1e-5 run-to-run reproducibility of the fp16 step — profiles/r02/t_*, u_*)
 _FUSED_FINALIZE = __import__("os").environ.get("STREAMYOLO_FUSED_FINALIZE", "0") != "0"
+# BatchNorm finalisation by the producing convolution's LAST workgroup (sy_conv_desc::fin) instead of a sy_bn_finalize launch:
+# removing the ~130 finalize launches of an l step outright is worth 2.0 ms of 22.8 (profiles/r03/abl_ablate_step_train_l.txt:
+# a dependent launch on the critical path costs its drain + dispatch whatever it does).  Built and parity-tested at the end of
+# round 3 with no GPU time left to measure it: default off until it has been.
+CONV_FINALIZE = __import__("os").environ.get("STREAMYOLO_CONV_FINALIZE", "0") != "0"
 
 class _GradSpace:
     """Gradient mirrors of activation buffers + first-write / accumulate bookkeeping per channel range."""
@@ -329,6 +334,7 @@ class TrainPlan:
         BC = self.BWD_COPIES
         self.bwd_arena = torch.zeros(2 * BC * tot_c, dtype=torch.float32, device=device)  # [copies][sum dz | sum dz*xhat]
         self.aff_arena = torch.empty(4 * tot_c, dtype=torch.float32, device=device)       # scale|shift|mean|invstd
+        self._fin_tickets, self._fin_off = None, 0                                        # sy_bn_fin counters (CONV_FINALIZE)
         off = 0
         max_raw = 0
         nf = self.n_frame_ops
@@ -630,6 +636,20 @@ class TrainPlan:
         g, b_ = self.cache.bn[id(op.mod)]
         return g, b_, bn.eps, mom
 
+    def _fin(self, op, gamma, beta, eps, aff, nseg):
+        """The sy_bn_fin record of `op`'s statistics launch (nseg = 2: the paired launch over both frames), built once."""
+        assert not _FUSED_FINALIZE
+        key = "fin%d" % nseg
+        rec = op._tiles.get(key)
+        if rec is None:
+            n = nseg * ((op.y.C + 31) // 32)
+            if self._fin_tickets is None or self._fin_off + n > self._fin_tickets.numel():
+                self._fin_tickets, self._fin_off = torch.zeros(4096, dtype=torch.int32, device=self.device), 0
+            tk = self._fin_tickets[self._fin_off:self._fin_off + n]
+            self._fin_off += n
+            rec = op._tiles[key] = ops.BnFinRecord(tk, gamma, beta, eps, op.y.pixels, *aff)
+        return rec
+
     def _bn_grads(self, op):
         """(dgamma, dbeta) arena views starting at the op's first part (the parts' slots are adjacent: see the arena order)."""
         bn = base_convs(op.mod)[0].bn
@@ -655,10 +675,13 @@ class TrainPlan:
                 t = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride, self.device,
                                    with_stats=True)
                 a._tiles["fwd_stats2"] = t
+        fin = self._fin(a, gamma, beta, eps, (scale, shift, mean, invstd), 2) if CONV_FINALIZE else None
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
                    wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2,
-                   in_affine=in_aff, in_segments=2)
-        if _FUSED_FINALIZE:
+                   in_affine=in_aff, in_segments=2, fin=fin)
+        if fin is not None:
+            self._apply(a, lambda: ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2))
+        elif _FUSED_FINALIZE:
             ops.bn_finalize_apply(u_sum, u_sq, a.y.pixels, gamma, beta, eps, scale, shift, mean, invstd, raw2, y2,
                                   res=None if a.res is None else a.res.pair(), nseg=2)
         else:
@@ -760,12 +783,15 @@ class TrainPlan:
                                                                  self.device, with_stats=True, only=(117, 118))
             else:
                 t = op.tile("fwd_stats")
-            ops.conv2d(x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
-                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None, in_affine=in_aff)
             scale, shift, mean, invstd = op.aff
+            fin = self._fin(op, gamma, beta, eps, op.aff, 1) if CONV_FINALIZE else None
+            ops.conv2d(x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
+                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None, in_affine=in_aff, fin=fin)
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
-            if _FUSED_FINALIZE:
+            if fin is not None:
+                self._apply(op, lambda: ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res))
+            elif _FUSED_FINALIZE:
                 ops.bn_finalize_apply(op.stat[0], op.stat[1], op.y.pixels, gamma, beta, eps, scale, shift, mean, invstd,
                                       op.yraw, op.y, res=op.res)
             else:

@@ -429,3 +429,57 @@ def test_conv3x3_split_k_equals_the_single_pass_kernel(backend, tile, dt, splits
     assert _rel(y1.nchw().cpu(), ref) < TOL[dt]
     # vs the single-pass kernel: same products, a different fp32 summation order -> a few last-bit flips of the stored type
     assert _rel(y1.nchw().cpu(), y0.nchw().cpu()) < {"fp32": 1e-5, "fp16": 2e-3, "bf16": 1.6e-2}[dt]
+
+
+@pytest.mark.parametrize("k,stride,tile,cin,cout,N,H,W,dt", [
+    (3, 1, 0, 32, 48, 2, 8, 7, "bf16"),          # implicit GEMM, heuristic tile, ragged channel tile
+    (3, 2, 19, 32, 64, 2, 9, 12, "bf16"),        # stride 2
+    (1, 1, 3, 64, 96, 4, 5, 6, "fp32"),
+    (3, 1, 114, 64, 160, 2, 9, 37, "bf16"),      # halo kernel, ragged 64 / 128-channel tiles
+    (3, 1, 117, 64, 72, 4, 7, 33, "fp16"),       # halo2
+    (3, 1, 118, 32, 256, 2, 5, 40, "bf16"),
+    (1, 1, 120, 128, 160, 4, 5, 13, "bf16"),     # weight-stationary stream (workgroups without tiles take a ticket too)
+    (1, 1, 120, 64, 72, 2, 40, 41, "bf16"),
+    (1, 1, 121, 128, 160, 4, 5, 13, "bf16"),     # whole-K burst kernels
+    (1, 1, 122, 64, 64, 2, 16, 33, "fp16"),
+])
+@pytest.mark.parametrize("segments", [1, 2])
+def test_conv_statistics_finalised_by_the_last_workgroup(backend, k, stride, tile, cin, cout, N, H, W, dt, segments):
+    """sy_conv_desc::fin: the workgroup that adds the last partial sums of a channel tile folds the replicas and writes the
+    BatchNorm affine.  On the SAME replica arrays sy_bn_finalize must give bit-identical scale / shift / mean / invstd; the
+    ticket counters are back at zero, so the next launch of the layer finalises again."""
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(7 * cin + cout + tile)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, dt)
+    xv = View.alloc(N, H, W, cin, dt, backend); xv.set_nchw(x.to(backend))
+    wp = pack_conv_weight(w, code).to(backend)
+    wf = pack_conv_weight_frag(wp, k)
+    Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
+    yv = View.alloc(N, Ho, Wo, cout, dt, backend)
+    copies = 5
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(backend)
+    beta = torch.randn(cout, generator=g).to(backend)
+    count = (N // segments) * Ho * Wo
+    ticket = torch.zeros(segments * ((cout + 31) // 32), dtype=torch.int32, device=backend)
+    aff = [torch.full((segments, cout), float("nan"), device=backend) for _ in range(4)]
+    rec = ops.BnFinRecord(ticket, gamma, beta, 1e-3, count, *aff)
+    for rnd in range(2):
+        ssum = torch.zeros(segments * copies * cout, device=backend); ssq = torch.zeros_like(ssum)
+        for t in aff:
+            t.fill_(float("nan"))
+        try:
+            ops.conv2d(xv, wp, yv, k, stride, stats=(ssum, ssq), tile=tile, wfrag=wf if tile >= ops.TILE_WR else None,
+                       segments=segments, fin=rec)
+        except ops._lib.HipLibraryError:
+            pytest.skip("tile %d does not take this shape" % tile)
+        want = [torch.empty(segments, cout, device=backend) for _ in range(4)]
+        ops.bn_finalize(ssum, ssq, count, gamma, beta, 1e-3, 0.03, None, None, *want, nseg=segments)
+        for name, a, b in zip(("scale", "shift", "mean", "invstd"), aff, want):
+            assert torch.equal(a, b), (rnd, name, float((a - b).abs().max()))
+        assert int(ticket.abs().sum()) == 0
+    # and the statistics themselves are the batch statistics of the raw output
+    y = F.conv2d(x, w, stride=stride, padding=(k - 1) // 2)
+    for s_ in range(segments):
+        ys = y[s_ * (N // segments):(s_ + 1) * (N // segments)]
+        assert float((aff[2][s_].cpu() - ys.mean((0, 2, 3))).abs().max()) < TOL[dt]

@@ -445,3 +445,55 @@ def test_frames_as_stream_parallel_chains_match_the_paired_launches(backend, gol
         assert _rel(Bm[k].cpu(), A[k].cpu()) < tol, k
     for k in ra:
         assert _rel(rb[k], ra[k]) < (1e-6 if str(backend) == "cpu" else 1e-5), k
+
+
+@pytest.mark.parametrize("fwd_split", [False, True])
+def test_batchnorm_finalised_by_the_convolution_matches_the_finalize_launch(backend, monkeypatch, fwd_split):
+    """STREAMYOLO_CONV_FINALIZE: every statistics launch carries a sy_bn_fin record and the sy_bn_finalize launches are gone from
+    the plan — same loss, gradients and running statistics as the default plan, through the direct step, the recorded step
+    and tape replays (the ticket counters must be back at zero after every launch for that), with the frames as one paired
+    launch and as two chains."""
+    from streamyolo_amd import train_engine, ops as ops_mod
+    from streamyolo_amd.train_engine import TrainStep
+    res = {}
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    Hh, Ww = (32, 64) if str(backend) == "cpu" else (128, 192)
+    x = synth_frames(2, Hh, Ww, seed=2).to(backend)
+    lab, sup = synth_labels(2, Hh, Ww, cfg.num_classes, num_gt=4, seed=3)
+    targets = (lab.to(backend), sup.to(backend))
+    monkeypatch.setattr(train_engine, "FWD_SPLIT_FRAMES", fwd_split)
+    calls = {"n": 0}
+    real = ops_mod.bn_finalize
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops_mod, "bn_finalize", counted)
+    for mode in ("launch", "in_conv"):
+        monkeypatch.setattr(train_engine, "CONV_FINALIZE", mode == "in_conv")
+        calls["n"] = 0
+        model = sy.build_model("nano")
+        model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        model = model.to(backend).train().set_compute_dtype("fp32")
+        model.head.use_l1 = True
+        st = TrainStep(model, graph=False)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        for _ in range(4):                                       # direct, recorded, replayed twice
+            model.load_state_dict(state0)
+            out = st.step(x, targets)
+        assert (calls["n"] == 0) == (mode == "in_conv")
+        if mode == "in_conv":
+            assert int(st.plan._fin_tickets.abs().sum()) == 0
+        res[mode] = (float(out["total_loss"]), {n: st.plan.gview[id(p)].clone() for n, p in model.named_parameters()},
+                     {k: v.clone() for k, v in model.state_dict().items() if "running" in k}, st.plan.loss_ws.fg.clone())
+    (la, ga, ra, fa), (lb, gb, rb, fb) = res["launch"], res["in_conv"]
+    assert abs(la - lb) / abs(la) < 1e-5
+    if int((fa != fb).sum()):                                    # a SimOTA tie assigned differently (GPU atomics-order noise)
+        assert int((fa != fb).sum()) <= 2
+        return
+    tol = 1e-5 if str(backend) == "cpu" else 1e-3
+    for k in ga:
+        assert _rel(gb[k].cpu(), ga[k].cpu()) < tol, k
+    for k in ra:
+        assert _rel(rb[k], ra[k]) < (1e-6 if str(backend) == "cpu" else 1e-5), k
