@@ -201,7 +201,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
 //     affine of all Cin channels is parked in LDS once per workgroup; out-of-image halo pixels stay zero (padding applies to the
 //     ACTIVATED tensor).
 template <typename T, int WC, int WP, int TC, int TP, int NORM = 0>
-__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_halo2_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1 : 2))) void conv3x3_halo2_kernel(ConvArgs p) {
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
     constexpr int ESZ = 16 / EPC;
@@ -405,7 +405,7 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     if (NORM && (a.in_scale == nullptr || a.in_seg_N <= 0 || a.Cin > 2048 || a.mode != SY_CONV_FWD)) return SY_ERR_UNSUPPORTED;
     constexpr size_t smem_k = 2 * (size_t)BUF + (NORM ? 2 * 2048 * sizeof(float) : 0);
     constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
-    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= 48 * 1024);
+    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= StageLimit<WC, WP, TC, TP>::kBytes);
     constexpr size_t smem_s = (size_t)WP * CT * 8;            // statistics scratch of the un-staged epilogue
     constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
     const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
@@ -414,7 +414,9 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        const void* fn = GEN == 2 ? (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM> : (const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>;
+        const void* fn;                                        // (if constexpr: only the generation this tile code launches is instantiated)
+        if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM>;
+        else fn = (const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
         attr_done = true;
     }
@@ -439,6 +441,11 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         // second generation (in-wave software pipeline) of 115 / 113; with an input affine: the NORM instantiation
         case 117: return a.in_scale != nullptr ? launch_halo<T, 4, 1, 1, 2, 2, 1>(a, stream) : launch_halo<T, 4, 1, 1, 2, 2>(a, stream);
         case 118: return a.in_scale != nullptr ? launch_halo<T, 4, 1, 1, 4, 2, 1>(a, stream) : launch_halo<T, 4, 1, 1, 4, 2>(a, stream);
+        // one workgroup per CU, one wave per SIMD, eight 32 x 32 accumulators per wave (the whole 512-register file): every
+        // fragment read from LDS / L2 feeds two to four MFMAs instead of one — candidates for the next measurement round
+        // (not in the tuner's default candidate set: STREAMYOLO_HALO_TILES)
+        case 119: return launch_halo<T, 2, 2, 2, 4, 2>(a, stream);  // 128 ch x ( 8 rows x 32 px), 4 waves x (64 ch x 128 px)
+        case 111: return launch_halo<T, 2, 2, 4, 2, 2>(a, stream);  // 256 ch x ( 4 rows x 32 px), 4 waves x (128 ch x 64 px)
         default: return SY_ERR_ARG;
     }
 }

@@ -120,6 +120,10 @@ __device__ __forceinline__ void conv_stats_finalize(const Args& p, int seg, int 
     }
 }
 
+// Staged write-out needs PT * (2 * CT + 16) bytes of LDS: up to 48 KiB for the tiles that share a CU with other workgroups; the
+// one-workgroup-per-CU tiles (8 accumulators per wave, conv3x3_halo.h tile codes 111 / 119) may take 96 KiB.
+template <int WC, int WP, int TC, int TP> struct StageLimit { static constexpr size_t kBytes = (WC == 2 && WP == 2 && TC * TP == 8 ? 96 : 48) * 1024; };
+
 // LDS in front of the staged output tile: BN-statistics scratch [WP][CT][2] floats
 template <int WP, int CT> struct EpiLds { static constexpr int kStatBytes = WP * CT * 8; };
 
@@ -666,7 +670,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
     // addresses (the K loop is over, its LDS is free).
     constexpr int kStagePitch = CT * 2 + 16;                    // bytes per staged pixel row (+16: bank spread)
     constexpr int kStatBytes = EpiLds<WP, CT>::kStatBytes;      // BN-statistics scratch [WP][CT][2] floats (aliases too)
-    constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 8 + kStatBytes <= 48 * 1024);
+    constexpr bool kCanStage = (ESZ == 2) && ((size_t)PT * kStagePitch + PT * 8 + kStatBytes <= StageLimit<WC, WP, TC, TP>::kBytes);
     // (+= outputs — data gradients of activations with several consumers — are staged too: the write-out pass reads
     //  the old row chunk, adds in fp32 and stores, all coalesced; the staged value was already rounded to 16 bits,
     //  one extra rounding the gradient path tolerates.  Residual adds keep the direct path: single rounding.)
@@ -991,13 +995,13 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
     }
 }
 
-template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 112..118)
+template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 111..119)
 template <typename T> int launch_1x1_stream(const ConvArgs& a, void* stream);      // conv1x1_stream.h (tile code 120)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..123)
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
-    if (a.tile >= 112 && a.tile <= 118) return launch_halo_typed<T>(a, stream);
+    if ((a.tile >= 112 && a.tile <= 119) || a.tile == 111) return launch_halo_typed<T>(a, stream);
     if (a.tile == 120) return launch_1x1_stream<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 123) return launch_1x1_tile<T>(a, stream);
     // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide
