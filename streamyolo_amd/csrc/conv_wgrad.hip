@@ -479,7 +479,11 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
 constexpr int kHaloPix = 3 * 34;                  // halo pixels of a slab (3 rows x (32 + 2))
 constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (102 used) x 16 channels + bank padding
 
-template <typename T, int STG>
+// PD: (k-half, tap) steps whose x fragments are requested ahead of the step that multiplies (ring of PD + 1 fragments).  With one
+// wave per SIMD nothing else covers the LDS latency: at PD = 2 (tile codes 49 / 65) a fragment is requested ~1.5 MFMAs = 50-60
+// cycles before its use, less than a loaded ds_read_b64_tr_b16 round trip; PD = 4 (tile codes 50 / 66, + 8 VGPRs) requests it
+// ~3.5 MFMAs ahead.
+template <typename T, int STG, int PD = 2>
 __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
     constexpr int CT = 128, CIT = 32;
     constexpr int SB = CT / 16;                   // dy subtiles per slab
@@ -585,25 +589,24 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
         const unsigned char* const yb = smem + stage_r * STAGE + 2 * kXSub + (wv * 2) * kSubPitch + y_lane;
         stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
         // fragments of step (k-half, tap) + 2 are read while step (k-half, tap) multiplies
-        uint4 a[3], b[2];
+        uint4 a[PD + 1], b[2];
         auto read_a = [&](auto st_) {
             constexpr int ST = decltype(st_)::value;
             constexpr int KS = ST / 9, TAP = ST % 9;
             const unsigned char* ptr = xb + ((TAP / 3) * 34 + (TAP % 3)) * 32 + KS * 512;
             const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
-            a[ST % 3] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            a[ST % (PD + 1)] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         };
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uint2 lo = sy_lds_read_tr16(yb + ks * 512), hi = sy_lds_read_tr16(yb + ks * 512 + 128);
             b[ks] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-        read_a(sy_int<0>());
-        read_a(sy_int<1>());
+        sy_static_for<0, PD>([&](auto st_) { read_a(st_); });
         sy_static_for<0, 18>([&](auto st_) {
             constexpr int ST = decltype(st_)::value;
-            if constexpr (ST + 2 < 18) read_a(sy_int<ST + 2>());
-            acc[ST % 9] = sy_mfma_group(T(), a[ST % 3], b[ST / 9], acc[ST % 9]);
+            if constexpr (ST + PD < 18) read_a(sy_int<ST + PD>());
+            acc[ST % 9] = sy_mfma_group(T(), a[ST % (PD + 1)], b[ST / 9], acc[ST % 9]);
             sy_sched_fence();
         });
     }
@@ -912,7 +915,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int STG, int EIGHT = 0>
+template <typename T, int STG, int EIGHT = 0, int PD = 2>
 int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
     if constexpr (T::kEPC != 8) {
         return SY_ERR_UNSUPPORTED;
@@ -937,7 +940,9 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 #ifndef SY_EMU
         static bool attr_done = false;
         if (!attr_done) {
-            const void* fn = EIGHT ? (const void*)conv_wgrad9b_kernel<T, STG> : (const void*)conv_wgrad9_kernel<T, STG>;
+            const void* fn;
+            if constexpr (EIGHT) fn = (const void*)conv_wgrad9b_kernel<T, STG>;
+            else fn = (const void*)conv_wgrad9_kernel<T, STG, PD>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
             attr_done = true;
         }
@@ -945,7 +950,7 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
         if constexpr (EIGHT) {
             SY_LAUNCH((conv_wgrad9b_kernel<T, STG>), dim3(gx, gy, splits), dim3(512), smem, stream, a);
         } else {
-            SY_LAUNCH((conv_wgrad9_kernel<T, STG>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
+            SY_LAUNCH((conv_wgrad9_kernel<T, STG, PD>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
         }
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
         if (splits > 1) return launch_fold(a, splits, 9, stream);
@@ -957,6 +962,8 @@ template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
     if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
     if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
+    if (a.tile == 50) return launch_wgrad9<T, 3, 0, 4>(a, ws_bytes, stream);  // ... x fragments requested four steps ahead instead of two:
+    if (a.tile == 66) return launch_wgrad9<T, 4, 0, 4>(a, ws_bytes, stream);  //     candidates for the next measurement round, not tuner defaults
     if (a.tile == 51) return launch_wgrad9<T, 3, 1>(a, ws_bytes, stream);  // ... on eight waves (two per SIMD), pipelined fragment reads
     if (a.tile == 67) return launch_wgrad9<T, 4, 1>(a, ws_bytes, stream);
     switch (a.tile) {          // (k rows x output channels) per workgroup

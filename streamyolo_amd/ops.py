@@ -483,6 +483,8 @@ class _TuneStore:
                     h.update(fn.encode() + b"\0" + f.read())
         h.update(_lib.lib().sy_version())
         h.update(repr((HALO_TILES, STREAM_1X1, TILE_1X1K)).encode())          # candidate-set switches (A/B runs)
+        if WGRAD_EXTRA:
+            h.update(repr(WGRAD_EXTRA).encode())
         # (no device name in the key: this library is gfx950-only, and torch reports an empty name under rocprofv3 — a profiled
         #  run then overwrote the cache of the normal runs with its own)
         return h.hexdigest()[:16]
@@ -671,6 +673,9 @@ _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 102
                      (49, 128), (49, 256), (49, 512), (65, 256), (65, 512),
                      # ... on eight waves (conv_wgrad9b_kernel)
                      (51, 128), (51, 256), (67, 256), (67, 512)]
+# further candidates for A/B runs, "tile:blocks,tile:blocks" (e.g. the deeper-prefetch 3x3 kernels "50:128,50:256,66:256"); part
+# of the tuner-cache key, so such a run tunes by itself
+WGRAD_EXTRA = [tuple(int(v) for v in e.split(":")) for e in _os.environ.get("STREAMYOLO_WGRAD_EXTRA", "").split(",") if e]
 
 def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace):
     """(tile, target_blocks) of the fastest sy_conv2d_wgrad variant for this shape (cached), (0, 0) when off."""
@@ -686,8 +691,8 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
     dy = View.alloc(N, Ho, Wo, Cout, code, device, zero=True)
     dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
     best, best_t = (0, 0), float("inf")
-    for (t, tb) in _WGRAD_CANDIDATES:
-        if t in (49, 65, 51, 67):
+    for (t, tb) in _WGRAD_CANDIDATES + WGRAD_EXTRA:
+        if t in (49, 65, 51, 67, 50, 66):
             if k != 3 or stride != 1 or Cin % 32 or Cout % 16:
                 continue
         elif (t & 15) in (1, 5, 6) and Cout < 128:

@@ -231,12 +231,14 @@ def test_conv3x3_halo_kernel(backend, tile, dt, mode):
         assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("tile", [49, 65, 51, 67])
+@pytest.mark.parametrize("tile", [49, 65, 51, 67, 50, 66])
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 144, 7, 37), (1, 32, 48, 5, 70)])
 def test_wgrad_all_taps_kernel(backend, tile, N, cin, cout, H, W):
     """conv_wgrad9_kernel (tile codes 49 / 65): 3x3 stride-1 weight gradient with all nine taps per workgroup and the x halo
     window resident in LDS — ragged 32-pixel row segments, ragged Cout tile, one split and many splits (+ fold), packed and
     OIHW layouts, against torch and against the per-tap transpose-read kernel."""
+    if tile in (50, 66) and str(backend) != "cpu" and not os.environ.get("STREAMYOLO_TEST_NEW_TILES"):
+        pytest.skip("deeper fragment prefetch: built after the round's last GPU minute — run with STREAMYOLO_TEST_NEW_TILES=1 first")
     dt = "bf16"
     g = torch.Generator().manual_seed(tile + cin)
     x = _q(torch.randn(N, cin, H, W, generator=g), dt)
