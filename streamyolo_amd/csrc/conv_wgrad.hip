@@ -981,6 +981,9 @@ int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
         case 22: return launch_wgrad_cfg<T, 2, 2, 1, 2, 3>(a, ws_bytes, stream);
         case 33: return launch_wgrad_cfg<T, 2, 2, 2, 2, 4>(a, ws_bytes, stream);
         case 34: return launch_wgrad_cfg<T, 4, 1, 1, 2, 4>(a, ws_bytes, stream);
+        // eight accumulator tiles per wave (16 MFMAs per slab barrier instead of 8): candidates for the next measurement round
+        case 35: return launch_wgrad_cfg<T, 2, 2, 4, 2, 3>(a, ws_bytes, stream);   // 256 x 128
+        case 36: return launch_wgrad_cfg<T, 2, 2, 2, 4, 3>(a, ws_bytes, stream);   // 128 x 256
         default: break;
     }
     // defaults: transpose-read variants (they fall back to the scatter kernel of the same tile when not applicable)
