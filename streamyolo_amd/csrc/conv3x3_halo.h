@@ -200,7 +200,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
 //     bn_silu_apply pass (2 + 2 bytes per element of HBM traffic and a launch) is not needed for this consumer.  The per-channel
 //     affine of all Cin channels is parked in LDS once per workgroup; out-of-image halo pixels stay zero (padding applies to the
 //     ACTIVATED tensor).
-template <typename T, int WC, int WP, int TC, int TP, int NORM = 0>
+//   * S2 (forward only): the same kernel for STRIDE 2.  The tile of TH x 32 output pixels needs (2 TH + 1) x 65 input pixels; they
+//     are parked with the columns split by parity — LDS row of input pixel (hy, hx) = hy * 66 + (hx & 1) * 33 + (hx >> 1) — so
+//     that the 32 lanes of a tap (input column 2 * lane + kw) read 32 CONSECUTIVE rows exactly as at stride 1 (same XOR swizzle,
+//     conflict free), and the parity split costs nothing: every DMA lane picks its own global pixel anyway.
+template <typename T, int WC, int WP, int TC, int TP, int NORM = 0, int S2 = 0>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1 : 2))) void conv3x3_halo2_kernel(ConvArgs p) {
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
@@ -208,7 +212,8 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     constexpr int BK = 4 * EPC;
     constexpr int CT = WC * TC * 32;
     constexpr int TH = WP * TP;
-    constexpr int HR = (TH + 2) * kHaloW;
+    constexpr int RW = S2 ? 66 : kHaloW;                   // LDS rows per input row of the tile
+    constexpr int HR = (S2 ? 2 * TH + 1 : TH + 2) * RW;
     constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;
     constexpr int BUF = NW * NI * 16 * 64;
     constexpr int BD = (TC * TP <= 2) ? SY_HALO2_BD : 3;   // pixel-fragment ring: BD - 1 (tap, k-half) steps of reads in flight
@@ -233,10 +238,13 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int r = (wave + i * NW) * 16 + (lane >> 2);
-        const int hy = r / kHaloW, hx = r - hy * kHaloW;
-        const int h = h0 - 1 + hy, w = w0 - 1 + hx;
+        const int hy = r / RW;
+        int hx = r - hy * RW;
+        bool col_ok = true;
+        if constexpr (S2) { col_ok = hx != 65; hx = hx >= 33 ? 2 * (hx - 33) + 1 : 2 * hx; }     // parity planes: even columns, then odd
+        const int h = (S2 ? 2 * h0 : h0) - 1 + hy, w = (S2 ? 2 * w0 : w0) - 1 + hx;
         const int chunk = (lane & 3) ^ ((r >> 2) & 3);
-        const bool ok = r < HR && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W && !(p.ablate & 1);
+        const bool ok = r < HR && col_ok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W && !(p.ablate & 1);
         voff[i] = ok ? (unsigned)((((long long)n * p.xbs + ((long long)h * p.W + w) * p.ldx) + chunk * EPC) * ESZ) : 0xFFFFFFFFu;
     }
     const sy_lds_base_t lds0 = sy_lds_base(smem);
@@ -288,10 +296,10 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap % 3;
-        const int toff = fwd ? (kh * kHaloW + kw) : ((2 - kh) * kHaloW + (2 - kw));
+        const int toff = S2 ? (kh * RW + (kw & 1) * 33 + (kw >> 1)) : (fwd ? (kh * kHaloW + kw) : ((2 - kh) * kHaloW + (2 - kw)));
 #pragma unroll
         for (int u = 0; u < TP; ++u) {
-            const int row = (wp * TP + u) * kHaloW + l31 + toff;
+            const int row = (S2 ? 2 : 1) * (wp * TP + u) * RW + l31 + toff;
             ba[tap][u] = (unsigned)(row * 64 + ((half ^ ((row >> 2) & 3)) << 4));
         }
     }
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
                 sh[j] = aff[p.Cin + cs * BK + c * EPC + j];
             }
             for (int r = tid >> 2; r < HR; r += NW * 16) {
+                static_assert(!(NORM && S2), "input normalisation: stride 1 only");
                 const int hy = r / kHaloW, hx = r - hy * kHaloW;
                 const int h = h0 - 1 + hy, w = w0 - 1 + hx;
                 if ((unsigned)h >= (unsigned)p.H || (unsigned)w >= (unsigned)p.W) continue;     // padding of the ACTIVATED tensor: zeros
@@ -393,14 +402,21 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int NORM = 0>
+template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int NORM = 0, int S2 = 0>
 int launch_halo(const ConvArgs& a_in, void* stream) {
     constexpr int NW = WC * WP, CT = WC * TC * 32, TH = WP * TP, PT = TH * 32;
-    constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
+    constexpr int HR = S2 ? (2 * TH + 1) * 66 : (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
+    static_assert(!S2 || (GEN == 2 && !NORM), "stride 2: second-generation kernel, forward");
     ConvArgs a = a_in;
     a.s2_classes = 0;
     // 3x3, stride 1, "same" padding, whole channel slabs, 32-bit addressable input, fragment-packed weights
-    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
+    if constexpr (S2) {
+        if (a.KH != 3 || a.KW != 3 || a.stride != 2 || a.pad != 1 || a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2 || a.mode != SY_CONV_FWD ||
+            a.ksplit > 1)
+            return SY_ERR_UNSUPPORTED;
+    } else {
+        if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
+    }
     if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
     if (NORM && (a.in_scale == nullptr || a.in_seg_N <= 0 || a.Cin > 2048 || a.mode != SY_CONV_FWD)) return SY_ERR_UNSUPPORTED;
     constexpr size_t smem_k = 2 * (size_t)BUF + (NORM ? 2 * 2048 * sizeof(float) : 0);
@@ -415,14 +431,14 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     static bool attr_done = false;
     if (!attr_done) {
         const void* fn;                                        // (if constexpr: only the generation this tile code launches is instantiated)
-        if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM>;
+        if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM, S2>;
         else fn = (const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
     if constexpr (GEN == 2) {
-        SY_LAUNCH((conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM>), grid, dim3(NW * 64), smem, stream, a);
+        SY_LAUNCH((conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM, S2>), grid, dim3(NW * 64), smem, stream, a);
     } else {
         SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
     }
@@ -446,6 +462,9 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         // (not in the tuner's default candidate set: STREAMYOLO_HALO_TILES)
         case 119: return launch_halo<T, 2, 2, 2, 4, 2>(a, stream);  // 128 ch x ( 8 rows x 32 px), 4 waves x (64 ch x 128 px)
         case 111: return launch_halo<T, 2, 2, 4, 2, 2>(a, stream);  // 256 ch x ( 4 rows x 32 px), 4 waves x (128 ch x 64 px)
+        // STRIDE 2, forward (tile 117's configuration; the stride-2 layers run on the implicit-GEMM kernel today, 16 instructions
+        // per MFMA in its loop): candidate for the next measurement round (STREAMYOLO_HALO_S2_TILES)
+        case 110: return launch_halo<T, 4, 1, 1, 2, 2, 0, 1>(a, stream);
         default: return SY_ERR_ARG;
     }
 }

@@ -514,3 +514,42 @@ def test_wgrad_eight_accumulator_tiles(backend, tile, k, stride, cin, cout, N, H
         dw = torch.zeros(cout, k * k * cin, device=backend)
         ops.conv2d_wgrad(xv, dyv, dw, k, stride, workspace=ws, tile=tile, target_blocks=tb)
         assert _rel(dw.cpu(), ref) < TOL[dt], "splits target %d" % tb
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 72, 11, 37), (1, 32, 160, 8, 66), (2, 64, 128, 5, 130)])
+def test_conv3x3_stride2_halo_kernel(backend, dt, N, cin, cout, H, W):
+    """conv3x3_halo2_kernel<..., S2> (tile code 110): the 3x3 STRIDE-2 forward with the (2 TH + 1) x 65 input window resident in
+    LDS, columns split by parity — odd and even input sizes, ragged output tiles and channel tiles, training epilogue (raw output
+    + per-frame statistics) and eval epilogue (affine + SiLU), against torch and against the implicit-GEMM kernel."""
+    if str(backend) != "cpu" and not os.environ.get("STREAMYOLO_TEST_NEW_TILES"):
+        pytest.skip("built after the round's last GPU minute — run with STREAMYOLO_TEST_NEW_TILES=1 first")
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
+    w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, dt)
+    y = F.conv2d(x, w, None, 2, 1)
+    Ho, Wo = y.shape[2], y.shape[3]
+    xv = View.alloc(N, H, W, cin + 32, dt, backend, zero=True).slice(32, cin); xv.set_nchw(x.to(backend))
+    wp = pack_conv_weight(w, code).to(backend)
+    wf = pack_conv_weight_frag(wp, 3)
+    yv = View.alloc(N, Ho, Wo, cout + 8, dt, backend, zero=True).slice(8, cout)
+    segs = 2 if N % 2 == 0 else 1
+    ssum = torch.zeros(segs * 4 * cout, device=backend); ssq = torch.zeros(segs * 4 * cout, device=backend)
+    ops.conv2d(xv, wp, yv, 3, 2, stats=(ssum, ssq), tile=110, wfrag=wf, segments=segs)
+    assert _rel(yv.nchw().cpu(), y) < TOL[dt]
+    assert float(yv.buf[..., :8].float().abs().max()) == 0.0
+    for s_ in range(segs):
+        ys = y[s_ * (N // segs):(s_ + 1) * (N // segs)]
+        assert _rel(ssq.view(segs, 4, cout)[s_].sum(0).cpu(), (ys ** 2).sum((0, 2, 3))) < 1e-3
+        assert float((ssum.view(segs, 4, cout)[s_].sum(0).cpu() - ys.sum((0, 2, 3))).abs().max()) < 1e-2 * float(ys.abs().sum((0, 2, 3)).max())
+    scale, shift = (torch.rand(cout, generator=g) + 0.5), torch.randn(cout, generator=g) * 0.3
+    ops.conv2d(xv, wp, yv, 3, 2, scale.to(backend), shift.to(backend), epilogue=ops.EPI_SILU, tile=110, wfrag=wf)
+    ref = F.silu(y * scale[None, :, None, None] + shift[None, :, None, None])
+    assert _rel(yv.nchw().cpu(), ref) < TOL[dt]
+    ref_v = View.alloc(N, Ho, Wo, cout, dt, backend)
+    ops.conv2d(xv, wp, ref_v, 3, 2, scale.to(backend), shift.to(backend), epilogue=ops.EPI_SILU, tile=19)   # implicit GEMM, same operands
+    assert _rel(yv.nchw().cpu(), ref_v.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
+    # the data gradient of a stride-2 layer stays on the implicit-GEMM kernel
+    with pytest.raises(ops._lib.HipLibraryError):
+        ops.conv2d(ref_v, wp, xv, 3, 2, mode=ops.CONV_DGRAD, tile=110, wfrag=wf)
