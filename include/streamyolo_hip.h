@@ -308,6 +308,19 @@ SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda
                                 int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
                                 int dres_accumulate, int dtype, int nseg, void* stream);
 
+/* sy_bn_silu_bwd_reduce + sy_bn_silu_bwd_apply in ONE launch for tensors small enough that every workgroup of the launch is
+ * resident at once (the workgroups of a channel slice wait for each other, their chunk of both tensors held in registers):
+ * both tensors are read once, one dependent launch instead of two.  sums: fp32 [nseg][2][C], ZERO on entry (sum dz | sum dz*xhat
+ * afterwards); tickets: uint32 [nseg][C / slice][2] counters, zero before the first launch (they reset themselves).
+ * Returns SY_ERR_UNSUPPORTED when the tensor is too large for a resident launch: use the two-pass entries then.  "Resident" is
+ * the kernel's occupancy x CU count divided by SY_BN_FUSED_SHARE (default 2): launches of this entry on different streams may run
+ * at the same time, and two partially resident launches would wait for each other's slots.
+ * dres_accumulate: bit 0 = += into dres, bit 1 = dgamma / dbeta by atomics (as sy_bn_silu_bwd_apply). */
+SY_API int sy_bn_silu_bwd_fused(const void* y, int ldy, const void* da, int ldda, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* gamma, float* sums, uint32_t* tickets,
+                                void* dy, int lddy, int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
+                                int dres_accumulate, int dtype, int nseg, void* stream);
+
 /* SimOTA assignment + Trend-Aware loss, forward and gradient, for a whole batch, no host sync.
  * raw [B, A, 5+nc] fp32 raw head logits (reg4, obj, cls); labels/support [B, max_labels, 5] fp32 rows
  * (cls, cx, cy, w, h) zero padded; level_h/w/stride describe the anchor grid (level-major, row-major).

@@ -19,6 +19,7 @@ EPI_LINEAR, EPI_SILU, EPI_SIGMOID, EPI_DECODE = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD = 0, 1
 
 _ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape"}
+SY_ERR_UNSUPPORTED = 3
 
 
 class HipLibraryError(RuntimeError):
@@ -114,6 +115,7 @@ SIGNATURES = {
     "sy_bn_finalize_apply": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sy_bn_silu_bwd_fused": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),

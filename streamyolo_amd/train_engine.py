@@ -41,6 +41,10 @@ _FUSED_FINALIZE = __import__("os").environ.get("STREAMYOLO_FUSED_FINALIZE", "0")
 # a dependent launch on the critical path costs its drain + dispatch whatever it does).  Built and parity-tested at the end of
 # round 3 with no GPU time left to measure it: default off until it has been.
 CONV_FINALIZE = __import__("os").environ.get("STREAMYOLO_CONV_FINALIZE", "0") != "0"
+# BatchNorm.SiLU backward of the small / medium maps as ONE launch (sy_bn_silu_bwd_fused: the workgroups of a channel slice wait for
+# each other with their chunk of both tensors in registers) instead of reduce + apply; tensors too large for a resident launch
+# keep the two passes.  A kernel that spins is developed ON the GPU: built and emulator-green at the end of round 3, default off.
+BN_BWD_FUSED = __import__("os").environ.get("STREAMYOLO_BN_BWD_FUSED", "0") != "0"
 
 class _GradSpace:
     """Gradient mirrors of activation buffers + first-write / accumulate bookkeeping per channel range."""
@@ -636,18 +640,35 @@ class TrainPlan:
         g, b_ = self.cache.bn[id(op.mod)]
         return g, b_, bn.eps, mom
 
+    def _tickets(self, n):
+        """n zeroed int32 counters (self-resetting ticket words of the fin / fused-backward kernels)."""
+        if self._fin_tickets is None or self._fin_off + n > self._fin_tickets.numel():
+            self._fin_tickets, self._fin_off = torch.zeros(max(4096, n), dtype=torch.int32, device=self.device), 0
+        tk = self._fin_tickets[self._fin_off:self._fin_off + n]
+        self._fin_off += n
+        return tk
+
+    def _bn_bwd(self, op, y, da, aff, gamma, bsum, dy, dgamma, dbeta, nseg=1, dres=None, acc=False, atomic=False):
+        """BatchNorm.SiLU backward of one launch unit: one fused launch where the tensor allows it (BN_BWD_FUSED), else the two passes."""
+        if BN_BWD_FUSED:
+            key = "bwdtk%d" % nseg
+            tk = op._tiles.get(key)
+            if tk is None:
+                tk = op._tiles[key] = self._tickets(nseg * 2 * max(1, y.C // 8))
+            if ops.bn_silu_bwd_fused(y, da, *aff, gamma, bsum, tk, dy, dgamma, dbeta, nseg=nseg, dres=dres, dres_accumulate=acc,
+                                     atomic_param_grads=atomic):
+                return
+        ops.bn_silu_bwd_reduce(y, da, *aff, bsum, nseg=nseg)
+        ops.bn_silu_bwd_apply(y, da, *aff, gamma, bsum, dy, dgamma, dbeta, nseg=nseg, dres=dres, dres_accumulate=acc,
+                              atomic_param_grads=atomic)
+
     def _fin(self, op, gamma, beta, eps, aff, nseg):
         """The sy_bn_fin record of `op`'s statistics launch (nseg = 2: the paired launch over both frames), built once."""
         assert not _FUSED_FINALIZE
         key = "fin%d" % nseg
         rec = op._tiles.get(key)
         if rec is None:
-            n = nseg * ((op.y.C + 31) // 32)
-            if self._fin_tickets is None or self._fin_off + n > self._fin_tickets.numel():
-                self._fin_tickets, self._fin_off = torch.zeros(4096, dtype=torch.int32, device=self.device), 0
-            tk = self._fin_tickets[self._fin_off:self._fin_off + n]
-            self._fin_off += n
-            rec = op._tiles[key] = ops.BnFinRecord(tk, gamma, beta, eps, op.y.pixels, *aff)
+            rec = op._tiles[key] = ops.BnFinRecord(self._tickets(nseg * ((op.y.C + 31) // 32)), gamma, beta, eps, op.y.pixels, *aff)
         return rec
 
     def _bn_grads(self, op):
@@ -1012,9 +1033,7 @@ class TrainPlan:
         dY = G.view(op.y)
         dres, acc = (None, False) if op.res is None else G.target(op.res)    # y = silu(bn(conv)) + res: dres (+)= dY
         scale, shift, mean, invstd = op.aff
-        ops.bn_silu_bwd_reduce(op.yraw, dY, scale, shift, mean, invstd, op.bsum)
-        ops.bn_silu_bwd_apply(op.yraw, dY, scale, shift, mean, invstd, gamma, op.bsum, dyraw,
-                              dgamma, dbeta, dres=dres, dres_accumulate=acc)
+        self._bn_bwd(op, op.yraw, dY, (scale, shift, mean, invstd), gamma, op.bsum, dyraw, dgamma, dbeta, dres=dres, acc=acc)
 
     def _wgrad(self, op, x, dyraw):
         w = base_convs(op.mod)[0].conv.weight                        # stacked parts: their arena slots follow this one
@@ -1063,9 +1082,7 @@ class TrainPlan:
             dres2 = dra.pair()                                       # written by the BN backward apply pass below
         _, _, u_bsum, (scale, shift, mean, invstd) = a.unit
         raw2 = a.yraw.pair()
-        ops.bn_silu_bwd_reduce(raw2, dY2, scale, shift, mean, invstd, u_bsum, nseg=2)
-        ops.bn_silu_bwd_apply(raw2, dY2, scale, shift, mean, invstd, gamma, u_bsum, dy2,
-                              dgamma, dbeta, nseg=2, dres=dres2, dres_accumulate=acca)
+        self._bn_bwd(a, raw2, dY2, (scale, shift, mean, invstd), gamma, u_bsum, dy2, dgamma, dbeta, nseg=2, dres=dres2, acc=acca)
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot)
         if a.need_dx:
             dxa, acca = G.target(a.x)
@@ -1097,9 +1114,8 @@ class TrainPlan:
             self._mark("acquire_cur", slot)                          # the wgrad that last read this slot has retired
             dres, acc = (None, False) if op.res is None else G.target(op.res)
             scale, shift, mean, invstd = op.aff
-            ops.bn_silu_bwd_reduce(op.yraw, G.view(op.y), scale, shift, mean, invstd, op.bsum)
-            ops.bn_silu_bwd_apply(op.yraw, G.view(op.y), scale, shift, mean, invstd, gamma, op.bsum, dyr, dgamma, dbeta,
-                                  dres=dres, dres_accumulate=acc, atomic_param_grads=True)
+            self._bn_bwd(op, op.yraw, G.view(op.y), (scale, shift, mean, invstd), gamma, op.bsum, dyr, dgamma, dbeta,
+                         dres=dres, acc=acc, atomic=True)
         self._chain = 0
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot, chains=(0, 2))
         if a.need_dx:

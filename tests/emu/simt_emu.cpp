@@ -166,14 +166,14 @@ Pool& pool() {
 std::mutex g_launch_mutex;      // one emulated launch at a time per process (launches from several host threads serialise)
 }  // namespace
 
-void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body) {
+void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body, bool coresident) {
     const unsigned long long nblocks = (unsigned long long)grid.x * grid.y * grid.z;
     if (nblocks == 0) return;
     const unsigned nthr = block.x * block.y * block.z;
     unsigned nworkers = std::thread::hardware_concurrency();
     if (const char* e = std::getenv("SY_EMU_THREADS")) nworkers = (unsigned)std::atoi(e);
     if (nworkers < 1) nworkers = 1;
-    if (nworkers > nblocks) nworkers = (unsigned)nblocks;
+    if (nworkers > nblocks || coresident) nworkers = (unsigned)nblocks;
     std::atomic<unsigned long long> next{0};
     const std::function<void()> worker = [&]() {
         unsigned char* const stacks = t_scratch.stack_base((size_t)(nthr + 1) * kStack);
@@ -191,6 +191,8 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>&
         }
     };
     if (nworkers == 1) { worker(); return; }
+    // (a co-resident launch: each worker takes exactly one block only if all of them start — they do, the pool grows to nworkers;
+    //  a worker that finishes early finds the block counter exhausted)
     std::lock_guard<std::mutex> lk(g_launch_mutex);
     pool().run(nworkers, worker);
 }

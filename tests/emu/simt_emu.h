@@ -93,7 +93,9 @@ inline void barrier_drop(Barrier& b) {
     if (b.expected > 0 && b.count == b.expected) { b.count = 0; ++b.gen; }
 }
 
-void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body);
+// coresident: every workgroup of the launch runs at the same time (one OS thread each) — for kernels whose workgroups wait for
+// one another (a bounded grid that is fully resident on the device)
+void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body, bool coresident = false);
 
 inline int lane_id() { const dim3& t = self().tid; Block* b = g_blk; return (int)((t.x + t.y * b->bdim.x + t.z * b->bdim.x * b->bdim.y) & 63); }
 inline int wave_id() { const dim3& t = self().tid; Block* b = g_blk; return (int)((t.x + t.y * b->bdim.x + t.z * b->bdim.x * b->bdim.y) >> 6); }

@@ -497,3 +497,57 @@ def test_batchnorm_finalised_by_the_convolution_matches_the_finalize_launch(back
         assert _rel(gb[k].cpu(), ga[k].cpu()) < tol, k
     for k in ra:
         assert _rel(rb[k], ra[k]) < (1e-6 if str(backend) == "cpu" else 1e-5), k
+
+
+def test_batchnorm_backward_in_one_launch_matches_the_two_passes(backend, monkeypatch):
+    """STREAMYOLO_BN_BWD_FUSED: reduce + apply of the BatchNorm.SiLU backward as one launch wherever the tensor fits a resident
+    launch — same loss, gradients and running statistics as the default plan through the direct step, the recorded step and tape
+    replays (the ticket words must reset themselves for that)."""
+    from streamyolo_amd import train_engine, ops as ops_mod
+    from streamyolo_amd.train_engine import TrainStep
+    if str(backend) != "cpu" and not os.environ.get("STREAMYOLO_TEST_NEW_TILES"):
+        pytest.skip("a kernel that spins: built after the round's last GPU minute — run with STREAMYOLO_TEST_NEW_TILES=1 first")
+    res = {}
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    Hh, Ww = (32, 64) if str(backend) == "cpu" else (128, 192)
+    x = synth_frames(2, Hh, Ww, seed=2).to(backend)
+    lab, sup = synth_labels(2, Hh, Ww, cfg.num_classes, num_gt=4, seed=3)
+    targets = (lab.to(backend), sup.to(backend))
+    calls = {"fused": 0, "two": 0}
+    real_f, real_r = ops_mod.bn_silu_bwd_fused, ops_mod.bn_silu_bwd_reduce
+
+    def fused(*a, **k):
+        ok = real_f(*a, **k)
+        calls["fused"] += 1 if ok else 0
+        return ok
+
+    def reduce(*a, **k):
+        calls["two"] += 1
+        return real_r(*a, **k)
+    monkeypatch.setattr(ops_mod, "bn_silu_bwd_fused", fused)
+    monkeypatch.setattr(ops_mod, "bn_silu_bwd_reduce", reduce)
+    for mode in ("two_pass", "fused"):
+        monkeypatch.setattr(train_engine, "BN_BWD_FUSED", mode == "fused")
+        calls["fused"] = calls["two"] = 0
+        model = sy.build_model("nano")
+        model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        model = model.to(backend).train().set_compute_dtype("fp32")
+        model.head.use_l1 = True
+        st = TrainStep(model, graph=False)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        for _ in range(4):                                       # direct, recorded, replayed twice
+            model.load_state_dict(state0)
+            out = st.step(x, targets)
+        assert (calls["fused"] > 0) == (mode == "fused")
+        if mode == "fused":
+            assert calls["fused"] > 10 * max(1, calls["two"])    # (nearly) every layer of this small model takes the one launch
+            assert int(st.plan._fin_tickets.abs().sum()) == 0
+        res[mode] = (float(out["total_loss"]), {n: st.plan.gview[id(p)].clone() for n, p in model.named_parameters()},
+                     st.plan.loss_ws.fg.clone())
+    (la, ga, fa), (lb, gb, fb) = res["two_pass"], res["fused"]
+    assert abs(la - lb) / abs(la) < 1e-6
+    if int((fa != fb).sum()):
+        return
+    for k in ga:
+        assert _rel(gb[k].cpu(), ga[k].cpu()) < (2e-5 if str(backend) == "cpu" else 1e-3), k
