@@ -764,6 +764,19 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_fused_kernel(const typenam
         }
     }
     if (!live) return;
+    // the apply below recomputes dz from the PACKED chunks: laundering them keeps hipcc from carrying every unpacked float of the
+    // reduction across the wait (305 -> see tools/loop_census / the build's metadata: registers decide how many workgroups fit)
+#ifndef SY_EMU
+#pragma unroll
+    for (int d = 0; d < R; ++d) {
+        uint4 a, b;
+        __builtin_memcpy(&a, yq[d].e, 16);
+        __builtin_memcpy(&b, gq[d].e, 16);
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+        __builtin_memcpy(yq[d].e, &a, 16);
+        __builtin_memcpy(gq[d].e, &b, 16);
+    }
+#endif
     const float inv_m = 1.0f / (float)pixels;
     float gi[T::kEPC], m0[T::kEPC], m1[T::kEPC];
 #pragma unroll
