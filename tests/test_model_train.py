@@ -479,7 +479,7 @@ def test_batchnorm_finalised_by_the_convolution_matches_the_finalize_launch(back
         model.head.use_l1 = True
         st = TrainStep(model, graph=False)
         state0 = {k: v.clone() for k, v in model.state_dict().items()}
-        for _ in range(4):                                       # direct, recorded, replayed twice
+        for _ in range(3):                                       # direct, recorded, replayed
             model.load_state_dict(state0)
             out = st.step(x, targets)
         assert (calls["n"] == 0) == (mode == "in_conv")
@@ -536,7 +536,7 @@ def test_batchnorm_backward_in_one_launch_matches_the_two_passes(backend, monkey
         model.head.use_l1 = True
         st = TrainStep(model, graph=False)
         state0 = {k: v.clone() for k, v in model.state_dict().items()}
-        for _ in range(4):                                       # direct, recorded, replayed twice
+        for _ in range(3):                                       # direct, recorded, replayed
             model.load_state_dict(state0)
             out = st.step(x, targets)
         assert (calls["fused"] > 0) == (mode == "fused")
