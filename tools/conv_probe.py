@@ -60,8 +60,9 @@ def main():
     ap.add_argument("--copies", type=int, default=16, help="stats mode: replicas of the statistics arrays per segment")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    tiles = [int(t) for t in a.tiles.split(",")]
-    sel = [int(i) for i in a.shapes.split(",")] if a.shapes else range(len(SHAPES))
+    # ("+" works as a separator too: tools/gpu.sh splits task arguments at commas)
+    tiles = [int(t) for t in a.tiles.replace("+", ",").split(",")]
+    sel = [int(i) for i in a.shapes.replace("+", ",").split(",")] if a.shapes else range(len(SHAPES))
     def nm(t):
         return NAMES.get(t & 255, "tile%d" % (t & 255)) + {0: "", 1: "-noX", 2: "-noW", 3: "-noXW", 8: "-noAtom", 24: "-noStatRed"}[t >> 8]
     print("%-10s %-28s " % ("layer", "shape") + " ".join("%15s" % nm(t) for t in tiles) + "   (TFLOP/s, median of %d)" % a.reps)

@@ -22,8 +22,8 @@ def main():
     dev = torch.device("cuda:0")
     variants = [(1, 1024), (2, 512), (4, 1024), (17, 512), (17, 1024), (33, 1024), (18, 512), (18, 1024), (34, 1024), (20, 1024), (22, 1024), (21, 1024)]
     if a.variants:
-        variants = [tuple(int(v) for v in p.split("/")) for p in a.variants.split(",")]
-    sel = [int(i) for i in a.shapes.split(",")] if a.shapes else range(len(SHAPES))
+        variants = [tuple(int(v) for v in p.split("/")) for p in a.variants.replace("+", ",").split(",")]
+    sel = [int(i) for i in a.shapes.replace("+", ",").split(",")] if a.shapes else range(len(SHAPES))
     ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     print("%-10s %-28s " % ("layer", "shape") + " ".join("%9s" % ("t%d/%d" % v) for v in variants) + "   (TFLOP/s)")
     for i in sel:
