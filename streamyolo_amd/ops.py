@@ -555,9 +555,9 @@ def save_tuned():
     _tune_store.save()
 
 
-HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "112,113,114,115,116,117,118").split(",") if t]
+HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "112,113,114,115,116,117,118").replace("+", ",").split(",") if t]
 # stride-2 3x3 forward on the halo kernel (tile code 110): empty until it has been measured
-HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "").split(",") if t]
+HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "").replace("+", ",").split(",") if t]
 STREAM_1X1 = _os.environ.get("STREAMYOLO_STREAM_1X1", "1") != "0"
 TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123").split(",") if t]
 
@@ -698,7 +698,9 @@ _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 102
                      (51, 128), (51, 256), (67, 256), (67, 512)]
 # further candidates for A/B runs, "tile:blocks,tile:blocks" (e.g. the deeper-prefetch 3x3 kernels "50:128,50:256,66:256"); part
 # of the tuner-cache key, so such a run tunes by itself
-WGRAD_EXTRA = [tuple(int(v) for v in e.split(":")) for e in _os.environ.get("STREAMYOLO_WGRAD_EXTRA", "").split(",") if e]
+# ("tile/blocks+tile/blocks" is accepted as well: tools/gpu.sh splits its task arguments at ":" and ",")
+WGRAD_EXTRA = [tuple(int(v) for v in e.replace("/", ":").split(":"))
+               for e in _os.environ.get("STREAMYOLO_WGRAD_EXTRA", "").replace("+", ",").split(",") if e]
 
 def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace):
     """(tile, target_blocks) of the fastest sy_conv2d_wgrad variant for this shape (cached), (0, 0) when off."""
