@@ -262,6 +262,13 @@ BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "auto")
 HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "1") != "0"
 DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "1") != "0"
 WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD_STREAMS", "2")) if DUAL_WGRAD else 1))]
+# A/B knobs for the next measurement round (the ablation says the weight gradients cost 4.0 ms of their 6.7 ms of kernel time:
+# they take CUs from the main chain): "off1" = weight gradients only on their own streams (3, 4, ...) instead of sharing stream 1
+# with the forward pass's support-frame chain, and a hardware queue priority for those streams (1 = low on ROCm, 0 = default)
+WGRAD_OWN_STREAMS = os.environ.get("STREAMYOLO_WGRAD_OWN_STREAMS", "0") != "0"
+WGRAD_PRIORITY = int(os.environ.get("STREAMYOLO_WGRAD_PRIORITY", "0"))
+if WGRAD_OWN_STREAMS:
+    WGRAD_STREAMS = [3, 4, 5][:max(1, len(WGRAD_STREAMS))]
 NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
 
 
@@ -378,7 +385,8 @@ class TrainPlan:
         w_ = float(getattr(pafpn, "width", 1.0)) if pafpn is not None else 0.0
         self.bwd_split = (BWD_SPLIT_FRAMES == "1") or (BWD_SPLIT_FRAMES == "auto" and B * H * W * w_ * w_ >= 2.0e6)
         self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and (self.bwd_split or HEAD_BWD_CHAINS)) else None
-        self.side_w = {k: torch.cuda.Stream(device=device) for k in WGRAD_STREAMS[1:]} if self.side is not None else {}
+        self.side_w = {k: torch.cuda.Stream(device=device, priority=WGRAD_PRIORITY)
+                       for k in (WGRAD_STREAMS if WGRAD_OWN_STREAMS else WGRAD_STREAMS[1:])} if self.side is not None else {}
         self.side3 = self.side_w.get(3)
         self._chain, self._wg_stream, self._wg_flip = 0, 1, 0
         self.tuned = False                    # the first step (autotuning) runs on one stream
@@ -492,7 +500,7 @@ class TrainPlan:
             slots = [torch.empty(ring_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.RING)]
             self._scratch_gen = 0
         self.dyraw_ring = [t[:self.max_raw * esz].view(self.tdtype) for t in slots]
-        self.wgrad_ws_by = {1: self.wgrad_ws}
+        self.wgrad_ws_by = {1: self.wgrad_ws, WGRAD_STREAMS[0]: self.wgrad_ws}
         for k in WGRAD_STREAMS[1:]:                              # one split-K workspace per weight-gradient stream
             self.wgrad_ws_by[k] = (self.pool.shared_scratch("wgrad_ws%d" % k, self.WGRAD_WS_BYTES, self.device)
                                    if self.pool is not None else torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device))
@@ -961,6 +969,9 @@ class TrainPlan:
         if split:
             self._mark("cur", 0)
             self._mark("dep", (2, 0))
+        for k in WGRAD_STREAMS:                                  # "join" covers stream 1; the further weight-gradient streams join
+            if k != 1:                                           # here: whoever reads the arena next does so on the main stream
+                self._mark("dep", (k, 0))
         self._mark("join")
 
     # ---- weight gradients off the critical path -------------------------------------------------------------

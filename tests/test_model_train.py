@@ -551,3 +551,34 @@ def test_batchnorm_backward_in_one_launch_matches_the_two_passes(backend, monkey
         return
     for k in ga:
         assert _rel(gb[k].cpu(), ga[k].cpu()) < (2e-5 if str(backend) == "cpu" else 1e-3), k
+
+
+def test_backward_tape_joins_every_weight_gradient_stream(backend, monkeypatch):
+    """The backward tape must end with main-stream waits for EVERY stream that carried a weight gradient (stream 1 through the
+    "join" mark, streams 3+ through "dep" marks): the arena's next reader — optimizer, all-reduce of late buckets, the caller —
+    works on the main stream."""
+    from streamyolo_amd import _lib, train_engine
+    from streamyolo_amd.train_engine import TrainStep
+    marks = []
+    real = _lib.NativeTape.mark
+
+    def logged(self, name, arg=None):
+        marks.append((name, arg))
+        return real(self, name, arg)
+    monkeypatch.setattr(_lib.NativeTape, "mark", logged)
+    assert train_engine.WGRAD_STREAMS[:2] == [1, 3]                  # the default: weight gradients alternate between two streams
+    cfg = O.OracleConfig.named("nano")
+    model = sy.build_model("nano")
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0), strict=True)
+    model = model.to(backend).train().set_compute_dtype("fp32")
+    x = synth_frames(2, 32, 64, seed=2).to(backend)
+    lab, sup = synth_labels(2, 32, 64, cfg.num_classes, num_gt=4, seed=3)
+    st = TrainStep(model, graph=False)
+    st.step(x, (lab.to(backend), sup.to(backend)))                   # direct
+    marks.clear()
+    st.step(x, (lab.to(backend), sup.to(backend)))                   # recorded: forward tape, then backward tape
+    used = {a for n, a in marks if n == "cur" and a not in (None, 0, 2)}
+    assert 3 in used and 1 in used
+    last_use = max(i for i, (n, a) in enumerate(marks) if n == "cur" and a == 3)
+    assert any(n == "dep" and a == (3, 0) for n, a in marks[last_use:]), "stream 3 is never joined after its last weight gradient"
+    assert marks[-1][0] == "join"
