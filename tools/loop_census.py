@@ -43,7 +43,17 @@ for f in sorted(glob.glob(WORK + '/*.hipv4-amdgcn-amd-amdhsa--gfx950')):
         if best:
             n,body=best
             c=collections.Counter(classify(l) for a,l in body)
-            print("%-78s loop %4d instr, %3d mfma -> %.2f others/mfma  %s" % (cur[14:92], len(body), n, (len(body)-n)/n, {k:v for k,v in sorted(c.items()) if k!='mfma'}))
+            # bytes per wave-instruction (64 lanes): what one MFMA slot asks of LDS and of the L1 / L2 path
+            width={'b128':1024,'dwordx4':1024,'b96':768,'dwordx3':768,'b64':512,'dwordx2':512,'b32':256,'dword':256}
+            def nbytes(l):
+                op=l.split()[0]
+                for k,v in width.items():
+                    if op.endswith(k) or ('_'+k+'_') in op or op.endswith(k+'_tr_b16') or (k in op and op.startswith('ds_read')): return v
+                return 0
+            lds_b=sum(nbytes(l) for a,l in body if l.split()[0].startswith('ds_read'))
+            l2_b=sum(nbytes(l) for a,l in body if l.split()[0].startswith(('buffer_load','global_load')))
+            print("%-78s loop %4d instr, %3d mfma -> %.2f others/mfma, LDS reads %.2f KB/mfma, global loads %.2f KB/mfma  %s" %
+                  (cur[14:92], len(body), n, (len(body)-n)/n, lds_b/n/1024, l2_b/n/1024, {k:v for k,v in sorted(c.items()) if k!='mfma'}))
     for line in txt.splitlines():
         m=re.match(r'^[0-9a-f]+ <(\S+)>:',line)
         if m: flush(); cur=m.group(1); ins=[]; continue
