@@ -462,6 +462,8 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         // (not in the tuner's default candidate set: STREAMYOLO_HALO_TILES)
         case 119: return launch_halo<T, 2, 2, 2, 4, 2>(a, stream);  // 128 ch x ( 8 rows x 32 px), 4 waves x (64 ch x 128 px)
         case 111: return launch_halo<T, 2, 2, 4, 2, 2>(a, stream);  // 256 ch x ( 4 rows x 32 px), 4 waves x (128 ch x 64 px)
+        case 109: return launch_halo<T, 1, 4, 4, 2, 2>(a, stream);  // 128 ch x ( 8 rows x 32 px), 4 waves x (128 ch x 64 px): all four waves
+                                                                    //   stream the SAME weight fragments (L1 hits), a quarter of the LDS reads
         // STRIDE 2, forward (tile 117's configuration; the stride-2 layers run on the implicit-GEMM kernel today, 16 instructions
         // per MFMA in its loop): candidate for the next measurement round (STREAMYOLO_HALO_S2_TILES)
         case 110: return launch_halo<T, 4, 1, 1, 2, 2, 0, 1>(a, stream);

@@ -122,7 +122,9 @@ __device__ __forceinline__ void conv_stats_finalize(const Args& p, int seg, int 
 
 // Staged write-out needs PT * (2 * CT + 16) bytes of LDS: up to 48 KiB for the tiles that share a CU with other workgroups; the
 // one-workgroup-per-CU tiles (8 accumulators per wave, conv3x3_halo.h tile codes 111 / 119) may take 96 KiB.
-template <int WC, int WP, int TC, int TP> struct StageLimit { static constexpr size_t kBytes = (WC == 2 && WP == 2 && TC * TP == 8 ? 96 : 48) * 1024; };
+template <int WC, int WP, int TC, int TP> struct StageLimit {
+    static constexpr size_t kBytes = (((WC == 2 && WP == 2 && TC * TP == 8) || (WC == 1 && WP == 4 && TC == 4 && TP == 2)) ? 96 : 48) * 1024;
+};
 
 // LDS in front of the staged output tile: BN-statistics scratch [WP][CT][2] floats
 template <int WP, int CT> struct EpiLds { static constexpr int kStatBytes = WP * CT * 8; };
@@ -995,13 +997,13 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
     }
 }
 
-template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 110..119)
+template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 109..119)
 template <typename T> int launch_1x1_stream(const ConvArgs& a, void* stream);      // conv1x1_stream.h (tile code 120)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..123)
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
-    if (a.tile >= 110 && a.tile <= 119) return launch_halo_typed<T>(a, stream);
+    if (a.tile >= 109 && a.tile <= 119) return launch_halo_typed<T>(a, stream);
     if (a.tile == 120) return launch_1x1_stream<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 123) return launch_1x1_tile<T>(a, stream);
     // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide
