@@ -455,6 +455,8 @@ def test_batchnorm_finalised_by_the_convolution_matches_the_finalize_launch(back
     launch and as two chains."""
     from streamyolo_amd import train_engine, ops as ops_mod
     from streamyolo_amd.train_engine import TrainStep
+    if str(backend) == "cpu" and not fwd_split:
+        pytest.skip("the paired-launch variant runs on the GPU only (CPU suite time); its two-segment records are covered at kernel level")
     res = {}
     cfg = O.OracleConfig.named("nano")
     sd = synth_state_dict(O.param_shapes(cfg), seed=0)
