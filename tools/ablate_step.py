@@ -49,7 +49,17 @@ lab, sup = synth_labels(args.batch, args.height, args.width, cfg.num_classes, se
 lab, sup = lab.to(dev), sup.to(dev)
 
 REAL = {n: getattr(ops, n) for n in ("conv2d", "conv2d_wgrad", "bn_finalize", "bn_finalize_apply", "bn_silu_apply",
-                                     "bn_silu_bwd_reduce", "bn_silu_bwd_apply")}
+                                     "bn_silu_bwd_reduce", "bn_silu_bwd_apply", "resize_nearest", "resize_nearest_bwd", "spp_pool",
+                                     "spp_pool_bwd", "view_copy", "rows_add_f32", "pred_grad_fold")}
+_dot = ops.View.alloc(1, 1, 1, 8, args.dtype, dev, zero=True)
+
+
+def tiny(n=1):
+    """n launches of a one-pixel kernel on the current launch stream: the step's launch / dependency skeleton without its work."""
+    def f(*a, **k):
+        for _ in range(n):
+            REAL["view_copy"](_dot, _dot)
+    return f
 
 
 def nothing(*a, **k):
@@ -77,6 +87,11 @@ CONFIGS = [
     ("bn_finalize", {"bn_finalize": nothing}),
     ("all_bn_wgrad", {"bn_silu_apply": nothing, "bn_finalize_apply": nothing, "bn_silu_bwd_reduce": nothing, "bn_silu_bwd_apply": nothing,
                       "bn_finalize": nothing, "conv2d_wgrad": nothing}),
+    # every launch of the forward / backward passes replaced by a one-pixel kernel on the same stream (the loss stays): what the
+    # step costs as a STRUCTURE — ~1600 launches, their stream switches and event pairs — before any of its work
+    ("skeleton", {"conv2d": tiny(), "conv2d_wgrad": tiny(2), "bn_finalize": tiny(), "bn_finalize_apply": tiny(), "bn_silu_apply": tiny(),
+                  "bn_silu_bwd_reduce": tiny(), "bn_silu_bwd_apply": tiny(), "resize_nearest": tiny(), "resize_nearest_bwd": tiny(),
+                  "spp_pool": tiny(), "spp_pool_bwd": tiny(), "view_copy": tiny(), "rows_add_f32": tiny(), "pred_grad_fold": tiny()}),
     ("base_again", {}),
 ]
 only = [s for s in args.only.split(",") if s]
