@@ -47,7 +47,8 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
        SY_TILE_HALO = 112, /* 112..118: 3x3 stride-1 kernel with the input tile + halo resident in LDS (csrc/conv3x3_halo.h; needs
                              wfrag): 128 ch x 4 rows x 32 px (2x2 waves) | 128 x 4 (4x1 waves) | 128 x 2 (8 waves) | 128 x 2 | 64 x 8;
                              119 / 111 / 109: one workgroup per CU with eight accumulators per wave, 128 ch x 8 rows | 256 ch x 4 rows | 128 ch x 8 rows;
-                             110: STRIDE 2 forward, 128 ch x 2 output rows x 32 px, input window split by column parity */
+                             110: STRIDE 2 forward, 128 ch x 2 output rows x 32 px, input window split by column parity;
+                             108: STRIDE 2 data gradient (csrc/conv3x3_s2dgrad.h), four output-parity classes */
        SY_TILE_STREAM1X1 = 120, /* 1x1 stride-1 weight-stationary pixel stream (csrc/conv1x1_stream.h; raw 16-bit output, Cin 64 / 128 / 256) */
        SY_TILE_1X1K = 121 /* 121..123: 1x1 stride-1 kernel with the tile's whole K extent requested in one burst (csrc/conv1x1_tile.h; needs
                              wfrag, 16-bit types, Cin 64 / 128 / 256 / 512): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px */ };

@@ -998,12 +998,14 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
 }
 
 template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 109..119)
+template <typename T> int launch_s2dgrad(const ConvArgs& a, void* stream);         // conv3x3_s2dgrad.h (tile code 108)
 template <typename T> int launch_1x1_stream(const ConvArgs& a, void* stream);      // conv1x1_stream.h (tile code 120)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..123)
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
     if (a.tile >= 109 && a.tile <= 119) return launch_halo_typed<T>(a, stream);
+    if (a.tile == 108) return launch_s2dgrad<T>(a, stream);
     if (a.tile == 120) return launch_1x1_stream<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 123) return launch_1x1_tile<T>(a, stream);
     // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide

@@ -556,7 +556,7 @@ def save_tuned():
 
 
 HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "112,113,114,115,116,117,118").replace("+", ",").split(",") if t]
-# stride-2 3x3 forward on the halo kernel (tile code 110): empty until it has been measured
+# stride-2 3x3 layers on the window-in-LDS kernels (tile codes 110 = forward, 108 = data gradient): empty until measured
 HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "").replace("+", ",").split(",") if t]
 STREAM_1X1 = _os.environ.get("STREAMYOLO_STREAM_1X1", "1") != "0"
 TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123").split(",") if t]
@@ -614,8 +614,8 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     if k == 3 and stride == 1 and wf is not None and HALO_TILES:
         # 3x3 stride-1 layers: the halo-resident kernel (csrc/conv3x3_halo.h), tiles of 64 / 128 / 256 channels
         cands += [t for t in HALO_TILES if not (t == 116 and Cout > 64)]
-    if k == 3 and stride == 2 and mode == CONV_FWD and wf is not None and Cin % (16 if code == DT_F32 else 32) == 0:
-        cands += HALO_S2_TILES
+    if k == 3 and stride == 2 and wf is not None and Cin % (16 if code == DT_F32 else 32) == 0:
+        cands += [t for t in HALO_S2_TILES if (t == 108) == (mode == CONV_DGRAD)]     # 110: forward, 108: data gradient
     if (k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256) and code != DT_F32 and STREAM_1X1
             and (with_stats or mode == CONV_DGRAD)):
         cands.append(120)                      # weight-stationary pixel stream (csrc/conv1x1_stream.h): raw outputs only

@@ -553,3 +553,39 @@ def test_conv3x3_stride2_halo_kernel(backend, dt, N, cin, cout, H, W):
     # the data gradient of a stride-2 layer stays on the implicit-GEMM kernel
     with pytest.raises(ops._lib.HipLibraryError):
         ops.conv2d(ref_v, wp, xv, 3, 2, mode=ops.CONV_DGRAD, tile=110, wfrag=wf)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 72, 11, 37), (1, 32, 160, 8, 66), (2, 64, 128, 6, 129)])
+def test_conv3x3_stride2_data_gradient_kernel(backend, dt, N, cin, cout, H, W):
+    """conv3x3_s2dgrad_kernel (tile code 108): the data gradient of a 3x3 stride-2 convolution as four output-parity classes of 1 / 2 /
+    2 / 4 taps read from a (TH + 1) x 34 window of dy in LDS — odd and even input sizes (ragged last class row / column), ragged
+    channel tiles, first write and +=, against torch and against the implicit-GEMM kernel."""
+    if str(backend) != "cpu" and not os.environ.get("STREAMYOLO_TEST_NEW_TILES"):
+        pytest.skip("built after the round's last GPU minute — run with STREAMYOLO_TEST_NEW_TILES=1 first")
+    code = ops.dtype_code(dt)
+    slab = 16 if dt == "fp32" else 32
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt).requires_grad_(True)
+    w = _q(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, dt)
+    y = F.conv2d(x, w, None, 2, 1)
+    dy = _q(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    Hs, Ws = y.shape[2], y.shape[3]
+    cpad = -(-cout // slab) * slab                                   # the window kernel walks whole channel slabs of dy
+    dyp = View.alloc(N, Hs, Ws, cpad, dt, backend, zero=True)
+    dyp.slice(0, cout).set_nchw(dy.to(backend))
+    wt = pack_conv_weight(torch.cat([w, w.new_zeros(cpad - cout, cin, 3, 3)], 0), code, transpose=True).to(backend)
+    wf = pack_conv_weight_frag(wt, 3)
+    dxv = View.alloc(N, H, W, cin + 8, dt, backend, zero=True).slice(8, cin)
+    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=108, wfrag=wf)
+    assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
+    assert float(dxv.buf[..., :8].float().abs().max()) == 0.0
+    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=108, wfrag=wf, accumulate=True)
+    assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]
+    ref = View.alloc(N, H, W, cin, dt, backend, zero=True)
+    ops.conv2d(dyp, wt, ref, 3, 2, mode=ops.CONV_DGRAD, tile=19)      # implicit GEMM (four parity classes), same operands
+    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=108, wfrag=wf)
+    assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
+    with pytest.raises(ops._lib.HipLibraryError):                    # forward launches are not this kernel's
+        ops.conv2d(dxv, wt, dyp, 3, 2, tile=108, wfrag=wf)

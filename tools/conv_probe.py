@@ -44,7 +44,7 @@ NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64
          51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64",
          121: "k1-128x64", 122: "k1-64x128", 123: "k1-128x128", 117: "halo2-128x2", 118: "halo2-128x4w",
          120: "stream1x1", 112: "halo128x4", 113: "halo128x4w", 114: "halo128x2-8w", 115: "halo128x2", 116: "halo64x8",
-         119: "halo2-128x8/8acc", 111: "halo2-256x4/8acc", 109: "halo2-128x8w/8acc", 110: "halo2-s2-128x2",
+         119: "halo2-128x8/8acc", 111: "halo2-256x4/8acc", 109: "halo2-128x8w/8acc", 110: "halo2-s2-128x2", 108: "s2dgrad-128x2",
          99: "w3-128x128", 102: "w3-128x64", 103: "w3-64x64", 24: "rs256x64", 88: "wr256x64", 89: "wr256x128", 83: "wr128x128", 84: "wr64x256", 85: "wr32x256", 86: "wr128x64", 87: "wr64x64"}
 
 
