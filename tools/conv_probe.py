@@ -80,10 +80,14 @@ def main():
         shift = torch.zeros(cout, device=dev)
         kw = dict(epilogue=ops.EPI_SILU)
         if a.mode == "dgrad":
-            if st != 1:
-                continue
             scale = shift = None
             kw = dict(mode=ops.CONV_DGRAD)
+            if st != 1:
+                # stride 2: the launch's input is dy on the SMALL map, its output dx on the large one, weights transposed
+                x, y = View.alloc(N, y.H, y.W, cout, a.dtype, dev), View.alloc(N, H, W, cin, a.dtype, dev)
+                x.buf.copy_(torch.randn(x.buf.shape, generator=g).to(x.buf.dtype))
+                w = (torch.randn(cin, k * k * cout, generator=g) / (cout * k * k) ** 0.5).to(x.buf.dtype).to(dev)
+                wf = pack_conv_weight_frag(w, k)
         if a.mode == "stats":
             scale = shift = None
             kw = dict(stats=(torch.zeros(2 * a.copies * cout, device=dev), torch.zeros(2 * a.copies * cout, device=dev)), segments=2)
@@ -100,10 +104,13 @@ def main():
             if (112 <= (t & 255) < 120 or (t & 255) in (111, 109)) and (k != 3 or st != 1):
                 res.append(float("nan"))
                 continue
+            if (t & 255) == 108 and (k != 3 or st != 2 or a.mode != "dgrad"):
+                res.append(float("nan"))
+                continue
             if (t & 255) == 110 and (k != 3 or st != 2 or a.mode == "dgrad"):
                 res.append(float("nan"))
                 continue
-            if (t & 255) < 109 and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
+            if (t & 255) < 108 and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
                 res.append(float("nan"))
                 continue
             try:
