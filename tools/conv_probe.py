@@ -91,7 +91,7 @@ def main():
         if a.mode == "stats":
             scale = shift = None
             kw = dict(stats=(torch.zeros(2 * a.copies * cout, device=dev), torch.zeros(2 * a.copies * cout, device=dev)), segments=2)
-        flops = 2.0 * cin * cout * k * k * y.pixels
+        flops = 2.0 * cin * cout * k * k * (x.pixels if (a.mode == "dgrad" and st != 1) else y.pixels)   # products of the forward op
         res = []
         for t in tiles:
             if 121 <= (t & 255) <= 123 and (k != 1 or st != 1 or cin not in (64, 128, 256, 512, 1024, 2048) or ((t & 255) == 122 and cout > 64)
