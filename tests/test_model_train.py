@@ -584,3 +584,66 @@ def test_backward_tape_joins_every_weight_gradient_stream(backend, monkeypatch):
     last_use = max(i for i, (n, a) in enumerate(marks) if n == "cur" and a == 3)
     assert any(n == "dep" and a == (3, 0) for n, a in marks[last_use:]), "stream 3 is never joined after its last weight gradient"
     assert marks[-1][0] == "join"
+
+
+def test_plan_on_the_unmeasured_kernel_variants_matches_the_default_plan(backend, monkeypatch):
+    """The kernel variants built after round 3's last GPU minute (halo tiles 119 / 111 / 109, the stride-2 window kernels 110 / 108,
+    weight-gradient tiles 35 / 36) inside a whole training step: the tuner is replaced by a function that hands them out wherever
+    their shape rules allow, and the step must reproduce the default plan's loss and gradients (exact-fp32 mode)."""
+    from streamyolo_amd import ops as ops_mod
+    from streamyolo_amd.train_engine import TrainStep
+    if str(backend) != "cpu" and not os.environ.get("STREAMYOLO_TEST_NEW_TILES"):
+        pytest.skip("built after the round's last GPU minute — run with STREAMYOLO_TEST_NEW_TILES=1 first")
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    Hh, Ww = (64, 96) if str(backend) == "cpu" else (128, 192)
+    x = synth_frames(2, Hh, Ww, seed=2).to(backend)
+    lab, sup = synth_labels(2, Hh, Ww, cfg.num_classes, num_gt=4, seed=3)
+    targets = (lab.to(backend), sup.to(backend))
+    handed = {"halo": 0, "s2": 0, "s2d": 0, "wg": 0}
+
+    def tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=False, only=None):
+        if only is not None or k != 3 or Cin % 16:
+            return 0 if only is None else only[-1]
+        if stride == 1:
+            handed["halo"] += 1
+            return (119, 111, 109)[handed["halo"] % 3]
+        if mode == ops_mod.CONV_FWD:
+            handed["s2"] += 1
+            return 110
+        handed["s2d"] += 1
+        return 108
+
+    def wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace):
+        if k == 3 and stride == 1:
+            return (0, 0)
+        handed["wg"] += 1
+        return ((35, 256), (36, 64))[handed["wg"] % 2]
+    res = {}
+    for mode in ("default", "new_tiles"):
+        if mode == "new_tiles":
+            monkeypatch.setattr(ops_mod, "tuned_tile", tile)
+            monkeypatch.setattr(ops_mod, "tuned_wgrad", wgrad)
+        model = sy.build_model("nano")
+        model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        model = model.to(backend).train().set_compute_dtype("fp32")
+        model.head.use_l1 = True
+        st = TrainStep(model, graph=False)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        for _ in range(2):                                       # direct, recorded
+            model.load_state_dict(state0)
+            out = st.step(x, targets)
+        res[mode] = (float(out["total_loss"]), {n: st.plan.gview[id(p)].clone() for n, p in model.named_parameters()},
+                     st.plan.loss_ws.fg.clone())
+    assert min(handed.values()) > 0, handed
+    (la, ga, fa), (lb, gb, fb) = res["default"], res["new_tiles"]
+    assert abs(la - lb) / abs(la) < 1e-5
+    if int((fa != fb).sum()):
+        return
+    # other kernels = another fp32 summation order (1e-7 per layer), amplified by the BatchNorms of the deepest maps, which
+    # normalise over a handful of values at this input size.  The level to expect is the one the GPU-verified halo tile 117 shows
+    # against the same default plan on the emulator (median 8e-5, maximum 2.5e-4; tiles 119 / 111 / 109 / 110 alone: 4e-5 ... 8e-5
+    # median, the data-gradient and weight-gradient variants alone 3e-7)
+    errs = sorted((_rel(gb[k].cpu(), ga[k].cpu()), k) for k in ga)
+    assert errs[len(errs) // 2][0] < 3e-4, errs[len(errs) // 2]
+    assert errs[-1][0] < 2e-3, errs[-5:]
