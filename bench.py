@@ -232,7 +232,7 @@ def main():
 
     workload = args.workload
     if args.graph is None:
-        args.graph = 1
+        args.graph = 0 if EMU_SELFTEST else 1            # (no hipGraphs on the emulator)
     if workload is None:
         try:
             from streamyolo_amd import train_engine  # noqa: F401
