@@ -439,7 +439,7 @@ def main():
         mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad", "conv(pred)", "dgrad(pred)", "wgrad(pred)"))
         ach = flops_pair * B / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         traffic, traffic_src, traffic_commit = pmc_traffic_full(workload, args, B)
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_halo(2)_kernel+conv1x1_tile_kernel+conv1x1_stream_kernel" +
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_halo(2)_kernel+conv1x1_tile_kernel" +
                     ("+conv_wgrad_tr_kernel+conv_wgrad9_kernel(+wgrad_fold)" if workload == "train" else ""),
                     "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_unit": "bytes/step (MFMA kernels)",

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 4
+#define SY_ABI_VERSION 5
 #define SY_API __attribute__((visibility("default")))
 
 enum { SY_DT_BF16 = 0, SY_DT_F16 = 1, SY_DT_F32 = 2 };
@@ -44,12 +44,10 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
        SY_TILE_DMA2 = 32, /* add: 2-deep LDS-DMA ring */
        SY_TILE_DMA3 = 48, /* add: 3-deep LDS-DMA ring */
        SY_TILE_WR = 80,   /* add: register-staged pixels + fragment-packed weights loaded straight into VGPRs */
-       SY_TILE_HALO = 112, /* 112..118: 3x3 stride-1 kernel with the input tile + halo resident in LDS (csrc/conv3x3_halo.h; needs
-                             wfrag): 128 ch x 4 rows x 32 px (2x2 waves) | 128 x 4 (4x1 waves) | 128 x 2 (8 waves) | 128 x 2 | 64 x 8;
-                             119 / 111 / 109: one workgroup per CU with eight accumulators per wave, 128 ch x 8 rows | 256 ch x 4 rows | 128 ch x 8 rows;
+       SY_TILE_HALO = 112, /* 114..118 (HALO + 2..6): 3x3 stride-1 kernel with the input tile + halo resident in LDS (csrc/conv3x3_halo.h;
+                             needs wfrag): 128 ch x 2 rows x 32 px (8 waves) | 128 x 2 | 64 x 8 | 128 x 2 and 128 x 4 software-pipelined;
                              110: STRIDE 2 forward, 128 ch x 2 output rows x 32 px, input window split by column parity;
                              108: STRIDE 2 data gradient (csrc/conv3x3_s2dgrad.h), four output-parity classes */
-       SY_TILE_STREAM1X1 = 120, /* 1x1 stride-1 weight-stationary pixel stream (csrc/conv1x1_stream.h; raw 16-bit output, Cin 64 / 128 / 256) */
        SY_TILE_1X1K = 121 /* 121..123: 1x1 stride-1 kernel with the tile's whole K extent requested in one burst (csrc/conv1x1_tile.h; needs
                              wfrag, 16-bit types, Cin 64 / 128 / 256 / 512): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px */ };
 
@@ -58,24 +56,6 @@ enum {
     SY_CONV_FWD = 0,        /* out(ho,wo) <- in(ho*s - p + kh, wo*s - p + kw)                  */
     SY_CONV_DGRAD = 1       /* out(h,w)  <- in((h + p - kh)/s, (w + p - kw)/s) when divisible  */
 };
-
-/* Training-mode BatchNorm finalisation done by the producing convolution (sy_conv_desc::fin).  All pointers are device pointers;
- * the record itself lives in DEVICE memory.  Same arithmetic, in the same order, as sy_bn_finalize: per channel, eight float
- * partials over the replicas k = r, r + 8, ..., summed in double; var = E[x^2] - mean^2 clamped at 0 (biased, as
- * torch.nn.functional.batch_norm normalises in training mode); scale = gamma * invstd, shift = beta - mean * scale.
- * ticket: segments * ceil(Cout / 32) counters, zero before the first launch; the finalising workgroup resets its counter. */
-typedef struct sy_bn_fin {
-    uint32_t* ticket;
-    const float* gamma;                 /* [Cout] (shared by the segments) */
-    const float* beta;
-    float* scale;                       /* [segments][Cout] */
-    float* shift;
-    float* mean;                        /* [segments][Cout] or NULL */
-    float* invstd;
-    double count;                       /* pixels per segment */
-    float eps;
-    int32_t reserved;
-} sy_bn_fin;
 
 typedef struct sy_conv_desc {
     /* tensors */
@@ -107,23 +87,12 @@ typedef struct sy_conv_desc {
     int64_t x_bytes, w_bytes;           /* bytes addressable from x / w (buffer bounds of the fast gather; 0 = unknown) */
     const void* wfrag;                  /* optional: weights re-packed in MFMA-fragment order (SY_TILE_WR variants) */
     int64_t wfrag_bytes;
-    /* optional INPUT transform x' = silu(in_scale[c] * x + in_shift[c]) applied to the operand tile after it has landed in LDS
-       (tiles 117 / 118 only): the producer's BatchNorm + SiLU normalisation done by the CONSUMER, so the producer's raw output
-       is this launch's operand and its bn_silu_apply pass (nn.BatchNorm2d + nn.SiLU of the producing BaseConv) is not needed.
-       Arrays [in_segments][Cin] fp32, segment of image n = n / (N / in_segments); NULL = no transform.  Padding stays zero. */
-    const float* in_scale;
-    const float* in_shift;
-    int32_t in_segments;
     /* k_splits S > 1 (tiles 117 / 118, forward, y_f32 = 1, SY_EPI_LINEAR, no scale / shift / res / statistics): the channel slabs
        of the contraction are cut into S ranges, one per gridDim.z; split z writes its fp32 PARTIAL sums as images [z*N, (z+1)*N) of
        y (which must hold S*N images, batch stride ybs).  sy_splitk_epilogue sums the partials and applies the epilogue.  For the
        deep small-map layers of the batch-1 streaming step: 36-72 workgroups become 144-288. */
     int32_t k_splits;
     int32_t reserved;
-    /* optional (forward launches with stat_sum / stat_sq only): the workgroup that adds the LAST partial sums of a channel tile
-       also folds the replicas and emits the BatchNorm affine — what a separate sy_bn_finalize launch would do, without the
-       dependent launch on the step's critical path.  DEVICE pointer to a sy_bn_fin record that lives as long as the launch. */
-    const struct sy_bn_fin* fin;
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.
@@ -309,19 +278,6 @@ SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda
                                 int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
                                 int dres_accumulate, int dtype, int nseg, void* stream);
 
-/* sy_bn_silu_bwd_reduce + sy_bn_silu_bwd_apply in ONE launch for tensors small enough that every workgroup of the launch is
- * resident at once (the workgroups of a channel slice wait for each other, their chunk of both tensors held in registers):
- * both tensors are read once, one dependent launch instead of two.  sums: fp32 [nseg][2][C], ZERO on entry (sum dz | sum dz*xhat
- * afterwards); tickets: uint32 [nseg][C / slice][2] counters, zero before the first launch (they reset themselves).
- * Returns SY_ERR_UNSUPPORTED when the tensor is too large for a resident launch: use the two-pass entries then.  "Resident" is
- * the kernel's occupancy x CU count divided by SY_BN_FUSED_SHARE (default 2): launches of this entry on different streams may run
- * at the same time, and two partially resident launches would wait for each other's slots.
- * dres_accumulate: bit 0 = += into dres, bit 1 = dgamma / dbeta by atomics (as sy_bn_silu_bwd_apply). */
-SY_API int sy_bn_silu_bwd_fused(const void* y, int ldy, const void* da, int ldda, const float* scale, const float* shift,
-                                const float* mean, const float* invstd, const float* gamma, float* sums, uint32_t* tickets,
-                                void* dy, int lddy, int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
-                                int dres_accumulate, int dtype, int nseg, void* stream);
-
 /* SimOTA assignment + Trend-Aware loss, forward and gradient, for a whole batch, no host sync.
  * raw [B, A, 5+nc] fp32 raw head logits (reg4, obj, cls); labels/support [B, max_labels, 5] fp32 rows
  * (cls, cx, cy, w, h) zero padded; level_h/w/stride describe the anchor grid (level-major, row-major).
@@ -391,12 +347,16 @@ enum { SY_TAPE_END = -1, SY_TAPE_LAUNCH = 0,
        /* plans with more than two chains (sy_tape_replay_n: streams[0] = main, [1] = side, [2..] = further chains) */
        SY_TAPE_CUR = 9,      /* cursor -> stream `arg`, no new dependency                                     */
        SY_TAPE_DEP = 10,     /* stream (arg >> 4) records an event, stream (arg & 15) waits for it            */
-       SY_TAPE_SLOT_DONE = 11,   /* event on the CURRENT stream = "ring slot `arg` is free again"             */
-       SY_TAPE_ACQUIRE_CUR = 12  /* the CURRENT stream waits for ring slot `arg` (the slot stays marked)      */ };
+       SY_TAPE_SLOT_DONE = 11,   /* event on the CURRENT stream = "this stream's readers of ring slot `arg` are done"; a slot keeps
+                                    one such event PER STREAM, the first one after an acquisition starts a new set      */
+       SY_TAPE_ACQUIRE_CUR = 12  /* the CURRENT stream waits for every event of slot `arg`'s set recorded on ANOTHER stream
+                                    (the set stays: several chains may acquire their part of one slot)                  */ };
 SY_API void* sy_tape_begin(void);
 SY_API int sy_tape_mark(int kind, int arg);
 SY_API void* sy_tape_end(void);
 SY_API int sy_tape_size(const void* tape, int* n_entries, int* n_launches);
+/* events recorded / stream-waits issued by the last (or current) replay pass of `tape` */
+SY_API int sy_tape_counters(const void* tape, int* n_events, int* n_waits);
 SY_API int sy_tape_replay(void* tape, void* main_stream, void* side_stream, int* pos, int stop_buckets, int* stop_kind,
                           int* stop_arg, int* stop_on_side);
 /* the same over n_streams (1..8) streams; *stop_stream = index of the cursor stream at a BREAK / BUCKET return.  A chain index

@@ -18,6 +18,7 @@ DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 EPI_LINEAR, EPI_SILU, EPI_SIGMOID, EPI_DECODE = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD = 0, 1
 
+ABI_VERSION = 5          # SY_ABI_VERSION of include/streamyolo_hip.h this binding was written against
 _ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape"}
 SY_ERR_UNSUPPORTED = 3
 
@@ -37,16 +38,7 @@ class ConvDesc(C.Structure):
         ("xbs", C.c_int64), ("ybs", C.c_int64), ("rbs", C.c_int64),
         ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
         ("accumulate", C.c_int32), ("dec_stride", C.c_float), ("stat_copies", C.c_int32), ("stat_segments", C.c_int32), ("tile", C.c_int32), ("x_bytes", C.c_int64), ("w_bytes", C.c_int64), ("wfrag", C.c_void_p), ("wfrag_bytes", C.c_int64),
-        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_segments", C.c_int32), ("k_splits", C.c_int32),
-        ("reserved", C.c_int32), ("fin", C.c_void_p),
-    ]
-
-
-class BnFin(C.Structure):
-    """sy_bn_fin: the record of sy_conv_desc::fin (device pointers; the record itself is copied to device memory by ops.BnFinRecord)."""
-    _fields_ = [
-        ("ticket", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
-        ("mean", C.c_void_p), ("invstd", C.c_void_p), ("count", C.c_double), ("eps", C.c_float), ("reserved", C.c_int32),
+        ("k_splits", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -115,7 +107,6 @@ SIGNATURES = {
     "sy_bn_finalize_apply": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "sy_bn_silu_bwd_fused": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),
@@ -127,6 +118,7 @@ SIGNATURES = {
     "sy_tape_mark": (_I, [_I, _I]),
     "sy_tape_end": (_P, []),
     "sy_tape_size": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sy_tape_counters": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sy_tape_replay": (_I, [_P, _P, _P, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sy_tape_replay_n": (_I, [_P, C.POINTER(C.c_void_p), _I, C.POINTER(C.c_int), _I, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.POINTER(C.c_int)]),
@@ -152,7 +144,7 @@ def _bind(path):
             raise HipLibraryError("streamyolo_amd: %s lacks symbol %s (stale build?)" % (path, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sy_abi_version() != 4:
+    if lib.sy_abi_version() != ABI_VERSION:
         raise HipLibraryError("streamyolo_amd: ABI version mismatch in %s" % path)
     return lib
 
@@ -266,6 +258,12 @@ class NativeTape:
         n, l = C.c_int(0), C.c_int(0)
         check(self._lib.sy_tape_size(self.handle, C.byref(n), C.byref(l)), "sy_tape_size")
         return n.value, l.value
+
+    def counters(self):
+        """(events recorded, stream-waits issued) by the last replay pass."""
+        e, w = C.c_int(0), C.c_int(0)
+        check(self._lib.sy_tape_counters(self.handle, C.byref(e), C.byref(w)), "sy_tape_counters")
+        return e.value, w.value
 
     def replay(self, main, side=None, on_snippet=None, on_bucket=None, more=()):
         """main / side (/ more...): raw hipStream_t (ctypes c_void_p or int) of chains 0 / 1 (/ 2...).  on_snippet(fn, k) runs a

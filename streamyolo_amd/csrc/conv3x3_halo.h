@@ -194,17 +194,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
 //     have landed — the (9 - NI) x 2 TC fragment loads issued after the last piece stay in flight across the barrier;
 //   * no branches in the slab body: the DMA pieces of the slab after the last one are issued out of range (zeros into the
 //     idle buffer, drained before the epilogue reuses the LDS).
-//   * NORM (VERDICT r02 "next" #3): the operand is the PRODUCER's raw convolution output; once a slab has landed, every thread
-//     rewrites its share of the halo tile in place — ds_read_b128, silu(scale * x + shift) per element in fp32, round,
-//     ds_write_b128 — one extra barrier per slab, and the nine taps then read normalised activations: the producer's
-//     bn_silu_apply pass (2 + 2 bytes per element of HBM traffic and a launch) is not needed for this consumer.  The per-channel
-//     affine of all Cin channels is parked in LDS once per workgroup; out-of-image halo pixels stay zero (padding applies to the
-//     ACTIVATED tensor).
 //   * S2 (forward only): the same kernel for STRIDE 2.  The tile of TH x 32 output pixels needs (2 TH + 1) x 65 input pixels; they
 //     are parked with the columns split by parity — LDS row of input pixel (hy, hx) = hy * 66 + (hx & 1) * 33 + (hx >> 1) — so
 //     that the 32 lanes of a tap (input column 2 * lane + kw) read 32 CONSECUTIVE rows exactly as at stride 1 (same XOR swizzle,
 //     conflict free), and the parity split costs nothing: every DMA lane picks its own global pixel anyway.
-template <typename T, int WC, int WP, int TC, int TP, int NORM = 0, int S2 = 0>
+template <typename T, int WC, int WP, int TC, int TP, int S2 = 0>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1 : 2))) void conv3x3_halo2_kernel(ConvArgs p) {
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
@@ -306,56 +300,10 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
 
     sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, cs_begin); });
     sy_static_for<0, 9>([&](auto t_) { fetch(t_, cs_begin); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
-    // NORM: the input affine [Cin] x {scale, shift} of this image's segment is parked behind the two halo buffers.  Its global
-    // loads are issued AFTER the first slab's DMA pieces and fragment fetches (they ride in the same in-order VMEM queue, so
-    // the workgroup does not pay a serial load latency in front of its first slab — that cost ~7 us per launch in situ).
-    float* const aff = reinterpret_cast<float*>(smem + 2 * BUF);
-    if constexpr (NORM) {
-        const float* const gs = p.in_scale + (long long)(n / p.in_seg_N) * p.Cin;
-        const float* const gh = p.in_shift + (long long)(n / p.in_seg_N) * p.Cin;
-        float4 va[2], vb[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = (tid + i * NW * 64) * 4;
-            if (c < p.Cin) { va[i] = *reinterpret_cast<const float4*>(gs + c); vb[i] = *reinterpret_cast<const float4*>(gh + c); }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = (tid + i * NW * 64) * 4;
-            if (c < p.Cin) { *reinterpret_cast<float4*>(aff + c) = va[i]; *reinterpret_cast<float4*>(aff + p.Cin + c) = vb[i]; }
-        }
-        __syncthreads();                          // LDS writes visible to every wave (waits lgkmcnt as well)
-    }
     for (int cs = cs_begin; cs < ncs; ++cs) {
         sy_wait_vmcnt<(9 - NI) * 2 * TC>();      // the slab's DMA pieces (older than the last (9 - NI) taps of fragment loads)
         sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
         const unsigned hbo = (unsigned)((cs & 1) * BUF);
-        if constexpr (NORM) {
-            // in-place normalisation of the landed slab: thread -> (halo row, logical 16-byte chunk); the chunk index is fixed
-            // per thread (the thread count is a multiple of 4), so its EPC channels' affine is read once per slab
-            const int c = tid & 3;
-            float sc[EPC], sh[EPC];
-#pragma unroll
-            for (int j = 0; j < EPC; ++j) {
-                sc[j] = aff[cs * BK + c * EPC + j];
-                sh[j] = aff[p.Cin + cs * BK + c * EPC + j];
-            }
-            for (int r = tid >> 2; r < HR; r += NW * 16) {
-                static_assert(!(NORM && S2), "input normalisation: stride 1 only");
-                const int hy = r / kHaloW, hx = r - hy * kHaloW;
-                const int h = h0 - 1 + hy, w = w0 - 1 + hx;
-                if ((unsigned)h >= (unsigned)p.H || (unsigned)w >= (unsigned)p.W) continue;     // padding of the ACTIVATED tensor: zeros
-                unsigned char* const a = smem + hbo + r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
-                uint4 v = *reinterpret_cast<const uint4*>(a);
-                typename T::elem e[EPC];
-                __builtin_memcpy(e, &v, 16);
-#pragma unroll
-                for (int j = 0; j < EPC; ++j) e[j] = T::from_f32(sy_silu(T::to_f32(e[j]) * sc[j] + sh[j]));     // bn_silu_apply_kernel's expression
-                __builtin_memcpy(&v, e, 16);
-                *reinterpret_cast<uint4*>(a) = v;
-            }
-            __syncthreads();                      // the rewritten tile is visible to every wave (LDS writes drained, then barrier)
-        }
         uint4 b[BD][TP];
         auto read_step = [&](auto s_) {
             constexpr int S = decltype(s_)::value;
@@ -402,11 +350,11 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int NORM = 0, int S2 = 0>
+template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int S2 = 0>
 int launch_halo(const ConvArgs& a_in, void* stream) {
     constexpr int NW = WC * WP, CT = WC * TC * 32, TH = WP * TP, PT = TH * 32;
     constexpr int HR = S2 ? (2 * TH + 1) * 66 : (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
-    static_assert(!S2 || (GEN == 2 && !NORM), "stride 2: second-generation kernel, forward");
+    static_assert(!S2 || GEN == 2, "stride 2: second-generation kernel, forward");
     ConvArgs a = a_in;
     a.s2_classes = 0;
     // 3x3, stride 1, "same" padding, whole channel slabs, 32-bit addressable input, fragment-packed weights
@@ -418,8 +366,7 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
         if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
     }
     if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
-    if (NORM && (a.in_scale == nullptr || a.in_seg_N <= 0 || a.Cin > 2048 || a.mode != SY_CONV_FWD)) return SY_ERR_UNSUPPORTED;
-    constexpr size_t smem_k = 2 * (size_t)BUF + (NORM ? 2 * 2048 * sizeof(float) : 0);
+    constexpr size_t smem_k = 2 * (size_t)BUF;
     constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
     constexpr bool can_stage = (T::kEPC == 8 && smem_e <= StageLimit<WC, WP, TC, TP>::kBytes);
     constexpr size_t smem_s = (size_t)WP * CT * 8;            // statistics scratch of the un-staged epilogue
@@ -431,42 +378,33 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     static bool attr_done = false;
     if (!attr_done) {
         const void* fn;                                        // (if constexpr: only the generation this tile code launches is instantiated)
-        if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM, S2>;
+        if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, S2>;
         else fn = (const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
     if constexpr (GEN == 2) {
-        SY_LAUNCH((conv3x3_halo2_kernel<T, WC, WP, TC, TP, NORM, S2>), grid, dim3(NW * 64), smem, stream, a);
+        SY_LAUNCH((conv3x3_halo2_kernel<T, WC, WP, TC, TP, S2>), grid, dim3(NW * 64), smem, stream, a);
     } else {
         SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
     }
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-// tile codes 112..118 of sy_conv_desc::tile (SY_TILE_HALO + k)
+// tile codes 110, 114..118 of sy_conv_desc::tile
 template <typename T>
 int launch_halo_typed(const ConvArgs& a, void* stream) {
     switch (a.tile) {
-        case 112: return launch_halo<T, 2, 2, 2, 2>(a, stream);     // 128 ch x ( 4 rows x 32 px)
-        case 113: return launch_halo<T, 4, 1, 1, 4>(a, stream);     // 128 ch x ( 4 rows x 32 px), 4 waves x (32 ch x 128 px)
         case 114: return launch_halo<T, 4, 2, 1, 1>(a, stream);     // 128 ch x ( 2 rows x 32 px), 8 waves x (32 ch x 32 px)
         case 115: return launch_halo<T, 4, 1, 1, 2>(a, stream);     // 128 ch x ( 2 rows x 32 px)
         case 116: return launch_halo<T, 1, 4, 2, 2>(a, stream);     //  64 ch x ( 8 rows x 32 px)
-        // second generation (in-wave software pipeline) of 115 / 113; with an input affine: the NORM instantiation
-        case 117: return a.in_scale != nullptr ? launch_halo<T, 4, 1, 1, 2, 2, 1>(a, stream) : launch_halo<T, 4, 1, 1, 2, 2>(a, stream);
-        case 118: return a.in_scale != nullptr ? launch_halo<T, 4, 1, 1, 4, 2, 1>(a, stream) : launch_halo<T, 4, 1, 1, 4, 2>(a, stream);
-        // one workgroup per CU, one wave per SIMD, eight 32 x 32 accumulators per wave (the whole 512-register file): every
-        // fragment read from LDS / L2 feeds two to four MFMAs instead of one — candidates for the next measurement round
-        // (not in the tuner's default candidate set: STREAMYOLO_HALO_TILES)
-        case 119: return launch_halo<T, 2, 2, 2, 4, 2>(a, stream);  // 128 ch x ( 8 rows x 32 px), 4 waves x (64 ch x 128 px)
-        case 111: return launch_halo<T, 2, 2, 4, 2, 2>(a, stream);  // 256 ch x ( 4 rows x 32 px), 4 waves x (128 ch x 64 px)
-        case 109: return launch_halo<T, 1, 4, 4, 2, 2>(a, stream);  // 128 ch x ( 8 rows x 32 px), 4 waves x (128 ch x 64 px): all four waves
-                                                                    //   stream the SAME weight fragments (L1 hits), a quarter of the LDS reads
-        // STRIDE 2, forward (tile 117's configuration; the stride-2 layers run on the implicit-GEMM kernel today, 16 instructions
-        // per MFMA in its loop): candidate for the next measurement round (STREAMYOLO_HALO_S2_TILES)
-        case 110: return launch_halo<T, 4, 1, 1, 2, 2, 0, 1>(a, stream);
+        // second generation (in-wave software pipeline) of 115 / 113
+        case 117: return launch_halo<T, 4, 1, 1, 2, 2>(a, stream);
+        case 118: return launch_halo<T, 4, 1, 1, 4, 2>(a, stream);
+        // STRIDE 2, forward (tile 117's configuration over a parity-split input window): +7 % / +26 % over the implicit-GEMM
+        // variants on dark2.0 / dark4.0 (profiles/r04/a_probe_s2_stats.txt)
+        case 110: return launch_halo<T, 4, 1, 1, 2, 2, 1>(a, stream);
         default: return SY_ERR_ARG;
     }
 }

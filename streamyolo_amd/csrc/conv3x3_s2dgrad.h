@@ -189,8 +189,7 @@ int launch_s2dgrad(const ConvArgs& a_in, void* stream) {
     // launch input = dy [N, H, W, Cin] on the small map, output = dx [N, Ho, Wo, Cout] with H = ceil(Ho / 2), W = ceil(Wo / 2)
     if (a.KH != 3 || a.KW != 3 || a.stride != 2 || a.pad != 1 || a.mode != SY_CONV_DGRAD || a.H != (a.Ho + 1) / 2 || a.W != (a.Wo + 1) / 2)
         return SY_ERR_UNSUPPORTED;
-    if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0 || a.stat_sum != nullptr || a.ksplit > 1 ||
-        a.in_scale != nullptr)
+    if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0 || a.stat_sum != nullptr || a.ksplit > 1)
         return SY_ERR_UNSUPPORTED;
     constexpr size_t smem_k = 2 * (size_t)BUF;
     constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;

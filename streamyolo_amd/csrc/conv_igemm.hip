@@ -39,16 +39,6 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.w_extent = (d->w_bytes > 0 && d->w_bytes < 0xFFFFFFF0LL) ? (unsigned)d->w_bytes : 0u;
     a.wfrag = (const unsigned char*)d->wfrag;
     a.wfrag_extent = (d->wfrag != nullptr && d->wfrag_bytes > 0 && d->wfrag_bytes < 0xFFFFFFF0LL) ? (unsigned)d->wfrag_bytes : 0u;
-    a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_seg_N = 0;
-    if ((d->in_scale == nullptr) != (d->in_shift == nullptr)) return SY_ERR_ARG;
-    if (d->in_scale != nullptr) {
-        const int segs = d->in_segments > 0 ? d->in_segments : 1;
-        if (d->N % segs != 0) return SY_ERR_ARG;
-        if ((d->tile & 0xff) != 117 && (d->tile & 0xff) != 118) return SY_ERR_UNSUPPORTED;   // operand-in-LDS kernels only
-        a.in_seg_N = d->N / segs;
-    }
-    a.fin = d->fin;
-    if (d->fin != nullptr && (d->stat_sum == nullptr || d->mode != SY_CONV_FWD || d->k_splits > 1)) return SY_ERR_ARG;
     a.ksplit = 0;
     if (d->k_splits > 1) {
         if (((d->tile & 0xff) != 117 && (d->tile & 0xff) != 118) || d->mode != SY_CONV_FWD || !d->y_f32 || d->epilogue != SY_EPI_LINEAR ||

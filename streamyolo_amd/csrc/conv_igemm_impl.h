@@ -59,72 +59,12 @@ struct ConvArgs {
     unsigned x_extent, w_extent; // bytes addressable from x / w (FAST loader's buffer bounds)
     const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
     unsigned wfrag_extent;
-    const float* in_scale;      // optional input normalisation (conv3x3_halo2_kernel NORM): [segments][Cin]
-    const float* in_shift;
-    int in_seg_N;               // images per normalisation segment (0: no input transform)
     int ksplit;                 // > 1: split-K over channel-slab ranges (conv3x3_halo2_kernel), gridDim.z splits, fp32 partial outputs
-    const sy_bn_fin* fin;       // optional (statistics launches): the last workgroup of a channel tile finalises the BatchNorm affine
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads, 8 = no statistics atomics, 16 = no cross-lane statistics reduction
 };
 
-// sy_conv_desc::fin — the tail of a statistics launch.  Every workgroup of one (segment, channel tile) takes a ticket once its
-// own statistic atomics have retired; the one that draws the last ticket folds the replicas of its CT channels exactly as
-// bn_finalize_kernel (train_ops.hip) does — eight float partials over the replicas k = r, r + 8, ..., summed in double — and
-// writes scale / shift / mean / invstd.  The separate finalize launch (a ~13 us dependent launch per BaseConv on the step's
-// critical path, whatever it does) disappears; the cost is one agent-scope atomic per workgroup and ~2 x copies loads per
-// channel in ONE workgroup per channel tile.  `smem`: any LDS word nobody reads any more.
-template <int CT, int kThreads, typename Args>
-__device__ __forceinline__ void conv_stats_finalize(const Args& p, int seg, int c0, int tid, unsigned char* smem) {
-    const sy_bn_fin* const f = p.fin;
-    sy_wait_vmcnt<0>();                                          // this thread's statistic atomics have been performed
-    __syncthreads();
-    unsigned* const flag = reinterpret_cast<unsigned*>(smem);
-    if (tid == 0) {
-        const unsigned nseg = p.seg_M > 0 ? (unsigned)(p.M / p.seg_M) : 1u;
-        const unsigned group = (gridDim.x * gridDim.y * gridDim.z) / ((unsigned)((p.Cout + CT - 1) / CT) * nseg);
-        unsigned* const t = f->ticket + (unsigned)seg * (unsigned)((p.Cout + 31) >> 5) + (unsigned)(c0 >> 5);
-        const bool last = sy_ticket_take(t) == group - 1u;
-        if (last) sy_ticket_reset(t);                            // ready for the next launch of this layer
-        *flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    if (*flag == 0u) return;
-    const long long so = (long long)seg * p.stat_copies * p.Cout, ao = (long long)seg * p.Cout;
-    for (int cl = tid; cl < CT; cl += kThreads) {
-        const int c = c0 + cl;
-        if (c >= p.Cout) continue;
-        float ps[8], pq[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { ps[r] = 0.0f; pq[r] = 0.0f; }
-        for (int k0 = 0; k0 < p.stat_copies; k0 += 8) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (k0 + r < p.stat_copies) {
-                    ps[r] += sy_load_agent(p.stat_sum + so + (long long)(k0 + r) * p.Cout + c);
-                    pq[r] += sy_load_agent(p.stat_sq + so + (long long)(k0 + r) * p.Cout + c);
-                }
-            }
-        }
-        double ds = 0.0, dq = 0.0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { ds += (double)ps[r]; dq += (double)pq[r]; }
-        const double mean = ds / f->count;
-        double var = dq / f->count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)f->eps));
-        const float sc = f->gamma[c] * invstd;
-        f->scale[ao + c] = sc;
-        f->shift[ao + c] = f->beta[c] - (float)mean * sc;
-        if (f->mean != nullptr) f->mean[ao + c] = (float)mean;
-        if (f->invstd != nullptr) f->invstd[ao + c] = invstd;
-    }
-}
-
-// Staged write-out needs PT * (2 * CT + 16) bytes of LDS: up to 48 KiB for the tiles that share a CU with other workgroups; the
-// one-workgroup-per-CU tiles (8 accumulators per wave, conv3x3_halo.h tile codes 111 / 119) may take 96 KiB.
-template <int WC, int WP, int TC, int TP> struct StageLimit {
-    static constexpr size_t kBytes = (((WC == 2 && WP == 2 && TC * TP == 8) || (WC == 1 && WP == 4 && TC == 4 && TP == 2)) ? 96 : 48) * 1024;
-};
+// Staged write-out needs PT * (2 * CT + 16) bytes of LDS: up to 48 KiB (the tiles share a CU with other workgroups)
+template <int WC, int WP, int TC, int TP> struct StageLimit { static constexpr size_t kBytes = 48 * 1024; };
 
 // LDS in front of the staged output tile: BN-statistics scratch [WP][CT][2] floats
 template <int WP, int CT> struct EpiLds { static constexpr int kStatBytes = WP * CT * 8; };
@@ -951,7 +891,6 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             atomicAdd(p.stat_sum + (long long)copy * p.Cout + co, a);
             atomicAdd(p.stat_sq + (long long)copy * p.Cout + co, b);
         }
-        if (p.fin != nullptr) conv_stats_finalize<CT, kThreads>(p, mp.seg, c0, tid, smem);
     }
 }
 
@@ -997,16 +936,14 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
     }
 }
 
-template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 109..119)
+template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 110, 114..118)
 template <typename T> int launch_s2dgrad(const ConvArgs& a, void* stream);         // conv3x3_s2dgrad.h (tile code 108)
-template <typename T> int launch_1x1_stream(const ConvArgs& a, void* stream);      // conv1x1_stream.h (tile code 120)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..123)
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
-    if (a.tile >= 109 && a.tile <= 119) return launch_halo_typed<T>(a, stream);
+    if (a.tile == 110 || (a.tile >= 114 && a.tile <= 118)) return launch_halo_typed<T>(a, stream);
     if (a.tile == 108) return launch_s2dgrad<T>(a, stream);
-    if (a.tile == 120) return launch_1x1_stream<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 123) return launch_1x1_tile<T>(a, stream);
     // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide
     // layers use 256 ch x 256 px (8 waves, 128 accumulator registers per lane).  Layers too small to give

@@ -479,10 +479,9 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
 constexpr int kHaloPix = 3 * 34;                  // halo pixels of a slab (3 rows x (32 + 2))
 constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (102 used) x 16 channels + bank padding
 
-// PD: (k-half, tap) steps whose x fragments are requested ahead of the step that multiplies (ring of PD + 1 fragments).  With one
-// wave per SIMD nothing else covers the LDS latency: at PD = 2 (tile codes 49 / 65) a fragment is requested ~1.5 MFMAs = 50-60
-// cycles before its use, less than a loaded ds_read_b64_tr_b16 round trip; PD = 4 (tile codes 50 / 66, + 8 VGPRs) requests it
-// ~3.5 MFMAs ahead.
+// PD: (k-half, tap) steps whose x fragments are requested ahead of the step that multiplies (ring of PD + 1 fragments).  PD = 4
+// (+ 8 VGPRs, waits become lgkmcnt(6)) was measured against PD = 2 in round 4: 3-8 % SLOWER on every 3x3 layer
+// (profiles/r04/a_probe_wgrad.txt) — removed; so was the eight-wave variant of this tile (ties, round 2).
 template <typename T, int STG, int PD = 2>
 __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
     constexpr int CT = 128, CIT = 32;
@@ -637,157 +636,6 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
         }
 }
 
-// ---- the same tile on EIGHT waves: two waves per SIMD, software-pipelined fragment reads ---------------------------------------
-// conv_wgrad9_kernel runs one workgroup of four waves per CU (the split-K slabs + fold cap the launch at ~256 workgroups), i.e.
-// ONE wave per SIMD: every LDS-DMA issue (~100 cycles each, 4 per slab), every ds_read_b64_tr_b16 latency and the slab barrier
-// stall the only wave the MFMA pipe has — the kernel runs at the same speed with its global loads ablated
-// (profiles/r02/q_wgrad9_ablation.txt).  Here the nine taps of the workgroup's tile are split over two groups of four waves (taps
-// 0-4 / 5-8; wave = 32 output channels x 32 input channels x its taps), so a SIMD hosts two waves whose stalls overlap, each wave
-// issues two DMA pieces per slab instead of four, and inside a wave the x fragments of step (k-half, tap) + 2 are read while
-// step (k-half, tap) multiplies.  The second group's fifth step repeats tap 8 into a scratch accumulator (branch-free body).
-template <typename T, int STG>
-__global__ __launch_bounds__(512) void conv_wgrad9b_kernel(WgradArgs p) {
-    constexpr int CT = 128, CIT = 32;
-    constexpr int SB = CT / 16;
-    constexpr int STAGE = 2 * kXSub + SB * kSubPitch;
-    static_assert(T::kEPC == 8, "16-bit elements");
-    SY_DYN_SMEM(smem);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = sy_uniform(tid >> 6);
-    const int cw = wv & 3, tg = wv >> 2;          // output-channel tile, tap group
-    const sy_block_id bid = sy_xcd_block_id();
-    const int ci0 = bid.x * CIT;
-    const int c0 = bid.y * CT;
-    const int wsegs = (p.Wo + 31) >> 5;
-    const int slabs_total = p.N * p.Ho * wsegs;
-    const int slab0 = bid.z * p.slabs_per_split;
-    int nslab = p.slabs_per_split;
-    if (slab0 + nslab > slabs_total) nslab = slabs_total - slab0;
-    if (nslab <= 0) return;
-
-    // ---- DMA per slab: wave w issues x piece w (subtile w >> 2, 32-pixel quarter w & 3 of the flattened 3 x 34 window) and dy
-    //      subtile w; lane -> (pixel lane >> 1, 16-byte channel half lane & 1)
-    const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
-    const sy_buffer bufdy = sy_make_buffer(p.dy, p.dy_extent);
-    const sy_lds_base_t lds0 = sy_lds_base(smem);
-    const int half8 = (lane & 1) * 8;
-    const int x_pp = (wv & 3) * 32 + (lane >> 1);
-    const bool x_ok = x_pp < kHaloPix;
-    const int x_hy = x_pp / 34, x_hx = x_pp - x_hy * 34;
-    const int x_c = ci0 + (wv >> 2) * 16 + half8;
-    int cur_n, cur_h, cur_ws;
-    {
-        const int per_img = p.Ho * wsegs;
-        cur_n = slab0 / per_img;
-        const int rem = slab0 - cur_n * per_img;
-        cur_h = rem / wsegs;
-        cur_ws = rem - cur_h * wsegs;
-    }
-    int issued = 0, stage_w = 0;
-    auto issue_slab = [&]() {
-        const unsigned stage = (unsigned)(stage_w * STAGE);
-        const int w0 = cur_ws * 32;
-        {
-            const int hi = cur_h - 1 + x_hy, wi = w0 - 1 + x_hx;
-            const bool ok = x_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && !(p.ablate & 1);
-            const int off = cur_n * (int)p.xbs + (hi * p.W + wi) * p.ldx + x_c;
-            sy_glds16_buf_at(bufx, ok ? (unsigned)(off * 2) : 0xFFFFFFFFu, lds0, stage + (unsigned)((wv >> 2) * kXSub + (wv & 3) * 1024));
-        }
-        {
-            const int wo = w0 + (lane >> 1);
-            const int co = c0 + wv * 16 + half8;
-            const bool ok = wo < p.Wo && co < p.Cout && !(p.ablate & 2);
-            const int off = cur_n * (int)p.dybs + (cur_h * p.Wo + wo) * p.lddy + co;
-            sy_glds16_buf_at(bufdy, ok ? (unsigned)(off * 2) : 0xFFFFFFFFu, lds0, stage + (unsigned)(2 * kXSub + wv * kSubPitch));
-        }
-        if (++cur_ws == wsegs) { cur_ws = 0; if (++cur_h == p.Ho) { cur_h = 0; ++cur_n; } }
-        ++issued;
-        stage_w = (stage_w + 1 == STG) ? 0 : stage_w + 1;
-    };
-    auto wait_slab = [&](int ahead) {             // at most `ahead` later slabs of this wave's loads (2 each) still in flight
-        if (ahead >= 3) sy_wait_vmcnt<6>();
-        else if (ahead == 2) sy_wait_vmcnt<4>();
-        else if (ahead == 1) sy_wait_vmcnt<2>();
-        else sy_wait_vmcnt<0>();
-    };
-
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    // window byte offsets of this wave's taps (wave-uniform): tap group 0 = taps 0-4, group 1 = taps 5-8 (+ tap 8 again)
-    int toff[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        int tap = tg * 5 + i;
-        if (tap > 8) tap = 8;
-        toff[i] = sy_uniform(((tap / 3) * 34 + (tap % 3)) * 32);
-    }
-    const int x_lane = ((lane >> 4) & 1) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
-    const int y_lane = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
-
-    for (int j = 0; j < STG - 1 && j < nslab; ++j) issue_slab();
-    int stage_r = 0;
-    for (int s = 0; s < nslab; ++s) {
-        wait_slab(issued - s - 1);
-        sy_barrier();                             // slab s complete for every wave; everyone is past slab s - 1
-        if (issued < nslab) issue_slab();
-        const unsigned char* const xb = smem + stage_r * STAGE + x_lane;
-        const unsigned char* const yb = smem + stage_r * STAGE + 2 * kXSub + (cw * 2) * kSubPitch + y_lane;
-        stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
-        uint4 a[3], b[2];
-        auto read_a = [&](auto st_) {             // step = (k-half, tap slot)
-            constexpr int ST = decltype(st_)::value;
-            const unsigned char* ptr = xb + toff[ST % 5] + (ST / 5) * 512;
-            const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
-            a[ST % 3] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        };
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const uint2 lo = sy_lds_read_tr16(yb + ks * 512), hi = sy_lds_read_tr16(yb + ks * 512 + 128);
-            b[ks] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-        read_a(sy_int<0>());
-        read_a(sy_int<1>());
-        sy_static_for<0, 10>([&](auto st_) {
-            constexpr int ST = decltype(st_)::value;
-            if constexpr (ST + 2 < 10) read_a(sy_int<ST + 2>());
-            acc[ST % 5] = sy_mfma_group(T(), a[ST % 3], b[ST / 5], acc[ST % 5]);
-            sy_sched_fence();
-        });
-    }
-
-    // ---- epilogue: D[row = (tap, ci)][col = co]; partial slab of this split, or += into dW (one split)
-    const int l31 = lane & 31, half = lane >> 5;
-    const int co = c0 + cw * 32 + l31;
-    if (co >= p.Cout) return;
-    sy_static_for<0, 5>([&](auto i_) {
-        constexpr int I = decltype(i_)::value;
-        const int t = tg * 5 + I;
-        if (t > 8) return;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ci = ci0 + q * 8 + half * 4;
-            const int kb = t * p.Cin + ci;
-            const float v0 = acc[I][q * 4 + 0], v1 = acc[I][q * 4 + 1], v2 = acc[I][q * 4 + 2], v3 = acc[I][q * 4 + 3];
-            if (p.splits > 1) {
-                wgrad_store_slab(p, bid.z, co, kb, v0, v1, v2, v3);
-            } else if (p.oihw) {
-                float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
-                row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
-            } else {
-                float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co * p.K + kb);
-                float4 o = *dst;
-                o.x += v0; o.y += v1; o.z += v2; o.w += v3;
-                *dst = o;
-            }
-        }
-    });
-}
-
 // dW (+)= sum over splits of the partial slabs; also applies the slab -> packed / OIHW layout change.
 // Slabs are [split][K / 4][Cout][4] (coalesced stores in the weight-gradient kernels); the fold walks them in that order —
 // coalesced reads of the `splits` x larger side — and scatters its single read-modify-write of dW.
@@ -915,7 +763,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int STG, int EIGHT = 0, int PD = 2>
+template <typename T, int STG>
 int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
     if constexpr (T::kEPC != 8) {
         return SY_ERR_UNSUPPORTED;
@@ -940,18 +788,12 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 #ifndef SY_EMU
         static bool attr_done = false;
         if (!attr_done) {
-            const void* fn;
-            if constexpr (EIGHT) fn = (const void*)conv_wgrad9b_kernel<T, STG>;
-            else fn = (const void*)conv_wgrad9_kernel<T, STG, PD>;
+            const void* fn = (const void*)conv_wgrad9_kernel<T, STG>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
             attr_done = true;
         }
 #endif
-        if constexpr (EIGHT) {
-            SY_LAUNCH((conv_wgrad9b_kernel<T, STG>), dim3(gx, gy, splits), dim3(512), smem, stream, a);
-        } else {
-            SY_LAUNCH((conv_wgrad9_kernel<T, STG, PD>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
-        }
+        SY_LAUNCH((conv_wgrad9_kernel<T, STG>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
         if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
@@ -962,10 +804,6 @@ template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
     if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
     if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
-    if (a.tile == 50) return launch_wgrad9<T, 3, 0, 4>(a, ws_bytes, stream);  // ... x fragments requested four steps ahead instead of two:
-    if (a.tile == 66) return launch_wgrad9<T, 4, 0, 4>(a, ws_bytes, stream);  //     candidates for the next measurement round, not tuner defaults
-    if (a.tile == 51) return launch_wgrad9<T, 3, 1>(a, ws_bytes, stream);  // ... on eight waves (two per SIMD), pipelined fragment reads
-    if (a.tile == 67) return launch_wgrad9<T, 4, 1>(a, ws_bytes, stream);
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128
         case 2: return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);   // 128 x  64
@@ -981,9 +819,6 @@ int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
         case 22: return launch_wgrad_cfg<T, 2, 2, 1, 2, 3>(a, ws_bytes, stream);
         case 33: return launch_wgrad_cfg<T, 2, 2, 2, 2, 4>(a, ws_bytes, stream);
         case 34: return launch_wgrad_cfg<T, 4, 1, 1, 2, 4>(a, ws_bytes, stream);
-        // eight accumulator tiles per wave (16 MFMAs per slab barrier instead of 8): candidates for the next measurement round
-        case 35: return launch_wgrad_cfg<T, 2, 2, 4, 2, 3>(a, ws_bytes, stream);   // 256 x 128
-        case 36: return launch_wgrad_cfg<T, 2, 2, 2, 4, 3>(a, ws_bytes, stream);   // 128 x 256
         default: break;
     }
     // defaults: transpose-read variants (they fall back to the scatter kernel of the same tile when not applicable)

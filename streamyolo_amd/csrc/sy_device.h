@@ -23,20 +23,6 @@
         if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
         sy_launch_fn_(nullptr);                                                                                      \
     } while (0)
-// a launch whose workgroups wait for one another: the caller bounds the grid by the device's residency; the emulator runs every
-// workgroup on its own OS thread
-#define SY_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...)                                                   \
-    do {                                                                                                             \
-        const dim3 sy_grid_ = (grid), sy_block_ = (block);                                                           \
-        const size_t sy_smem_ = (smem);                                                                              \
-        auto sy_args_ = std::make_tuple(__VA_ARGS__);                                                                \
-        auto sy_launch_fn_ = [=](void*) {                                                                            \
-            emu::launch(sy_grid_, sy_block_, sy_smem_,                                                               \
-                        [=]() { std::apply([](auto... sy_a_) { kernel(sy_a_...); }, sy_args_); }, true);             \
-        };                                                                                                           \
-        if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
-        sy_launch_fn_(nullptr);                                                                                      \
-    } while (0)
 #define SY_LAUNCH_OK() 0
 #else
 #include <hip/hip_runtime.h>
@@ -59,7 +45,6 @@
         if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
         sy_launch_fn_((void*)(stream));                                                                              \
     } while (0)
-#define SY_LAUNCH_RESIDENT SY_LAUNCH
 #define SY_LAUNCH_OK() ((int)hipGetLastError())
 #endif
 
@@ -178,32 +163,6 @@ __device__ __forceinline__ void sy_glds16(const void* gsrc, unsigned char* lds_w
 }
 template <int N> __device__ __forceinline__ void sy_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void sy_barrier() { __builtin_amdgcn_s_barrier(); }
-#endif
-
-// ---- agent-scope helpers of the "last workgroup finalises" pattern (conv_stats_finalize, conv_igemm_impl.h) -----------------
-// The statistic atomics of every workgroup are agent-scope RMWs (performed at the device's coherence point, not in one XCD's
-// L2); a ticket taken AFTER they have retired (sy_wait_vmcnt<0>) orders them before the last workgroup's agent-scope loads.
-#ifdef SY_EMU
-static inline unsigned sy_ticket_take(unsigned* t) { return reinterpret_cast<std::atomic<unsigned>*>(t)->fetch_add(1u); }
-static inline void sy_ticket_reset(unsigned* t) { reinterpret_cast<std::atomic<unsigned>*>(t)->store(0u); }
-static inline float sy_load_agent(const float* p) {
-    return reinterpret_cast<const std::atomic<float>*>(p)->load();
-}
-static inline void sy_spin_until_ge(const unsigned* p, unsigned target) {
-    while (reinterpret_cast<const std::atomic<unsigned>*>(p)->load() < target) std::this_thread::yield();
-}
-#else
-__device__ __forceinline__ unsigned sy_ticket_take(unsigned* t) {
-    return __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sy_ticket_reset(unsigned* t) { __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float sy_load_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one lane polls an agent-scope counter (the waiting workgroup sleeps between polls: the others need the issue slots)
-__device__ __forceinline__ void sy_spin_until_ge(const unsigned* p, unsigned target) {
-    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-}
 #endif
 
 // ---- LDS transpose read (ds_read_b64_tr_b16) ---------------------------------------------------------

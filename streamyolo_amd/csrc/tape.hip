@@ -14,8 +14,11 @@
 // and, for plans that run more than two chains (sy_tape_replay_n, streams[0] = main, [1] = side, [2..] = further chains):
 //   CUR(k)        cursor to stream k, no new dependency
 //   DEP(a, b)     stream a records an event, stream b waits for it (arg = a * 16 + b)
-//   SLOT_DONE(s)  event on the CURRENT stream = "ring slot s is free again"
-//   ACQUIRE_CUR(s) the CURRENT stream waits for that event (the slot stays marked: several chains may wait for it)
+//   SLOT_DONE(s)  event on the CURRENT stream = "this stream's readers of ring slot s are done".  A slot collects one such event
+//                 PER STREAM (the weight gradient on its stream, the data gradient(s) of the same raw gradient on the chain(s)
+//                 that produced it): the first SLOT_DONE after an acquisition starts a new set.
+//   ACQUIRE_CUR(s) the CURRENT stream waits for EVERY event of the slot's set that was recorded on another stream (the set stays:
+//                 several chains may acquire the same slot — each frame's half of it)
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
 
@@ -34,10 +37,21 @@ struct Tape {
     std::vector<Entry> entries;
     int launches = 0;
     // replay state (persists across the BREAK / BUCKET returns of one pass)
-    bool on_side = false;
     int cur_k = 0;                       // index of the cursor stream (0 = main, 1 = side, ...)
-    int ei = 0;
-    int ring_done[kMaxSlots];
+    int ei = 0;                          // events used so far in this pass
+    int waits = 0;                       // stream-waits issued so far in this pass
+    struct Slot {
+        int ev[kMaxStreams];             // latest "done" event of the slot per stream index (-1: none)
+        bool acquired;                   // somebody acquired the slot since the last SLOT_DONE: the next one starts a new set
+    } slots[kMaxSlots];
+    void slot_clear(int s) {
+        for (int k = 0; k < kMaxStreams; ++k) slots[s].ev[k] = -1;
+        slots[s].acquired = false;
+    }
+    void slot_done(int s, int k, int ev) {
+        if (slots[s].acquired) slot_clear(s);
+        slots[s].ev[k] = ev;
+    }
 #ifndef SY_EMU
     std::vector<hipEvent_t> pool;
     hipEvent_t next_event() {
@@ -75,7 +89,9 @@ extern "C" int sy_tape_mark(int kind, int arg) {
     if (g_rec == nullptr || kind <= SY_TAPE_LAUNCH || kind > SY_TAPE_ACQUIRE_CUR) return SY_ERR_ARG;
     if ((kind == SY_TAPE_MAIN || kind == SY_TAPE_ACQUIRE || kind == SY_TAPE_SLOT_DONE || kind == SY_TAPE_ACQUIRE_CUR) && arg >= kMaxSlots)
         return SY_ERR_ARG;
-    if ((kind == SY_TAPE_SLOT_DONE || kind == SY_TAPE_ACQUIRE_CUR || kind == SY_TAPE_CUR || kind == SY_TAPE_DEP) && arg < 0) return SY_ERR_ARG;
+    if ((kind == SY_TAPE_SLOT_DONE || kind == SY_TAPE_ACQUIRE_CUR || kind == SY_TAPE_ACQUIRE || kind == SY_TAPE_CUR || kind == SY_TAPE_DEP) && arg < 0)
+        return SY_ERR_ARG;
+    if (kind == SY_TAPE_CUR && arg >= kMaxStreams) return SY_ERR_ARG;
     g_rec->entries.push_back(Entry{kind, arg, nullptr});
     return SY_OK;
 }
@@ -98,6 +114,14 @@ extern "C" void sy_tape_free(void* tape) {
     if (tape != nullptr && tape != g_rec) delete (Tape*)tape;
 }
 
+extern "C" int sy_tape_counters(const void* tape, int* n_events, int* n_waits) {
+    if (tape == nullptr) return SY_ERR_ARG;
+    const Tape* t = (const Tape*)tape;
+    if (n_events != nullptr) *n_events = t->ei;
+    if (n_waits != nullptr) *n_waits = t->waits;
+    return SY_OK;
+}
+
 extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams, int* pos, int stop_buckets, int* stop_kind,
                                 int* stop_arg, int* stop_stream) {
     if (tape == nullptr || pos == nullptr || stop_kind == nullptr || stop_arg == nullptr || g_rec != nullptr || streams == nullptr ||
@@ -108,21 +132,38 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
     int i = *pos;
     if (i < 0 || i > n) return SY_ERR_ARG;
     if (i == 0) {
-        t->on_side = false;
         t->cur_k = 0;
         t->ei = 0;
-        for (int s = 0; s < kMaxSlots; ++s) t->ring_done[s] = -1;
+        t->waits = 0;
+        for (int s = 0; s < kMaxSlots; ++s) t->slot_clear(s);
     }
     void* const main_stream = streams[0];
     void* const side_stream = n_streams > 1 ? streams[1] : nullptr;
     const bool two = side_stream != nullptr && side_stream != main_stream;
     // a chain index the caller gave no stream for runs on the main stream (one- / two-stream replay of a three-chain tape)
     auto stream_of = [&](int k) -> void* { return (two && k >= 0 && k < n_streams && streams[k] != nullptr) ? streams[k] : main_stream; };
+    // event bookkeeping (the same in the emulator build, which issues nothing: tests/test_tape.py counts events and waits there)
+    bool failed = false;
+    auto record = [&](void* on) -> int {                     // event on stream `on` -> its index in the pool
 #ifndef SY_EMU
-    hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+        hipEvent_t ev = t->next_event();
+        if (ev == nullptr || hipEventRecord(ev, (hipStream_t)on) != hipSuccess) failed = true;
+        return t->ei - 1;
+#else
+        (void)on;
+        return t->ei++;
 #endif
+    };
+    auto wait = [&](void* who, int ev) {                     // stream `who` waits for event `ev`
+        t->waits++;
+#ifndef SY_EMU
+        if (hipStreamWaitEvent((hipStream_t)who, t->pool[ev], 0) != hipSuccess) failed = true;
+#else
+        (void)who; (void)ev;
+#endif
+    };
     void* cur = stream_of(t->cur_k);
-    for (; i < n; ++i) {
+    for (; i < n && !failed; ++i) {
         Entry& e = t->entries[i];
         switch (e.kind) {
             case SY_TAPE_LAUNCH:
@@ -134,18 +175,14 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
                 *pos = i + 1;
                 *stop_kind = e.kind;
                 *stop_arg = e.arg;
-                if (stop_stream != nullptr) *stop_stream = two ? t->cur_k : 0;
+                // index of the stream the cursor REALLY issues on: a chain the caller gave no stream for runs on main (0), and
+                // the snippet that runs at this break must be issued there too
+                if (stop_stream != nullptr) *stop_stream = (two && cur != main_stream) ? t->cur_k : 0;
                 return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
             case SY_TAPE_SIDE:
             case SY_TAPE_FORK:
                 if (!two) break;
-#ifndef SY_EMU
-                {
-                    hipEvent_t ev = t->next_event();
-                    if (ev == nullptr || hipEventRecord(ev, ms) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess)
-                        return SY_ERR_LAUNCH;
-                }
-#endif
+                wait(side_stream, record(main_stream));
                 if (e.kind == SY_TAPE_SIDE) { cur = side_stream; t->cur_k = 1; }
                 break;
             case SY_TAPE_SIDE_NW:
@@ -154,33 +191,18 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
                 break;
             case SY_TAPE_MAIN:
                 if (!two) break;
-#ifndef SY_EMU
-                if (e.arg >= 0) {
-                    hipEvent_t ev = t->next_event();
-                    if (ev == nullptr || hipEventRecord(ev, ss) != hipSuccess) return SY_ERR_LAUNCH;
-                    t->ring_done[e.arg] = t->ei - 1;
-                }
-#endif
+                if (e.arg >= 0) t->slot_done(e.arg, 1, record(side_stream));
                 cur = main_stream; t->cur_k = 0;
                 break;
             case SY_TAPE_ACQUIRE:
                 if (!two) break;
-#ifndef SY_EMU
-                if (t->ring_done[e.arg] >= 0) {
-                    if (hipStreamWaitEvent(ms, t->pool[t->ring_done[e.arg]], 0) != hipSuccess) return SY_ERR_LAUNCH;
-                    t->ring_done[e.arg] = -1;
-                }
-#endif
+                for (int k = 1; k < kMaxStreams; ++k)
+                    if (t->slots[e.arg].ev[k] >= 0 && stream_of(k) != main_stream) wait(main_stream, t->slots[e.arg].ev[k]);
+                t->slot_clear(e.arg);
                 break;
             case SY_TAPE_JOIN:
                 if (!two) break;
-#ifndef SY_EMU
-                {
-                    hipEvent_t ev = t->next_event();
-                    if (ev == nullptr || hipEventRecord(ev, ss) != hipSuccess || hipStreamWaitEvent(ms, ev, 0) != hipSuccess)
-                        return SY_ERR_LAUNCH;
-                }
-#endif
+                wait(main_stream, record(side_stream));
                 break;
             case SY_TAPE_CUR:
                 if (!two) break;
@@ -192,35 +214,24 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
                 void* const from = stream_of(e.arg >> 4);
                 void* const to = stream_of(e.arg & 15);
                 if (from == to) break;
-#ifndef SY_EMU
-                hipEvent_t ev = t->next_event();
-                if (ev == nullptr || hipEventRecord(ev, (hipStream_t)from) != hipSuccess ||
-                    hipStreamWaitEvent((hipStream_t)to, ev, 0) != hipSuccess)
-                    return SY_ERR_LAUNCH;
-#endif
+                wait(to, record(from));
                 break;
             }
             case SY_TAPE_SLOT_DONE:
                 if (!two) break;
-#ifndef SY_EMU
-                {
-                    hipEvent_t ev = t->next_event();
-                    if (ev == nullptr || hipEventRecord(ev, (hipStream_t)cur) != hipSuccess) return SY_ERR_LAUNCH;
-                    t->ring_done[e.arg] = t->ei - 1;
-                }
-#endif
+                t->slot_done(e.arg, t->cur_k, record(cur));
                 break;
             case SY_TAPE_ACQUIRE_CUR:
                 if (!two) break;
-#ifndef SY_EMU
-                if (t->ring_done[e.arg] >= 0 && hipStreamWaitEvent((hipStream_t)cur, t->pool[t->ring_done[e.arg]], 0) != hipSuccess)
-                    return SY_ERR_LAUNCH;
-#endif
+                for (int k = 0; k < kMaxStreams; ++k)
+                    if (t->slots[e.arg].ev[k] >= 0 && stream_of(k) != cur) wait(cur, t->slots[e.arg].ev[k]);
+                t->slots[e.arg].acquired = true;
                 break;
             default:
                 return SY_ERR_ARG;
         }
     }
+    if (failed) return SY_ERR_LAUNCH;
     *pos = n;
     *stop_kind = SY_TAPE_END;
     *stop_arg = 0;

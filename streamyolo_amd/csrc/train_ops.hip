@@ -670,146 +670,6 @@ __global__ __launch_bounds__(kBlock) void fold_replicas_kernel(float* sums, int 
     sums[i] = a;
 }
 
-// ---- BatchNorm.SiLU backward in ONE launch (sy_bn_silu_bwd_fused) ---------------------------------------------------------------
-// The two row kernels above reach 4.4-5.8 TB/s on the big tensors but 1-3 TB/s on the 9-37 MB tensors of the 19x30 ... 75x120
-// maps, which are most of the launches of a step: there they are launch ramp + tail, twice, and the second pass re-reads both
-// tensors.  Here a workgroup owns (channel slice of CS channels = one 128-byte line per pixel row) x (a chunk of rows * R
-// pixels) and keeps its chunk of the raw output and of the incoming gradient in REGISTERS: it reduces the chunk, adds to the
-// slice's two sums, announces itself on the slice's arrival counter and waits until the slice's other chunks have arrived
-// (statistics are per channel: the wait is among the workgroups of ONE slice, all resident because the host bounds the grid),
-// then applies from registers.  One launch instead of two, both tensors read once.  Counters: [segment][slice][2] = arrivals,
-// departures; the last workgroup to depart resets both.  `sums` ([segment][2][C]) must be zero on entry.
-template <typename T, int R>
-__global__ __launch_bounds__(kBlock) void bn_silu_bwd_fused_kernel(const typename T::elem* y, int ldy, const typename T::elem* da, int ldda,
-                                                                   const float* scale, const float* shift, const float* mean,
-                                                                   const float* invstd, const float* gamma, float* sums,
-                                                                   unsigned* tickets, typename T::elem* dy, int lddy, long long pixels,
-                                                                   int C, int CS, float* dgamma, float* dbeta, typename T::elem* dres,
-                                                                   int lddres, int dres_acc) {
-    __shared__ float red[kBlock * 2 * 8];
-    __shared__ float s_tot[2 * 64];
-    const int cpp = CS / T::kEPC;
-    const int rows = kBlock / cpp;
-    const int cc = threadIdx.x % cpp;
-    const int pr = threadIdx.x / cpp;
-    const int cb = blockIdx.z * CS;
-    const int c0 = cb + cc * T::kEPC;
-    const int seg = blockIdx.y;
-    {
-        const long long ro = (long long)seg * pixels;
-        const int ao = seg * C;
-        y += ro * ldy; da += ro * ldda; dy += ro * lddy; scale += ao; shift += ao; mean += ao; invstd += ao;
-        sums += (long long)seg * 2 * C;
-        if (dres != nullptr) dres += ro * lddres;
-    }
-    const bool live = pr < rows;
-    const long long base = (long long)blockIdx.x * rows * R + pr;
-    Chunk<T> yq[R], gq[R];
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        const long long pd = base + (long long)d * rows;
-        if (live && pd < pixels) { yq[d] = Chunk<T>::load(y + pd * ldy + c0); gq[d] = Chunk<T>::load(da + pd * ldda + c0); }
-    }
-    float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], s0[T::kEPC], s1[T::kEPC];
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) {
-        const int c = live ? c0 + j : cb;
-        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
-        s0[j] = 0.0f; s1[j] = 0.0f;
-    }
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        if (live && base + (long long)d * rows < pixels) {
-#pragma unroll
-            for (int j = 0; j < T::kEPC; ++j) {
-                const float yy = T::to_f32(yq[d].e[j]);
-                const float dz = T::to_f32(gq[d].e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
-                s0[j] += dz;
-                s1[j] += dz * ((yy - mu[j]) * is[j]);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) {
-        red[(j * 2 + 0) * kBlock + threadIdx.x] = s0[j];
-        red[(j * 2 + 1) * kBlock + threadIdx.x] = s1[j];
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < cpp * T::kEPC * 2; t += kBlock) {
-        const int kind = t & 1, j = (t >> 1) % T::kEPC, ch = (t >> 1) / T::kEPC;
-        float v = 0.0f;
-        for (int r = 0; r < rows; ++r) v += red[(j * 2 + kind) * kBlock + r * cpp + ch];
-        atomicAdd(sums + kind * C + cb + ch * T::kEPC + j, v);
-    }
-    // ---- the slice's workgroups meet: arrive, wait for the others, read the totals
-    unsigned* const arrive = tickets + ((long long)seg * gridDim.z + blockIdx.z) * 2;
-    sy_wait_vmcnt<0>();                                   // this thread's atomics have been performed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sy_ticket_take(arrive);
-        sy_spin_until_ge(arrive, gridDim.x);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 2 * CS; t += kBlock) s_tot[t] = sy_load_agent(sums + (t / CS) * C + cb + (t % CS));
-    __syncthreads();
-    if (threadIdx.x == 0 && sy_ticket_take(arrive + 1) == gridDim.x - 1u) {       // last to depart: everybody has read the totals
-        sy_ticket_reset(arrive);
-        sy_ticket_reset(arrive + 1);
-    }
-    if (blockIdx.x == 0 && dgamma != nullptr) {
-        const bool atomics = gridDim.y > 1 || (dres_acc & 2);
-        for (int c = threadIdx.x; c < CS; c += kBlock) {
-            if (atomics) { atomicAdd(dbeta + cb + c, s_tot[c]); atomicAdd(dgamma + cb + c, s_tot[CS + c]); }
-            else { dbeta[cb + c] += s_tot[c]; dgamma[cb + c] += s_tot[CS + c]; }
-        }
-    }
-    if (!live) return;
-    // the apply below recomputes dz from the PACKED chunks: laundering them keeps hipcc from carrying every unpacked float of the
-    // reduction across the wait (305 -> see tools/loop_census / the build's metadata: registers decide how many workgroups fit)
-#ifndef SY_EMU
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        uint4 a, b;
-        __builtin_memcpy(&a, yq[d].e, 16);
-        __builtin_memcpy(&b, gq[d].e, 16);
-        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-        __builtin_memcpy(yq[d].e, &a, 16);
-        __builtin_memcpy(gq[d].e, &b, 16);
-    }
-#endif
-    const float inv_m = 1.0f / (float)pixels;
-    float gi[T::kEPC], m0[T::kEPC], m1[T::kEPC];
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) {
-        gi[j] = gamma[c0 + j] * is[j];
-        m0[j] = s_tot[cc * T::kEPC + j] * inv_m;
-        m1[j] = s_tot[CS + cc * T::kEPC + j] * inv_m;
-    }
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        const long long pix = base + (long long)d * rows;
-        if (pix >= pixels) continue;
-        Chunk<T> o;
-#pragma unroll
-        for (int j = 0; j < T::kEPC; ++j) {
-            const float yy = T::to_f32(yq[d].e[j]);
-            const float dz = T::to_f32(gq[d].e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
-            o.e[j] = T::from_f32(gi[j] * (dz - m0[j] - (yy - mu[j]) * is[j] * m1[j]));
-        }
-        o.store(dy + pix * lddy + c0);
-        if (dres != nullptr) {
-            typename T::elem* dst = dres + pix * lddres + c0;
-            Chunk<T> gv = gq[d];
-            if (dres_acc & 1) {
-                Chunk<T> r = Chunk<T>::load(dst);
-#pragma unroll
-                for (int j = 0; j < T::kEPC; ++j) gv.e[j] = T::from_f32(T::to_f32(gv.e[j]) + T::to_f32(r.e[j]));
-            }
-            gv.store(dst);
-        }
-    }
-}
-
 inline bool chunk_rows_ok(int C, int e) { const int cpp = C / e; return cpp >= 1 && cpp <= kBlock; }
 
 inline int env_cap(const char* name, int dflt) {          // tuning knob (tools/): workgroups per launch of the row kernels
@@ -930,61 +790,6 @@ extern "C" int sy_bn_finalize_apply(const float* sum, const float* sqsum, int co
                                        stream, sum, sqsum, copies, count, gamma, beta, eps, scale, shift, mean, invstd,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C, CS));
-}
-
-/* see the header */
-extern "C" int sy_bn_silu_bwd_fused(const void* y, int ldy, const void* da, int ldda, const float* scale, const float* shift,
-                                    const float* mean, const float* invstd, const float* gamma, float* sums, uint32_t* tickets,
-                                    void* dy, int lddy, int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
-                                    int dres_accumulate, int dtype, int nseg, void* stream) {
-    if (y == nullptr || da == nullptr || sums == nullptr || tickets == nullptr || dy == nullptr || pixels <= 0 || C <= 0 || nseg < 1)
-        return SY_ERR_ARG;
-    if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
-    const int e = epc_of(dtype);
-    if (C % e || ldy % e || ldda % e || lddy % e || (dres != nullptr && lddres % e)) return SY_ERR_UNSUPPORTED;
-    int CS = 0;
-    for (int c = (64 / e) * e; c >= e; c -= e)
-        if (c <= C && C % c == 0 && kBlock % (c / e) == 0) { CS = c; break; }
-    if (CS == 0) return SY_ERR_UNSUPPORTED;
-    const int nsl = C / CS, rows = kBlock / (CS / e);
-    // Every workgroup of the launch must be resident at once (they wait for each other), and so must the workgroups of any OTHER
-    // launch of this kernel that runs at the same time on another stream (the two frame chains of the backward pass): two
-    // partially resident spinning launches would wait for each other's slots for ever.  The grid is therefore bounded by the
-    // kernel's true residency (occupancy API) divided by the number of launches that may spin concurrently (SY_BN_FUSED_SHARE).
-#ifdef SY_EMU
-    const long long cap4 = 48, cap8 = 48, cap16 = 48;              // one OS thread per workgroup
-#else
-    static long long caps[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};      // [dtype][R index]
-    auto cap_of = [&](int ri, const void* fn) -> long long {
-        long long& c = caps[dtype - SY_DT_BF16][ri];
-        if (c < 0) {
-            int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                per_cu = 0;
-            static const int share = env_cap("SY_BN_FUSED_SHARE", 2);
-            c = (long long)per_cu * cus / share;
-        }
-        return c;
-    };
-#define SY_FUSED_FN(RR) (dtype == SY_DT_BF16 ? (const void*)bn_silu_bwd_fused_kernel<BF16, RR> : dtype == SY_DT_F16 ? (const void*)bn_silu_bwd_fused_kernel<F16, RR> : (const void*)bn_silu_bwd_fused_kernel<F32, RR>)
-    if (dtype < SY_DT_BF16 || dtype > SY_DT_F32) return SY_ERR_ARG;
-    const long long cap4 = cap_of(0, SY_FUSED_FN(4)), cap8 = cap_of(1, SY_FUSED_FN(8)), cap16 = cap_of(2, SY_FUSED_FN(16));
-#undef SY_FUSED_FN
-#endif
-    auto blocks = [&](int r) { return ((pixels + (long long)rows * r - 1) / ((long long)rows * r)) * nseg * nsl; };
-#define SY_FUSED(RR)                                                                                                         \
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH_RESIDENT((bn_silu_bwd_fused_kernel<T, RR>),                                           \
-                                                dim3((unsigned)((pixels + (long long)rows * RR - 1) / ((long long)rows * RR)), nseg, nsl), \
-                                                dim3(kBlock), 0, stream, (const typename T::elem*)y, ldy, (const typename T::elem*)da,   \
-                                                ldda, scale, shift, mean, invstd, gamma, sums, (unsigned*)tickets,           \
-                                                (typename T::elem*)dy, lddy, (long long)pixels, C, CS, dgamma, dbeta,         \
-                                                (typename T::elem*)dres, lddres, dres_accumulate))
-    if (blocks(4) <= cap4) { SY_FUSED(4); }
-    if (blocks(8) <= cap8) { SY_FUSED(8); }
-    if (blocks(16) <= cap16) { SY_FUSED(16); }
-#undef SY_FUSED
-    return SY_ERR_UNSUPPORTED;                 // too large for one resident launch: the two-pass kernels take it
 }
 
 extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,

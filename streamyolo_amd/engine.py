@@ -90,9 +90,8 @@ class FocusOp:
 # ------------------------------------------------------------------------------------------------
 # network builders
 # ------------------------------------------------------------------------------------------------
-# streaming launch tape: head level 0 beside levels 1-2 on a second stream.  Measured on MI355X (profiles/r03/c_*): 1.883 vs
-# 1.849 ms per frame on one stream — at batch 1 the frame is bound by dispatch, not by idle CUs; off by default.
-TWO_STREAM_HEAD = os.environ.get("STREAMYOLO_STREAM_HEAD_FORK", "0") != "0"
+# (streaming head level 0 beside levels 1-2 on a second stream: 1.883 vs 1.849 ms per frame on one stream — profiles/r03/c_* — at
+#  batch 1 the frame is bound by dispatch, not by idle CUs; removed in round 4)
 # test hook: "S,tile" forces a split-K decision for every eligible layer (the emulator has no tuner)
 FORCE_SPLIT_K = tuple(int(v) for v in os.environ["STREAMYOLO_FORCE_SPLIT_K"].split(",")) if os.environ.get("STREAMYOLO_FORCE_SPLIT_K") else None
 
@@ -343,7 +342,7 @@ class InferencePlan:
         self.decode = decode
         self.cache = ParamCache(self.dtype, device)
         self._stream_tape, self._tape_param_list = None, None
-        self._rec, self._side = None, None           # open native tape (run_stream_taped) / its side stream
+        self._rec = None                             # open native tape (run_stream_taped)
         # split-K for the deep small-map 3x3 layers of the streaming step (36-72 workgroups at batch 1): opt-in, because the
         # fp32 summation order differs from the single-pass kernel (the facade's off_pipe == chained on_pipe bit-identity is
         # kept on the exact path); StreamingDetector / bench.py --workload stream turn it on for the 16-bit modes
@@ -542,9 +541,7 @@ class InferencePlan:
         prog = self._stream_tape
         from . import _lib
         if prog is None or prog[0] != sig or prog[1] is not post:
-            # native tape (csrc/tape.hip): the launches are recorded inside the library and replayed by ONE C call; the head's
-            # levels fan out over two streams there (level 0 beside levels 1-2), which a hipGraph capture of this plan cannot
-            # do on this ROCm build
+            # native tape (csrc/tape.hip): the launches are recorded inside the library and replayed by ONE C call
             self._ensure_tuned()
             tape = _lib.NativeTape()
             with tape:
@@ -556,12 +553,7 @@ class InferencePlan:
                     self._rec = None
             self._stream_tape = (sig, post, tape, res)
             return res
-        main_h, side_h = ops.stream_of(self.out), None
-        if self.out.is_cuda and TWO_STREAM_HEAD:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            side_h = ops.C.c_void_p(self._side.cuda_stream)
-        prog[2].replay(main_h, side_h)
+        prog[2].replay(ops.stream_of(self.out), None)
         return prog[3]
 
     def export_buffer(self):
@@ -571,16 +563,8 @@ class InferencePlan:
 
     def run_head(self):
         head = self.ops[self.n_backbone_ops:]
-        self._mark("fork")                                        # (tape marks: no-ops outside run_stream_taped's recording)
         for op in head:
-            if op.level == 0:
-                self._run_op(op)
-        self._mark("side_nw")                                     # levels 1-2 beside level 0 on the side stream
-        for op in head:
-            if op.level != 0:
-                self._run_op(op)
-        self._mark("main")
-        self._mark("join")
+            self._run_op(op)
         if not self.decode:
             # decode_in_inference=False (tal_head.py:220-223): boxes stay raw, obj/cls are still sigmoids
             self.out[..., 4].sigmoid_()

@@ -118,7 +118,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None, segments=1, in_affine=None, in_segments=1, k_splits=0, fin=None):
+           cout=None, tile=0, wfrag=None, segments=1, k_splits=0):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -152,28 +152,7 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     if wfrag is not None:
         d.wfrag, d.wfrag_bytes = wfrag.data_ptr(), wfrag.numel() * wfrag.element_size()
     d.k_splits = int(k_splits)          # > 1: fp32 partial sums per channel-slab range (see sy_splitk_epilogue)
-    if in_affine is not None:           # x is the producer's RAW output: normalise it in LDS (tiles 117 / 118), see the header
-        d.in_scale, d.in_shift, d.in_segments = in_affine[0].data_ptr(), in_affine[1].data_ptr(), int(in_segments)
-    if fin is not None:                 # BnFinRecord: the last workgroup of every channel tile finalises the BatchNorm affine
-        d.fin = fin.ptr
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
-
-
-class BnFinRecord:
-    """A sy_bn_fin record in device memory (sy_conv_desc::fin): the statistics launch itself emits scale / shift / mean / invstd
-    of training-mode BatchNorm, in sy_bn_finalize's arithmetic.  ticket: zeroed int32 tensor, >= segments * ceil(C / 32)
-    counters of this layer (the finalising workgroups reset them); scale / shift / mean / invstd: fp32 [segments][C]."""
-
-    def __init__(self, ticket, gamma, beta, eps, count, scale, shift, mean=None, invstd=None):
-        assert ticket.dtype == torch.int32 and ticket.is_contiguous()
-        rec = _lib.BnFin()
-        rec.ticket, rec.gamma, rec.beta = ticket.data_ptr(), gamma.data_ptr(), beta.data_ptr()
-        rec.scale, rec.shift, rec.mean, rec.invstd = scale.data_ptr(), shift.data_ptr(), _p(mean), _p(invstd)
-        rec.count, rec.eps = float(count), float(eps)
-        self.keep = (ticket, gamma, beta, scale, shift, mean, invstd)
-        host = torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8)
-        self.dev = host.to(ticket.device)
-        self.ptr = self.dev.data_ptr()
 
 
 def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, target_blocks=0):
@@ -386,25 +365,6 @@ def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 
-def bn_silu_bwd_fused(y, da, scale, shift, mean, invstd, gamma, sums, tickets, dy, dgamma=None, dbeta=None, nseg=1,
-                      dres=None, dres_accumulate=False, atomic_param_grads=False):
-    """bn_silu_bwd_reduce + bn_silu_bwd_apply in one launch (sy_bn_silu_bwd_fused).  sums: zero fp32 [nseg * 2 * C] (at least);
-    tickets: zeroed int32 [nseg * slices * 2] counters of this layer.  Returns False when the tensor is too large for a resident
-    launch — nothing was launched, the caller runs the two passes."""
-    assert dres is None or (dres.C == y.C and dres.pixels == y.pixels)
-    assert tickets.dtype == torch.int32 and tickets.numel() >= nseg * 2 * max(1, y.C // 8)
-    rc = _lib.lib().sy_bn_silu_bwd_fused(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                                         invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(), tickets.data_ptr(), dy.ptr(), dy.ld,
-                                         y.pixels // nseg, y.C, _p(dgamma), _p(dbeta), None if dres is None else dres.ptr(),
-                                         0 if dres is None else dres.ld,
-                                         (1 if dres_accumulate else 0) | (2 if atomic_param_grads else 0), y.dtype, nseg,
-                                         stream_of(y.buf))
-    if rc == _lib.SY_ERR_UNSUPPORTED:
-        return False
-    check(rc, "sy_bn_silu_bwd_fused")
-    return True
-
-
 class PostprocessWorkspace:
     """Device buffers reused across sy_postprocess calls for a given (B, A)."""
 
@@ -501,9 +461,7 @@ class _TuneStore:
                 with open(_os.path.join(src, fn), "rb") as f:
                     h.update(fn.encode() + b"\0" + f.read())
         h.update(_lib.lib().sy_version())
-        h.update(repr((HALO_TILES, STREAM_1X1, TILE_1X1K)).encode())          # candidate-set switches (A/B runs)
-        if WGRAD_EXTRA or HALO_S2_TILES:
-            h.update(repr((WGRAD_EXTRA, HALO_S2_TILES)).encode())
+        h.update(repr((HALO_TILES, HALO_S2_TILES, TILE_1X1K, WGRAD_EXTRA)).encode())          # candidate-set switches (A/B runs)
         # (no device name in the key: this library is gfx950-only, and torch reports an empty name under rocprofv3 — a profiled
         #  run then overwrote the cache of the normal runs with its own)
         return h.hexdigest()[:16]
@@ -555,10 +513,12 @@ def save_tuned():
     _tune_store.save()
 
 
-HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "112,113,114,115,116,117,118").replace("+", ",").split(",") if t]
-# stride-2 3x3 layers on the window-in-LDS kernels (tile codes 110 = forward, 108 = data gradient): empty until measured
-HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "").replace("+", ",").split(",") if t]
-STREAM_1X1 = _os.environ.get("STREAMYOLO_STREAM_1X1", "1") != "0"
+# (112 / 113 — the first-generation 2x2-wave and 128-pixel tiles — were never chosen by the tuner on any StreamYOLO shape: removed)
+HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,116,117,118").replace("+", ",").split(",") if t]
+# stride-2 3x3 layers on the window-in-LDS kernels (tile codes 110 = forward, 108 = data gradient).  Measured in round 4
+# (profiles/r04/a_probe_s2_*.txt): forward 421 vs 395 (dark2.0) / 739 vs 585 TF/s (dark4.0) against the best implicit-GEMM
+# variant, data gradient 245 vs 250 / 504 vs 484; l step 22.61 vs 22.70 ms (b_bench_s2 / b_bench_base) — candidates by default
+HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "110,108").replace("+", ",").split(",") if t]
 TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123").split(",") if t]
 
 
@@ -616,9 +576,6 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
         cands += [t for t in HALO_TILES if not (t == 116 and Cout > 64)]
     if k == 3 and stride == 2 and wf is not None and Cin % (16 if code == DT_F32 else 32) == 0:
         cands += [t for t in HALO_S2_TILES if (t == 108) == (mode == CONV_DGRAD)]     # 110: forward, 108: data gradient
-    if (k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256) and code != DT_F32 and STREAM_1X1
-            and (with_stats or mode == CONV_DGRAD)):
-        cands.append(120)                      # weight-stationary pixel stream (csrc/conv1x1_stream.h): raw outputs only
     if k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256, 512, 1024, 2048) and code != DT_F32:
         # whole-K burst kernel (csrc/conv1x1_tile.h): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px (Cin <= 256)
         cands += [t for t in TILE_1X1K if not (t == 122 and Cout > 64) and not (t == 123 and Cin > 256) and not (t != 121 and Cin > 512)]
@@ -693,10 +650,8 @@ _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 102
                      (17, 256), (33, 256), (18, 256),
                      # 3x3 stride 1: all nine taps per workgroup (conv_wgrad9_kernel); few splits: the split-K slabs + fold are a
                      # third of its time at 1024 workgroups (profiles/r02/f_wgrad_probe.txt)
-                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512),
-                     # ... on eight waves (conv_wgrad9b_kernel)
-                     (51, 128), (51, 256), (67, 256), (67, 512)]
-# further candidates for A/B runs, "tile:blocks,tile:blocks" (e.g. the deeper-prefetch 3x3 kernels "50:128,50:256,66:256"); part
+                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512)]
+# further candidates for A/B runs, "tile:blocks,tile:blocks"; part
 # of the tuner-cache key, so such a run tunes by itself
 # ("tile/blocks+tile/blocks" is accepted as well: tools/gpu.sh splits its task arguments at ":" and ",")
 WGRAD_EXTRA = [tuple(int(v) for v in e.replace("/", ":").split(":"))
@@ -717,7 +672,7 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
     dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
     best, best_t = (0, 0), float("inf")
     for (t, tb) in _WGRAD_CANDIDATES + WGRAD_EXTRA:
-        if t in (49, 65, 51, 67, 50, 66):
+        if t in (49, 65):
             if k != 3 or stride != 1 or Cin % 32 or Cout % 16:
                 continue
         elif (t & 15) in (1, 5, 6) and Cout < 128:

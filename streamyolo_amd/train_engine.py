@@ -34,17 +34,13 @@ from .ops import View, EPI_LINEAR, CONV_DGRAD
 
 # one launch for BatchNorm finalize + BN.SiLU apply (sy_bn_finalize_apply); "0": the two separate launches (A/B timing)
 # (default off: kernel time 2.77 vs 2.90 ms per l step, but the step itself is not faster at 32 statistic replicas, and the 8
-# replicas that make it 0.26 ms faster break the 1e-5 run-to-run reproducibility of the fp16 step — profiles/r02/t_*, u_*)
+# replicas that make it 0.1-0.26 ms faster break the 1e-5 run-to-run reproducibility of the fp16 step — profiles/r02/t_*, u_*,
+# profiles/r04/d_bench_ff8.json)
 _FUSED_FINALIZE = __import__("os").environ.get("STREAMYOLO_FUSED_FINALIZE", "0") != "0"
-# BatchNorm finalisation by the producing convolution's LAST workgroup (sy_conv_desc::fin) instead of a sy_bn_finalize launch:
-# removing the ~130 finalize launches of an l step outright is worth 2.0 ms of 22.8 (profiles/r03/abl_ablate_step_train_l.txt:
-# a dependent launch on the critical path costs its drain + dispatch whatever it does).  Built and parity-tested at the end of
-# round 3 with no GPU time left to measure it: default off until it has been.
-CONV_FINALIZE = __import__("os").environ.get("STREAMYOLO_CONV_FINALIZE", "0") != "0"
-# BatchNorm.SiLU backward of the small / medium maps as ONE launch (sy_bn_silu_bwd_fused: the workgroups of a channel slice wait for
-# each other with their chunk of both tensors in registers) instead of reduce + apply; tensors too large for a resident launch
-# keep the two passes.  A kernel that spins is developed ON the GPU: built and emulator-green at the end of round 3, default off.
-BN_BWD_FUSED = __import__("os").environ.get("STREAMYOLO_BN_BWD_FUSED", "0") != "0"
+# Measured and REMOVED in round 4 (profiles/r04/README.md): BatchNorm finalisation by the producing convolution's last workgroup
+# (every statistics launch got 8-13 us slower — each workgroup waits for its own atomics and a ticket round trip — the l step
+# 22.6-23.9 vs 22.3-23.0 ms at 2 ... 32 replicas) and BatchNorm backward as one resident launch whose workgroups wait for each
+# other (parity-green on the MI355X, the step 24.58 vs 22.70 ms: spinning workgroups hold the CUs the other chains need).
 
 class _GradSpace:
     """Gradient mirrors of activation buffers + first-write / accumulate bookkeeping per channel range."""
@@ -135,9 +131,7 @@ class StagedWeights:
     exps/train_utils/double_trainer.py:114-119 — so nothing here is cached across steps).  Same lookup surface as
     engine.ParamCache: conv_weight / conv_weight_frag / pred."""
 
-    def __init__(self, plan_ops, dtype, device, early_ops=0):
-        """early_ops: the first `early_ops` ops of the plan get their weights from a separate (small) table, staged on the
-        critical path; the rest ("late") may be staged beside them on another stream (TrainPlan._forward_ops)."""
+    def __init__(self, plan_ops, dtype, device):
         from . import _lib
         self.dtype, self.device = dtype, device
         tdt = ops.TORCH_DTYPE[dtype]
@@ -162,10 +156,7 @@ class StagedWeights:
             return None if t is None else t.data_ptr()
 
         self.bn = {}                     # id(MergedConv) -> (gamma stack, beta stack) fp32, refreshed with the weights
-        n_early_rows = 0
-        for op_i, op in enumerate(plan_ops):
-            if op_i == early_ops:
-                n_early_rows = len(rows)
+        for op in plan_ops:
             if op.kind == "conv" and id(op.mod) not in self.conv:
                 parts = base_convs(op.mod)                                 # one BaseConv, or the stacked parts of a MergedConv
                 w0 = parts[0].conv.weight
@@ -202,27 +193,19 @@ class StagedWeights:
                 entry(op.reg_mod.bias, b_ro, None, None, None, 4, 1, 1, 0, 5, 5, 1, ops.DTYPE_NAME["fp32"])
                 entry(op.obj_mod.bias, b_ro, None, None, None, 1, 1, 1, 4, 5, 5, 1, ops.DTYPE_NAME["fp32"])
                 self.preds[id(op)] = (w_ro, b_ro, w_c, op.cls_mod.bias, w_ro_t, w_c_t)
-        if early_ops >= len(plan_ops):
-            n_early_rows = len(rows)
-        self.tables = []                 # [(device table, entries, tiles)]: early part, late part
-        for part in ((rows[:n_early_rows], rows[n_early_rows:]) if 0 < n_early_rows < len(rows) else (rows,)):
-            arr, tiles = _lib.pack_table(part)
-            self.tables.append((torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(part), tiles))
+        arr, tiles = _lib.pack_table(rows)
+        self.table = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(rows), tiles)
         self.n = len(rows)
         self.sig = tuple(t.data_ptr() for t in self.sources)
 
     def valid(self):
         return self.sig == tuple(t.data_ptr() for t in self.sources)
 
-    @property
-    def has_late(self):
-        return len(self.tables) > 1
-
-    def refresh(self, part=None):
-        """Stage the weights: part None = everything, 0 = the early table, 1 = the late table."""
-        for i, (table, n, tiles) in enumerate(self.tables):
-            if part is None or part == i:
-                ops.check(ops._lib.lib().sy_pack_weights(table.data_ptr(), n, tiles, ops.stream_of(table)), "sy_pack_weights")
+    def refresh(self):
+        """Stage the weights (one launch).  (Staging stem + dark2 first and the rest beside them on an idle stream was measured
+        neutral in round 3 — 22.45-22.55 vs 22.48-22.50 ms, profiles/r03/t_* — and removed.)"""
+        table, n, tiles = self.table
+        ops.check(ops._lib.lib().sy_pack_weights(table.data_ptr(), n, tiles, ops.stream_of(table)), "sy_pack_weights")
 
     def conv_weight(self, mod, transpose=False):
         return self.conv[id(mod)][1 if transpose else 0]
@@ -247,9 +230,6 @@ MERGE_SIBLINGS_TRAIN = os.environ.get("STREAMYOLO_MERGE_TRAIN", "1") != "0"
 # other's MFMA-bound convolutions.  Measured (profiles/r03/f_*): 23.18-23.24 vs 24.02 ms per l step at 8 pairs, 14.75 vs 15.28
 # at 4 — although the half-size kernels are individually slower (kernel sum 18.9 vs 18.0 ms).
 FWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_FWD_SPLIT_FRAMES", "1") != "0"
-# sy_pack_weights (0.25 ms for l, on the critical path in front of the stem) split in two: stem + dark2 weights at once, the rest
-# on an idle stream beside those layers' forward.  Measured neutral (22.45-22.55 vs 22.48-22.50 ms, profiles/r03/t_*): off.
-LATE_WEIGHT_STAGING = os.environ.get("STREAMYOLO_LATE_WEIGHT_STAGING", "0") != "0"
 # ... and in the backward pass: BatchNorm backward + data gradient of the two frames as chains on streams 0 and 2, the (paired)
 # weight gradient of the layer on stream 1 behind both.
 # Measured (profiles/r03/g_*, j_*): l at 8 pairs 22.7-23.0 vs 23.36 ms, l at 4 pairs 14.79 vs 14.75, m 15.45 (both) vs 15.83 (none),
@@ -262,14 +242,8 @@ BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "auto")
 HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "1") != "0"
 DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "1") != "0"
 WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD_STREAMS", "2")) if DUAL_WGRAD else 1))]
-# A/B knobs for the next measurement round (the ablation says the weight gradients cost 4.0 ms of their 6.7 ms of kernel time:
-# they take CUs from the main chain): "off1" = weight gradients only on their own streams (3, 4, ...) instead of sharing stream 1
-# with the forward pass's support-frame chain, and a hardware queue priority for those streams (1 = low on ROCm, 0 = default)
-WGRAD_OWN_STREAMS = os.environ.get("STREAMYOLO_WGRAD_OWN_STREAMS", "0") != "0"
-WGRAD_PRIORITY = int(os.environ.get("STREAMYOLO_WGRAD_PRIORITY", "0"))
-if WGRAD_OWN_STREAMS:
-    WGRAD_STREAMS = [3, 4, 5][:max(1, len(WGRAD_STREAMS))]
-NORM_IN_CONSUMER = os.environ.get("STREAMYOLO_NORM_IN_CONSUMER", "0") != "0"
+# (Weight gradients on streams of their own instead of sharing stream 1 with the forward pass's support-frame chain, with or without
+# a low hardware queue priority: 22.78-22.79 vs 22.70 ms — profiles/r04/b_bench_ownw*.json — removed.)
 
 
 def _csp_role(tag):
@@ -345,7 +319,6 @@ class TrainPlan:
         BC = self.BWD_COPIES
         self.bwd_arena = torch.zeros(2 * BC * tot_c, dtype=torch.float32, device=device)  # [copies][sum dz | sum dz*xhat]
         self.aff_arena = torch.empty(4 * tot_c, dtype=torch.float32, device=device)       # scale|shift|mean|invstd
-        self._fin_tickets, self._fin_off = None, 0                                        # sy_bn_fin counters (CONV_FINALIZE)
         off = 0
         max_raw = 0
         nf = self.n_frame_ops
@@ -385,8 +358,7 @@ class TrainPlan:
         w_ = float(getattr(pafpn, "width", 1.0)) if pafpn is not None else 0.0
         self.bwd_split = (BWD_SPLIT_FRAMES == "1") or (BWD_SPLIT_FRAMES == "auto" and B * H * W * w_ * w_ >= 2.0e6)
         self.side2 = torch.cuda.Stream(device=device) if (self.side is not None and (self.bwd_split or HEAD_BWD_CHAINS)) else None
-        self.side_w = {k: torch.cuda.Stream(device=device, priority=WGRAD_PRIORITY)
-                       for k in (WGRAD_STREAMS if WGRAD_OWN_STREAMS else WGRAD_STREAMS[1:])} if self.side is not None else {}
+        self.side_w = {k: torch.cuda.Stream(device=device) for k in WGRAD_STREAMS[1:]} if self.side is not None else {}
         self.side3 = self.side_w.get(3)
         self._chain, self._wg_stream, self._wg_flip = 0, 1, 0
         self.tuned = False                    # the first step (autotuning) runs on one stream
@@ -395,8 +367,7 @@ class TrainPlan:
         for op in self.ops:
             if op.kind == "spp":
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
-        self.cache = StagedWeights(self.ops, self.dtype, device, early_ops=self._early_ops())
-        self._find_norm_consumers()
+        self.cache = StagedWeights(self.ops, self.dtype, device)
         self.loss_ws = None
         self.run_table = None
         self.grads = _GradSpace()
@@ -440,50 +411,6 @@ class TrainPlan:
         self.pred_ws = torch.empty(int(ops._lib.lib().sy_pred_grad_fold_workspace_floats(self.nc)), dtype=torch.float32,
                                    device=device) if head is not None else None
 
-    # ---- producer BatchNorm.SiLU applied by the 3x3 consumer in LDS ------------------------------------------------------------
-    # A BaseConv whose activated output is read ONLY by 3x3 stride-1 convolutions (Bottleneck conv1 -> conv2, head stem ->
-    # first tower convs -> second tower convs) does not need that output in the forward pass: the consumer's halo kernel
-    # normalises the producer's RAW output tile in LDS (sy_conv_desc in_scale / in_shift).  The producer's bn_silu_apply still
-    # runs — the backward pass reads the activated tensor (weight gradient of the consumer) — but on the SIDE stream, off the
-    # forward critical path.  (A first probe without the LDS-write drain before the barrier showed the transform "for free" —
-    # profiles/r03/d_* — it was racing; with the wait in place it costs 12-22 us per launch, profiles/r03/e_*.)
-    def _find_norm_consumers(self):
-        for op in self.ops:
-            op.norm_src, op.defer_apply = None, False
-        if not NORM_IN_CONSUMER:
-            return
-
-        def key(v):
-            return (id(v.root[0]), v.root[1]) if v.root is not None else id(v.buf)
-        readers = {}
-        for op in self.ops:
-            if op.kind == "conv":
-                readers.setdefault(key(op.x), []).append((op.x, op, "x"))
-                if op.res is not None:
-                    readers.setdefault(key(op.res), []).append((op.res, op, "res"))
-            elif op.kind == "pred":
-                for v in (op.reg_x, op.cls_x):
-                    readers.setdefault(key(v), []).append((v, op, "pred"))
-            elif op.kind == "resize":
-                readers.setdefault(key(op.src), []).append((op.src, op, "resize"))
-            elif op.kind == "spp":
-                readers.setdefault(key(op.v), []).append((op.v, op, "spp"))
-        fused_keys = {key(f) for f in self.fused} if self.parts == "backbone" else set()
-        epc = 16 // torch.empty(0, dtype=self.tdtype).element_size()
-        for p_ in self.ops:
-            if p_.kind != "conv" or p_.res is not None or key(p_.y) in fused_keys:
-                continue
-            lo, hi = p_.y.c_off, p_.y.c_off + p_.y.C
-            rd = [(v, op, how) for v, op, how in readers.get(key(p_.y), []) if v.c_off < hi and v.c_off + v.C > lo]
-            ok = bool(rd) and all(how == "x" and op.kind == "conv" and op.k == 3 and op.stride == 1
-                                  and lo <= v.c_off and v.c_off + v.C <= hi and v.C % (4 * epc) == 0
-                                  and (v.N, v.H, v.W) == (p_.y.N, p_.y.H, p_.y.W) for v, op, how in rd)
-            if not ok:
-                continue
-            p_.defer_apply = True
-            for v, op, _ in rd:
-                op.norm_src = (p_, v.c_off - lo)          # producer, first channel of the consumer's slice inside it
-
     def _bind_scratch(self):
         """Split-K workspace and raw-gradient ring: shared with the module's other plans (multi-scale training keeps several
         plans alive; these two are pure scratch, 256 MB + RING x the largest raw gradient) or plan-owned without a pool."""
@@ -500,7 +427,7 @@ class TrainPlan:
             slots = [torch.empty(ring_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.RING)]
             self._scratch_gen = 0
         self.dyraw_ring = [t[:self.max_raw * esz].view(self.tdtype) for t in slots]
-        self.wgrad_ws_by = {1: self.wgrad_ws, WGRAD_STREAMS[0]: self.wgrad_ws}
+        self.wgrad_ws_by = {WGRAD_STREAMS[0]: self.wgrad_ws}       # WGRAD_STREAMS[0] == 1: the prediction convs' wgrads run there too
         for k in WGRAD_STREAMS[1:]:                              # one split-K workspace per weight-gradient stream
             self.wgrad_ws_by[k] = (self.pool.shared_scratch("wgrad_ws%d" % k, self.WGRAD_WS_BYTES, self.device)
                                    if self.pool is not None else torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device))
@@ -530,9 +457,8 @@ class TrainPlan:
             self._param_sig = sig
             self.programs.clear()                                # the tapes hold raw pointers
             if not self.cache.valid():
-                self.cache = StagedWeights(self.ops, self.dtype, self.device, early_ops=self._early_ops())
-        # this step's weights -> MFMA operand layouts: the first layers' now, the rest beside them (inside the forward pass)
-        self.cache.refresh(0 if (self.cache.has_late and LATE_WEIGHT_STAGING) else None)
+                self.cache = StagedWeights(self.ops, self.dtype, self.device)
+        self.cache.refresh()                                     # this step's weights -> MFMA operand layouts (one launch)
         self.stat_arena.zero_()
         if self.parts == "head":                                 # x = the three fused FPN features (NCHW-shaped tensors)
             for v, t in zip(self.fused, x):
@@ -564,46 +490,21 @@ class TrainPlan:
             torch._foreach_add_(list(ts), list(cs))
         return self.raw if self.head is not None else self.fused
 
-    def _early_ops(self):
-        """Number of leading plan ops whose weights are staged on the critical path: stem + dark2 of the frame network (a few
-        hundred thousand parameters, ~10 us); everything else is staged on another stream while those layers run."""
-        if not LATE_WEIGHT_STAGING or self.n_frame_ops == 0:
-            return len(self.ops)
-        n = 0
-        for op in self.ops[:self.n_frame_ops]:
-            if op.kind == "conv" and not (op.tag == "stem" or op.tag.startswith("dark2")):
-                break
-            n += 1
-        return n
-
     def _forward_ops(self):
         """The op loop in launch order.  The per-frame network runs ONCE over both frames (2B images per launch, one
         statistics segment per frame — the reference's two backbone passes, dfp_pafpn.py:120-165); after the DFP
         fusion the three head levels fan out over the two streams."""
         nf = self.n_frame_ops
-        late = self.cache.has_late and LATE_WEIGHT_STAGING
-        n_early = self._early_ops() if late else 0
-        ws = WGRAD_STREAMS[-1] if len(WGRAD_STREAMS) > 1 else 2          # a stream that idles during the forward pass
-        if late:
-            self._mark("dep", (0, ws))
-            self._mark("cur", ws)
-            self.cache.refresh(1)                                    # the bulk of the weights, beside stem + dark2
-            self._mark("cur", 0)
         if FWD_SPLIT_FRAMES and nf:
             # the two frames as two independent chains, current frame on the main stream, support frame on the side stream,
             # issued alternately (half-size launches, but one chain's tails and BatchNorm passes fill the other's gaps)
             self._mark("fork")
             for i in range(nf):
-                if late and i == n_early:
-                    self._mark("dep", (ws, 0))
-                    self._mark("dep", (ws, 1))
                 self._forward_op(self.ops[i])
                 self._mark("side_nw")
                 self._forward_op(self.ops[nf + i])
                 self._mark("main", None)
             self._mark("join")
-        elif late:
-            self._mark("dep", (ws, 0))                               # paired launches: no overlap window, wait at once
         for i in range(nf if not (FWD_SPLIT_FRAMES and nf) else 0):
             a, b2 = self.ops[i], self.ops[nf + i]
             if a.kind == "conv":
@@ -648,36 +549,11 @@ class TrainPlan:
         g, b_ = self.cache.bn[id(op.mod)]
         return g, b_, bn.eps, mom
 
-    def _tickets(self, n):
-        """n zeroed int32 counters (self-resetting ticket words of the fin / fused-backward kernels)."""
-        if self._fin_tickets is None or self._fin_off + n > self._fin_tickets.numel():
-            self._fin_tickets, self._fin_off = torch.zeros(max(4096, n), dtype=torch.int32, device=self.device), 0
-        tk = self._fin_tickets[self._fin_off:self._fin_off + n]
-        self._fin_off += n
-        return tk
-
     def _bn_bwd(self, op, y, da, aff, gamma, bsum, dy, dgamma, dbeta, nseg=1, dres=None, acc=False, atomic=False):
-        """BatchNorm.SiLU backward of one launch unit: one fused launch where the tensor allows it (BN_BWD_FUSED), else the two passes."""
-        if BN_BWD_FUSED:
-            key = "bwdtk%d" % nseg
-            tk = op._tiles.get(key)
-            if tk is None:
-                tk = op._tiles[key] = self._tickets(nseg * 2 * max(1, y.C // 8))
-            if ops.bn_silu_bwd_fused(y, da, *aff, gamma, bsum, tk, dy, dgamma, dbeta, nseg=nseg, dres=dres, dres_accumulate=acc,
-                                     atomic_param_grads=atomic):
-                return
+        """BatchNorm.SiLU backward of one launch unit: the reduce pass, then the apply pass."""
         ops.bn_silu_bwd_reduce(y, da, *aff, bsum, nseg=nseg)
         ops.bn_silu_bwd_apply(y, da, *aff, gamma, bsum, dy, dgamma, dbeta, nseg=nseg, dres=dres, dres_accumulate=acc,
                               atomic_param_grads=atomic)
-
-    def _fin(self, op, gamma, beta, eps, aff, nseg):
-        """The sy_bn_fin record of `op`'s statistics launch (nseg = 2: the paired launch over both frames), built once."""
-        assert not _FUSED_FINALIZE
-        key = "fin%d" % nseg
-        rec = op._tiles.get(key)
-        if rec is None:
-            rec = op._tiles[key] = ops.BnFinRecord(self._tickets(nseg * ((op.y.C + 31) // 32)), gamma, beta, eps, op.y.pixels, *aff)
-        return rec
 
     def _bn_grads(self, op):
         """(dgamma, dbeta) arena views starting at the op's first part (the parts' slots are adjacent: see the arena order)."""
@@ -689,44 +565,20 @@ class TrainPlan:
         gamma, beta, eps, mom = self._bn_params(a)
         x2, raw2, y2 = a.x.pair(), a.yraw.pair(), a.y.pair()
         u_sum, u_sq, _, (scale, shift, mean, invstd) = a.unit
-        in_aff = None
-        if a.norm_src is not None:                              # operand = the producer's RAW output, normalised in LDS
-            prod, c0 = a.norm_src
-            assert c0 == 0 and a.x.C == prod.y.C and not _FUSED_FINALIZE
-            x2, in_aff = prod.yraw.pair(), (prod.unit[3][0], prod.unit[3][1])
-            t = a._tiles.get("fwd_stats2n")
-            if t is None:
-                t = a._tiles["fwd_stats2n"] = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride,
-                                                             self.device, with_stats=True, only=(117, 118))
-        else:
-            t = a._tiles.get("fwd_stats2")
-            if t is None:
-                t = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride, self.device,
-                                   with_stats=True)
-                a._tiles["fwd_stats2"] = t
-        fin = self._fin(a, gamma, beta, eps, (scale, shift, mean, invstd), 2) if CONV_FINALIZE else None
+        t = a._tiles.get("fwd_stats2")
+        if t is None:
+            t = ops.tuned_tile(ops.CONV_FWD, x2.dtype, x2.N, x2.H, x2.W, x2.C, y2.C, a.k, a.stride, self.device,
+                               with_stats=True)
+            a._tiles["fwd_stats2"] = t
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
-                   wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2,
-                   in_affine=in_aff, in_segments=2, fin=fin)
-        if fin is not None:
-            self._apply(a, lambda: ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2))
-        elif _FUSED_FINALIZE:
+                   wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
+        if _FUSED_FINALIZE:
             ops.bn_finalize_apply(u_sum, u_sq, a.y.pixels, gamma, beta, eps, scale, shift, mean, invstd, raw2, y2,
                                   res=None if a.res is None else a.res.pair(), nseg=2)
         else:
             ops.bn_finalize(u_sum, u_sq, a.y.pixels, gamma, beta, eps, mom, None, None, scale, shift, mean, invstd,
                             nseg=2)
-            self._apply(a, lambda: ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2))
-
-    def _apply(self, op, launch):
-        """The BatchNorm.SiLU apply pass of `op`: inline, or — when every reader of the activated output normalises the raw
-        output itself (op.defer_apply) — on the side stream: only the backward pass needs the result."""
-        if op.defer_apply and not self._side_region and not _FUSED_FINALIZE:
-            self._mark("side")
-            launch()
-            self._mark("main", None)
-        else:
-            launch()
+            ops.bn_silu_apply(raw2, scale, shift, y2, res=None if a.res is None else a.res.pair(), nseg=2)
 
     # ---- launch programs ------------------------------------------------------------------------------------
     # Step 1 runs the Python wrappers directly (kernel variants get tuned).  Step 2 runs them again under
@@ -800,33 +652,19 @@ class TrainPlan:
         if k == "conv":
             gamma, beta, eps, mom = self._bn_params(op)
             w = self.cache.conv_weight(op.mod)
-            x, in_aff = op.x, None
-            if op.norm_src is not None:                         # operand = (a channel slice of) the producer's RAW output
-                prod, c0 = op.norm_src
-                assert not _FUSED_FINALIZE
-                x = prod.yraw.slice(c0, op.x.C)
-                in_aff = (prod.aff[0][c0:c0 + op.x.C], prod.aff[1][c0:c0 + op.x.C])
-                t = op._tiles.get("fwd_statsn")
-                if t is None:
-                    t = op._tiles["fwd_statsn"] = ops.tuned_tile(ops.CONV_FWD, x.dtype, x.N, x.H, x.W, x.C, op.y.C, op.k, op.stride,
-                                                                 self.device, with_stats=True, only=(117, 118))
-            else:
-                t = op.tile("fwd_stats")
+            t = op.tile("fwd_stats")
             scale, shift, mean, invstd = op.aff
-            fin = self._fin(op, gamma, beta, eps, op.aff, 1) if CONV_FINALIZE else None
-            ops.conv2d(x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
-                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None, in_affine=in_aff, fin=fin)
+            ops.conv2d(op.x, w, op.yraw, op.k, op.stride, stats=op.stat, tile=t,
+                       wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
-            if fin is not None:
-                self._apply(op, lambda: ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res))
-            elif _FUSED_FINALIZE:
+            if _FUSED_FINALIZE:
                 ops.bn_finalize_apply(op.stat[0], op.stat[1], op.y.pixels, gamma, beta, eps, scale, shift, mean, invstd,
                                       op.yraw, op.y, res=op.res)
             else:
                 ops.bn_finalize(op.stat[0], op.stat[1], op.y.pixels, gamma, beta, eps, mom,
                                 None, None, scale, shift, mean, invstd)
-                self._apply(op, lambda: ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res))
+                ops.bn_silu_apply(op.yraw, scale, shift, op.y, res=op.res)
         elif k == "resize":
             ops.resize_nearest(op.src, op.dst)
         elif k == "spp":
@@ -979,7 +817,11 @@ class TrainPlan:
     # stream, ordered after the main-stream kernels that produced its raw gradient, and the main stream goes
     # straight on to the data gradient of the same layer.
     def _scratch(self, numel):
-        """Next raw-gradient slot of the ring (the current chain first waits for the wgrad that last read it)."""
+        """Next raw-gradient slot of the ring.  A slot's raw gradient has up to three readers: the weight gradient (on a
+        weight-gradient stream) and the data gradient(s) on the chain(s) that produced it; each marks "slot_done" on its own
+        stream behind its launch, and the chain that overwrites the slot next waits ("acquire_cur") for every one of those
+        events that lives on ANOTHER stream — several chains share the ring (head levels 1-2 / the support frame on chain 2),
+        so the next writer is not necessarily on the stream of the previous data gradient."""
         self.ring_i = (self.ring_i + 1) % self.RING
         self._slot = self.ring_i
         self._mark("acquire_cur", self._slot)
@@ -1106,6 +948,7 @@ class TrainPlan:
             ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
                        mode=CONV_DGRAD, accumulate=acca, tile=t,
                        wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
+            self._mark("slot_done", slot)                            # ... and this chain's reader of the slot (see _scratch)
 
     def _conv_pair_backward_split(self, a, b2):
         """Layer i of the two frames as two chains: BatchNorm backward + data gradient of the current frame on stream 0, of the
@@ -1137,6 +980,7 @@ class TrainPlan:
                 ops.conv2d(dyr, self.cache.conv_weight(a.mod, transpose=True), dx, a.k, a.stride, mode=CONV_DGRAD,
                            accumulate=acc, tile=t,
                            wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
+                self._mark("slot_done", slot)                        # this chain's reader of its half of the slot
         self._mark("cur", 0)
 
     def _conv_backward(self, op):
@@ -1152,6 +996,7 @@ class TrainPlan:
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
                        mode=CONV_DGRAD, accumulate=acc, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None)
+            self._mark("slot_done", slot)                            # ... and this chain's reader of the slot (see _scratch)
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, x, targets, iters=2, detail=False):

@@ -76,3 +76,66 @@ def test_tape_api_rejects_misuse(backend):
         with _lib.NativeTape():
             with _lib.NativeTape():
                 pass
+
+
+def _fake_streams(n):
+    """n distinct non-null 'stream handles': the emulator issues nothing on them, the library only compares them."""
+    return [C.c_void_p(0x1000 + 16 * i) for i in range(n)]
+
+
+def test_ring_slot_waits_for_every_reader_on_another_stream(backend):
+    """A raw-gradient ring slot is read by the weight gradient (its own stream) AND by the data gradient(s) on the producing
+    chain(s); the chain that overwrites the slot next must wait for all of them that live on other streams (chains 0 and
+    2 share the ring, and only the weight gradient's event used to guard a slot)."""
+    if not _lib.is_emulator():
+        pytest.skip("event bookkeeping is counted without a device (fake stream handles)")
+    a, b = _views(backend, 2)
+    tape = _lib.NativeTape()
+    with tape:
+        # layer L on chain 2: acquire, produce, wgrad on stream 1, dgrad on chain 2
+        tape.mark("cur", 2); tape.mark("acquire_cur", 3)
+        ops.view_copy(a, b)
+        tape.mark("dep", (2, 1)); tape.mark("cur", 1)
+        ops.view_copy(a, b)
+        tape.mark("slot_done", 3); tape.mark("cur", 2)
+        ops.view_copy(a, b)
+        tape.mark("slot_done", 3)
+        # five layers later chain 0 takes the slot: it must wait for stream 1 AND stream 2
+        tape.mark("cur", 0); tape.mark("acquire_cur", 3)
+        ops.view_copy(a, b)
+        # ... and chain 2 acquiring its part of the same slot waits for stream 1 only (its own dgrad is stream-ordered)
+        tape.mark("cur", 2); tape.mark("acquire_cur", 3)
+        # the next layer's readers start a new set: one event, on stream 1
+        tape.mark("cur", 1); tape.mark("slot_done", 3)
+        tape.mark("cur", 0); tape.mark("acquire_cur", 3)
+    main, side, s2 = _fake_streams(3)
+    tape.replay(main, side, more=[s2])
+    events, waits = tape.counters()
+    # events: dep, slot_done x 2, slot_done = 4; waits: dep 1 + first acquire 0 + chain 0's acquire 2 + chain 2's 1 + last 1
+    assert (events, waits) == (4, 5)
+    tape.replay(main, side, more=[])              # chain 2 folded onto main: its events are same-stream for chain 0
+    events, waits = tape.counters()
+    assert (events, waits) == (4, 1 + 1 + 1 + 1)  # dep, then each acquisition waits for stream 1 only
+    tape.replay(main, None)                       # one stream: nothing to order
+    assert tape.counters() == (0, 0)
+
+
+def test_break_reports_the_stream_the_cursor_really_issues_on(backend):
+    """A snippet recorded while the cursor is on chain 2 runs on the MAIN stream when the replay was given no stream for chain 2
+    (hipGraph capture folds it back): the break must report stream 0 then, not 2."""
+    if not _lib.is_emulator():
+        pytest.skip("needs fake stream handles (emulator)")
+    seen = []
+    tape = _lib.NativeTape()
+    with tape:
+        tape.mark("cur", 2)
+        tape.snippet(lambda: None)
+    main, side, s2 = _fake_streams(3)
+    tape.replay(main, side, on_snippet=lambda f, k: seen.append(k), more=[s2])
+    tape.replay(main, side, on_snippet=lambda f, k: seen.append(k), more=[])
+    assert seen == [2, 0]
+    lib = _lib.lib()
+    t2 = _lib.NativeTape()
+    with t2:
+        assert lib.sy_tape_mark(_lib.TAPE_MARKS["acquire"], -1) != 0              # negative ring slot
+        assert lib.sy_tape_mark(_lib.TAPE_MARKS["acquire_cur"], -1) != 0

@@ -94,7 +94,7 @@ CONFIGS = [
                   "spp_pool": tiny(), "spp_pool_bwd": tiny(), "view_copy": tiny(), "rows_add_f32": tiny(), "pred_grad_fold": tiny()}),
     ("base_again", {}),
 ]
-only = [s for s in args.only.split(",") if s]
+only = [s for s in args.only.replace("+", ",").split(",") if s]
 
 
 def sync():

@@ -17,7 +17,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILIES = {"conv_igemm_kernel": "conv_igemm", "conv3x3_halo": "conv_halo", "conv1x1_stream_kernel": "conv_stream1x1", "conv1x1_tile_kernel": "conv_tile1x1",
+FAMILIES = {"conv_igemm_kernel": "conv_igemm", "conv3x3_halo": "conv_halo", "conv1x1_tile_kernel": "conv_tile1x1",
             "conv_wgrad9_kernel": "conv_wgrad9", "conv_wgrad_tr_kernel": "conv_wgrad", "conv_wgrad_kernel": "conv_wgrad",
             "wgrad_fold_kernel": "wgrad_fold", "bn_silu_bwd_apply": "bn_silu_bwd_apply", "bn_silu_bwd_reduce": "bn_silu_bwd_reduce",
             "bn_silu_apply": "bn_silu_apply", "bn_finalize": "bn_finalize", "fold_replicas": "fold_replicas",

@@ -46,6 +46,6 @@ for s, e, n, q in step:
     fam[key][0] += 1; fam[key][1] += e - s
 for k, (n, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:28]:
     print("%9.3f ms %5d  %s" % (d / 1e6, n, k))
-MFMA_NAMES = ("conv_igemm_kernel", "conv3x3_halo", "conv1x1_tile_kernel", "conv1x1_stream_kernel", "conv_wgrad", "wgrad_fold")
+MFMA_NAMES = ("conv_igemm_kernel", "conv3x3_halo", "conv1x1_tile_kernel", "conv_wgrad", "wgrad_fold")
 mfma = sum(d for k, (n, d) in fam.items() if any(m in k for m in MFMA_NAMES))
-print("MFMA kernels (conv_igemm + conv3x3_halo + conv1x1_tile/stream + conv_wgrad + wgrad_fold) in the last step: %.3f ms  (bench.py roofline.kernel_ms_per_step measures the same set with HIP events)" % (mfma / 1e6))
+print("MFMA kernels (conv_igemm + conv3x3_halo + conv1x1_tile + conv_wgrad + wgrad_fold) in the last step: %.3f ms  (bench.py roofline.kernel_ms_per_step measures the same set with HIP events)" % (mfma / 1e6))
