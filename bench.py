@@ -300,8 +300,8 @@ def main():
             raw = frame.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
             raw = raw.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
             frame = FramePairsU8(raw, None, (args.height, args.width), decimate=2)
-        plan = model._plans.inference(model.backbone, model.head, "on_pipe", frame, owner=model)
-        plan.allow_split_k = bool(args.split_k) and args.dtype != "fp32"       # what StreamingDetector does in the 16-bit modes
+        plan = model._plans.inference(model.backbone, model.head, "on_pipe", frame, owner=model,
+                                      split_k=bool(args.split_k) and args.dtype != "fp32")   # what StreamingDetector does in the 16-bit modes
         graph = None
         n_candidates = None
         if args.candidates == "realistic":

@@ -346,7 +346,7 @@ class InferencePlan:
         # split-K for the deep small-map 3x3 layers of the streaming step (36-72 workgroups at batch 1): opt-in, because the
         # fp32 summation order differs from the single-pass kernel (the facade's off_pipe == chained on_pipe bit-identity is
         # kept on the exact path); StreamingDetector / bench.py --workload stream turn it on for the 16-bit modes
-        self.allow_split_k, self._in_stream, self._splitk_ws = False, False, None
+        self.allow_split_k, self._in_stream, self._splitk_ws, self._ws_grew = False, False, None, False
         b = _Builder(self.dtype, device)
         b.merge_siblings = os.environ.get("STREAMYOLO_MERGE_SIBLINGS", "1") != "0"
         self.b = b
@@ -402,9 +402,17 @@ class InferencePlan:
     def _ensure_tuned(self):
         """Make every tuner decision of the streaming step now: the tuners time dummy launches, which must not land on a tape
         that is being recorded."""
+        need = 0
         for op in self.ops:
             if op.kind == "conv":
-                self._split_decision(op, op.tile("fwd"))
+                dec = self._split_decision(op, op.tile("fwd"))
+                if dec[0] > 1:
+                    need = max(need, dec[0] * op.y.pixels * op.y.C)
+        # the fp32 partial-sum scratch is sized HERE, once, for the largest split decision of the plan: a tape that is being
+        # recorded holds its raw pointer, so it must not be re-allocated in the middle of a recording (ADVICE r03)
+        if need and (self._splitk_ws is None or self._splitk_ws.numel() < need):
+            self._splitk_ws = torch.empty(max(need, 4 << 20), dtype=torch.float32, device=self.device)
+            self._stream_tape = None
 
     # -- execution --------------------------------------------------------------------------------
     def _run_op(self, op):
@@ -414,9 +422,10 @@ class InferencePlan:
             dec = self._split_decision(op, t) if self._in_stream else (1, t)
             if dec[0] > 1:
                 need = dec[0] * op.y.pixels * op.y.C
-                if self._splitk_ws is None or self._splitk_ws.numel() < need:
+                if self._splitk_ws is None or self._splitk_ws.numel() < need:      # (a decision made after _ensure_tuned ran)
                     self._splitk_ws = torch.empty(max(need, 4 << 20), dtype=torch.float32, device=self.device)
-                    self._stream_tape = None                            # recorded pointers are stale
+                    self._stream_tape = None                            # recorded pointers are stale ...
+                    self._ws_grew = True                                # ... and so are those of a recording that is open NOW
                 ops.conv2d_splitk(op.x, w, op.y, op.k, op.stride, scale, shift, self._splitk_ws, dec[0], res=op.res,
                                   epilogue=EPI_SILU, tile=dec[1], wfrag=self.cache.conv_weight_frag(op.mod))
                 return
@@ -544,6 +553,7 @@ class InferencePlan:
             # native tape (csrc/tape.hip): the launches are recorded inside the library and replayed by ONE C call
             self._ensure_tuned()
             tape = _lib.NativeTape()
+            self._ws_grew = False
             with tape:
                 self._rec = tape
                 try:
@@ -551,7 +561,9 @@ class InferencePlan:
                     res = post(out) if post is not None else out
                 finally:
                     self._rec = None
-            self._stream_tape = (sig, post, tape, res)
+            # a scratch buffer re-allocated DURING the recording left launches with the freed pointer on the tape: this call's
+            # results are correct (the wrappers ran with the pointers of their moment), the tape is not kept
+            self._stream_tape = None if self._ws_grew else (sig, post, tape, res)
             return res
         prog[2].replay(ops.stream_of(self.out), None)
         return prog[3]

@@ -83,13 +83,20 @@ class PlanCache:
             self.scratch_gen += 1
         return t
 
-    def inference(self, pafpn, head, mode, x, decode=True, owner=None):
+    def inference(self, pafpn, head, mode, x, decode=True, owner=None, split_k=False):
+        """split_k: the streaming step of this plan may run its deep small-map 3x3 layers as split-K (another fp32 summation
+        order) — part of the key, so the facade's exact on_pipe path never shares a plan object with a StreamingDetector."""
         from ..engine import InferencePlan
         owner = owner if owner is not None else (pafpn if pafpn is not None else head)
         dt = compute_dtype_for(owner, x)
         B, _, H, W = x.shape
-        key = ("inf", mode, B, H, W, dt, str(x.device), decode, pafpn is not None, head is not None)
-        return self.get(key, lambda: InferencePlan(pafpn, head, mode, B, H, W, dt, x.device, decode=decode))
+        key = ("inf", mode, B, H, W, dt, str(x.device), decode, pafpn is not None, head is not None, bool(split_k))
+
+        def build():
+            plan = InferencePlan(pafpn, head, mode, B, H, W, dt, x.device, decode=decode)
+            plan.allow_split_k = bool(split_k)
+            return plan
+        return self.get(key, build)
 
     def clear(self):
         self.plans.clear()

@@ -69,10 +69,10 @@ class StreamingDetector:
         self.num_classes, self.conf_thre, self.nms_thresh = num_classes, conf_thre, nms_thresh
         self._slot = torch.empty((1,) + self.frame_hw + (3,), dtype=torch.uint8, device=self.device)
         self._in = FramePairsU8(self._slot, None, self.canvas, self.decimate)
-        self.plan = model._plans.inference(model.backbone, model.head, "on_pipe", self._in, owner=model)
         # 16-bit speed modes: the deep small-map layers may run as split-K (different fp32 summation order than the facade's
-        # exact path); the fp32 parity mode keeps the single-pass kernels
-        self.plan.allow_split_k = str(dtype) not in ("fp32", "torch.float32") and os.environ.get("STREAMYOLO_STREAM_SPLITK", "1") != "0"
+        # exact path — a plan object of its own); the fp32 parity mode keeps the single-pass kernels
+        split_k = str(dtype) not in ("fp32", "torch.float32") and os.environ.get("STREAMYOLO_STREAM_SPLITK", "1") != "0"
+        self.plan = model._plans.inference(model.backbone, model.head, "on_pipe", self._in, owner=model, split_k=split_k)
         self._first = True
         self._post = lambda out: postprocess_device(out, num_classes, conf_thre, nms_thresh)   # one object: part of the tape key
 

@@ -374,7 +374,8 @@ class TrainPlan:
         self.grads.py = self._py
         self.programs, self._rec, self._param_sig = {}, None, None
         self._side_region = False
-        self.pending = 0                      # forwards of the drop-in autograd node whose backward has not run yet
+        self.pending = 0                      # forwards of an autograd node whose backward has not run yet (+ 1 while a TrainStep
+                                              # holds the plan): the plan cache never evicts (releases) such a plan
 
         # ---- flat gradient arena in parameter layout ------------------------------------------------
         # Parameter order of the arena = model.parameters() order, except that the parts of a merged convolution sit side by
@@ -435,8 +436,8 @@ class TrainPlan:
             self._scratch_gen = self.pool.scratch_gen
 
     def release(self):
-        """Dropped from the plan cache (LRU): free the recorded tapes (they hold raw pointers into buffers that go back to the
-        allocator with this object) and break the plan <-> gradient-space reference cycle so that the buffers are freed NOW,
+        """Dropped from the plan cache (LRU; never while `pending`; calling it twice is harmless): free the recorded tapes (they
+        hold raw pointers into buffers that go back to the allocator with this object) and break the plan <-> gradient-space reference cycle so that the buffers are freed NOW,
         not at some later cyclic-GC pass (measured: without this, cycling through five sizes doubled the allocated memory)."""
         self.programs.clear()
         self.grads.py = None
@@ -1114,12 +1115,18 @@ class _BackboneFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, x, *params):
         ctx.plan = plan
+        ctx.counted = any(ctx.needs_input_grad)         # False under no_grad: no backward will come
+        if ctx.counted:
+            plan.pending += 1
         fused = plan.forward(x)
         return tuple(f.buf.view(f.N, f.H, f.W, f.ld)[..., f.c_off:f.c_off + f.C].permute(0, 3, 1, 2).clone() for f in fused)
 
     @staticmethod
     def backward(ctx, *gouts):
         plan = ctx.plan
+        if ctx.counted:
+            plan.pending = max(0, plan.pending - 1)
+            ctx.counted = False
         arena = plan.backward(None, d_fused=[g.float() for g in gouts]).clone()
         return (None, None) + _arena_views(arena, plan.params)
 
@@ -1131,6 +1138,9 @@ class _HeadFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, labels, support, f0, f1, f2, *params):
         ctx.plan = plan
+        ctx.counted = any(ctx.needs_input_grad)
+        if ctx.counted:
+            plan.pending += 1
         plan.forward((f0, f1, f2))
         out, d_raw = plan.loss(labels, support)
         ctx.d_raw = d_raw
@@ -1141,6 +1151,9 @@ class _HeadFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_stats):
         plan = ctx.plan
+        if ctx.counted:
+            plan.pending = max(0, plan.pending - 1)
+            ctx.counted = False
         arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
         gf = tuple(g.to(plan.tdtype) for g in plan.fused_grads())
         return (None, None, None) + gf + _arena_views(arena, plan.params)
@@ -1218,11 +1231,18 @@ class TrainStep:
                                                     # branch is unguarded (tal_head.py:435), PIPEHead honours use_l1
 
     def _ensure(self, x):
-        if self.plan is None:
-            self.plan = get_train_plan(self.model, x)
-            for p in self.plan.params:
-                p.grad = self.plan.gview[id(p)]
-        return self.plan
+        """The plan of this input size, through the model's plan cache on EVERY step (LRU order stays right, a size change gets
+        its own plan); the step's current plan is pinned (`pending`) so that other users of the cache — the drop-in path at
+        other sizes, a second TrainStep — cannot evict and release it under this one."""
+        plan = get_train_plan(self.model, x)
+        if plan is not self.plan:
+            if self.plan is not None:
+                self.plan.pending = max(0, self.plan.pending - 1)
+            plan.pending += 1
+            self.plan = plan
+            for p in plan.params:
+                p.grad = plan.gview[id(p)]
+        return plan
 
     def _eager(self, x, lab, sup):
         plan = self.plan

@@ -52,6 +52,46 @@ def test_size_switches_reproduce_the_oracle_with_a_bounded_plan_cache(backend, m
     assert len(seen_scratch) == 1                                   # ONE split-K workspace for every size
 
 
+def test_a_train_step_pins_its_plan_against_the_drop_in_paths_evictions(backend, monkeypatch):
+    """TrainStep holds its plan across steps; the drop-in path at OTHER sizes (and the sub-module entry points between
+    their forward and backward) goes through the same bounded cache.  A plan somebody still uses must never be released: here
+    a TrainStep at one size survives the drop-in path cycling through three other sizes with two plans allowed."""
+    from streamyolo_amd.train_engine import TrainStep
+    monkeypatch.setattr(PlanCache, "MAX_TRAIN_PLANS", 2)
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    model = sy.build_model("nano")
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model = model.to(backend).train().set_compute_dtype("fp32")
+    model.head.use_l1 = True
+    H0, W0 = 32, 64
+    x0 = synth_frames(2, H0, W0, seed=40).to(backend)
+    lab0, sup0 = synth_labels(2, H0, W0, cfg.num_classes, num_gt=4, seed=50)
+    t0 = (lab0.to(backend), sup0.to(backend))
+    st = TrainStep(model, graph=False)
+    first = float(st.step(x0, t0)["total_loss"])
+    pinned = st.plan
+    assert pinned.pending == 1
+    for i, (H, W) in enumerate([(64, 64), (32, 96), (64, 96)]):
+        x = synth_frames(2, H, W, seed=41 + i).to(backend)
+        lab, sup = synth_labels(2, H, W, cfg.num_classes, num_gt=4, seed=51 + i)
+        out = model(x, (lab.to(backend), sup.to(backend)))
+        assert any(pl is pinned for pl in model._plans.plans.values()), "the TrainStep's plan was evicted"
+        out["total_loss"].backward()
+    assert pinned.grads.py is not None                                    # not released
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    for _ in range(3):                                                     # direct, recorded, replayed: same loss as the first step
+        model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        again = float(st.step(x0, t0)["total_loss"])
+        assert abs(again - first) / abs(first) < 1e-5
+    assert st.plan is pinned and pinned.pending == 1
+    # a size change moves the pin
+    x1 = synth_frames(2, 64, 64, seed=41).to(backend)
+    lab1, sup1 = synth_labels(2, 64, 64, cfg.num_classes, num_gt=4, seed=51)
+    st.step(x1, (lab1.to(backend), sup1.to(backend)))
+    assert st.plan is not pinned and pinned.pending == 0 and st.plan.pending == 1
+
+
 @pytest.mark.gpu
 def test_multiscale_memory_stays_flat_and_later_plans_build_from_the_tuner_cache(tmp_path, monkeypatch):
     """GPU: cycle through five sizes twice with at most three training plans alive: allocated memory after the second cycle
