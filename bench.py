@@ -131,26 +131,61 @@ def cpu_baseline(args, workload, flops_pair):
             "gflops_effective": n * flops_pair / el / 1e9}
 
 
-def pmc_traffic(workload, args, B):
-    return pmc_traffic_full(workload, args, B)[:2]
-
-
 def pmc_traffic_full(workload, args, B):
     """HBM-side bytes per step of the MFMA kernels from the committed PMC passes of this exact configuration
-    (tools/pmc_traffic.py: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE in separate passes).  PMC collection
-    serialises kernels, so it is not re-run inside the timed bench; null when no matching measurement exists."""
+    (tools/pmc_traffic.py: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE in separate passes).  PMC collection serialises
+    kernels, so it is not re-run inside the timed bench.  A file counts only when it was measured on THIS tree's kernels
+    (`kernel_source_key` = hash of csrc/, VERDICT r03 "weak" #6a): otherwise traffic is null and the stale source is named.
+    -> (bytes or None, source path, commit, note)"""
     import glob
+    from streamyolo_amd import _lib
     if (args.height, args.width) != (600, 960) or args.dtype != "bf16" or B != 8:
-        return None, None, None
+        return None, None, None, "no PMC measurement of this configuration"
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%s_%s.json" % (workload, args.model))))
     if not hits:
-        return None, None, None
+        return None, None, None, "no PMC measurement committed"
     try:
         with open(hits[-1]) as fh:
             d = json.load(fh)
-            return float(d["mfma_kernels_bytes"]), os.path.relpath(hits[-1], ROOT), d.get("commit")
+        src = os.path.relpath(hits[-1], ROOT)
+        if d.get("kernel_source_key") != _lib.kernel_source_key():
+            return None, src, d.get("commit"), "stale: measured on other kernel sources (%.3g bytes there)" % float(d["mfma_kernels_bytes"])
+        return float(d["mfma_kernels_bytes"]), src, d.get("commit"), "measured on this tree's kernels"
     except (OSError, ValueError, KeyError):
-        return None, None, None
+        return None, None, None, "unreadable traffic file"
+
+
+def other_configs(args):
+    """The other BASELINE.json configurations and the exact-fp32 mode of the headline step, each a short run of THIS file in a child
+    process (own plan, own tuner entries; the parent's GPU memory stays allocated — 288 GB), reduced to the figures that matter:
+      configs[4]  StreamYOLO-l, fp16, batch-1 streaming step incl. decode + NMS, realistic candidate count  -> ms / frame
+      configs[1]  StreamYOLO-s, bf16, eval forward (8 pairs and 1 pair per step)                              -> pairs / s
+      exact mode  the headline training step in the fp32 mode (exact-f32 MFMA, peak 157.3 TF/s): the mode whose parity with
+                  the reference is within 1e-3 (tests/test_model_train.py::test_headline_batch_l_8x600x960_exact_mode_vs_oracle)"""
+    runs = {
+        "configs4_stream_l_fp16": ["--workload", "stream", "--model", "l", "--dtype", "fp16", "--candidates", "realistic", "--steps", "200",
+                                   "--warmup", "20", "--u8-input", "1"],
+        "configs1_infer_s_bf16_b8": ["--workload", "infer", "--model", "s", "--dtype", "bf16", "--batch", "8", "--steps", "100", "--warmup", "10"],
+        "configs1_infer_s_bf16_b1": ["--workload", "infer", "--model", "s", "--dtype", "bf16", "--batch", "1", "--steps", "200", "--warmup", "20"],
+        "train_l_exact_fp32": ["--workload", "train", "--model", "l", "--dtype", "fp32", "--batch", "8", "--steps", "5", "--warmup", "3"],
+    }
+    out = {}
+    for name, extra in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--extras", "0",
+               "--height", str(args.height), "--width", str(args.width)] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = d.get("roofline") or {}
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "steps": d["steps"],
+                         "workload": d["config"]["workload"], "nms_candidates": d["config"].get("nms_candidates"),
+                         "roofline_frac": rf.get("frac"), "roofline_peak": rf.get("peak"), "whole_step_frac": rf.get("whole_step_frac")}
+        except (subprocess.SubprocessError, ValueError, KeyError, IndexError, OSError) as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if "value" in out.get("train_l_exact_fp32", {}):
+        out["train_l_exact_fp32"]["parity"] = ("fp32 mode vs the reference: s eval 1.2e-6, l eval 5.2e-4, l 8-pair loss dict 1e-3 / "
+                                               "gradients 1e-2 of their norm (DESIGN.md section 4; the bf16 headline mode: loss 1e-2)")
+    return out
 
 
 # TEST-SUITE ONLY (tests/test_bench_spawn.py): run the launcher / rank / reduction plumbing of this file against the
@@ -175,6 +210,26 @@ def spawn_ranks(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cores() // n)))
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def pin_rank_to_cores(local, world):
+    """One slice of the host cores per rank: a step is ~1500 kernel launches issued by ONE thread per rank, and eight ranks whose
+    launch threads migrate over (or share) the same cores issue more slowly than one does.  The process's allowed cores (affinity
+    mask, capped by the cgroup quota) are cut into `world` contiguous slices; rank `local` stays inside its own.  Returns the
+    cores it was pinned to (None when there are fewer cores than ranks or the platform has no affinity call)."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))[:effective_cores()]
+    per = len(cores) // world
+    if per < 1:
+        return None
+    mine = cores[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(per, int(os.environ.get("OMP_NUM_THREADS", per)))))
+    return mine
 
 
 class _Mark:
@@ -203,6 +258,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    pinned = pin_rank_to_cores(local, world)
     if world > 1 and args.path == "dropin":
         raise SystemExit("bench.py: --path dropin times the single-process boundary; the multi-GPU measurement is the default path "
                          "(the drop-in path under DDP is covered by tests/test_distributed_gloo.py)")
@@ -413,6 +469,26 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant kernels, HIP events on the launch stream (rank 0) -----------------
+    def host_issue(fn, n=5):
+        """Host time to ISSUE one step into empty queues (synchronise, issue, stop the clock before the GPU has finished): median
+        of n.  The loop-level figure of timed() also contains the time the host spends blocked on full hardware queues once it
+        runs a step ahead of the GPU (back-pressure) — at 8 pairs that was most of it (profiles/r04/c_ablate_skeleton.txt: the
+        step's ~1600 launches + stream events issue in 6.6 ms)."""
+        ts = []
+        for _ in range(n):
+            if on_gpu:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        if on_gpu:
+            torch.cuda.synchronize()
+        return sorted(ts)[len(ts) // 2]
+    host_issue_ms = host_issue(step)
+    launches = None
+    if workload == "train" and args.path == "trainstep" and stepper.plan is not None and stepper.plan.programs:
+        launches = sum(prog[1].size()[1] for prog in stepper.plan.programs.values())
+
     roofline = None
     if rank == 0 and on_gpu:
         dominant = None
@@ -438,12 +514,12 @@ def main():
             prof = profile(3)                                   # {kind: ms per step}
         mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad", "conv(pred)", "dgrad(pred)", "wgrad(pred)"))
         ach = flops_pair * B / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
-        traffic, traffic_src, traffic_commit = pmc_traffic_full(workload, args, B)
+        traffic, traffic_src, traffic_commit, traffic_note = pmc_traffic_full(workload, args, B)
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_halo(2)_kernel+conv1x1_tile_kernel" +
                     ("+conv_wgrad_tr_kernel+conv_wgrad9_kernel(+wgrad_fold)" if workload == "train" else ""),
                     "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_unit": "bytes/step (MFMA kernels)",
-                    "traffic_source": traffic_src, "traffic_commit": traffic_commit,
+                    "traffic_source": traffic_src, "traffic_commit": traffic_commit, "traffic_note": traffic_note,
                     "flops_per_step": flops_pair * B, "kernel_ms_per_step": mfma_ms,
                     "per_kind_ms": {k: round(v, 4) for k, v in prof.items()},
                     "dominant": dominant,
@@ -461,7 +537,7 @@ def main():
             out = model(x, (lab, sup))
             out["total_loss"].backward()
         el, hst, _ = timed(dropin_step, kw, ks)
-        extras["dropin"] = {"ms_per_step": el / ks * 1e3, "value": B * ks / el, "steps": ks, "host_launch_ms_per_step": round(hst, 3),
+        extras["dropin"] = {"ms_per_step": el / ks * 1e3, "value": B * ks / el, "steps": ks, "host_issue_ms_per_step": round(host_issue(dropin_step), 3),
                             "what": "model(x, targets)['total_loss'].backward() — the unchanged trainer's call sequence "
                                     "(exps/train_utils/double_trainer.py:107-114) through train_forward's autograd.Function"}
         if B == 8 and not args.u8_input:
@@ -469,9 +545,11 @@ def main():
             st4 = TrainStep(model, world_size=1, process_group=None, graph=False)
             el, hst, _ = timed(lambda: st4.step(x4, (lab4, sup4)), kw + 2, ks)
             extras["per_gpu_batch_4"] = {"ms_per_step": el / ks * 1e3, "value": 4 * ks / el, "steps": ks,
-                                         "host_launch_ms_per_step": round(hst, 3),
+                                         "host_issue_ms_per_step": round(host_issue(lambda: st4.step(x4, (lab4, sup4))), 3),
                                          "what": "same step at 4 frame pairs / GPU: BASELINE.json configs[3] (global batch 32 on 8 "
                                                  "GPUs) per-GPU load, the 1-GPU denominator of its weak-scaling efficiency"}
+        if not EMU_SELFTEST and args.model == "l" and B == 8 and args.dtype == "bf16" and (args.height, args.width) == (600, 960):
+            extras["other_configs"] = other_configs(args)
 
     if workload == "stream" and world == 1 and args.extras and plan.allow_split_k:
         # the same step with every layer on its single-pass kernel: what split-K buys at batch 1 (same process, same box)
@@ -499,9 +577,16 @@ def main():
     comm = None
     if workload == "train" and world > 1 and stepper.plan is not None:
         pl = stepper.plan
+        exposed = stepper.exposed_allreduce()
         comm = {"backend": "gloo (emulator self-test)" if EMU_SELFTEST else "nccl (RCCL over xGMI)",
-                "allreduce_bytes_per_step": int(pl.arena.numel()) * 4, "buckets": len(pl.buckets),
+                "grad_comm_dtype": "bf16" if stepper.comm_bf16 else "fp32",
+                "allreduce_bytes_per_step": int(pl.arena.numel()) * (2 if stepper.comm_bf16 else 4), "buckets": len(pl.buckets),
+                "bucket_bytes": [(hi - lo) * (2 if stepper.comm_bf16 else 4) for lo, hi, _ in pl.buckets],
+                "bucket_order": "all-reduces start back to front (head first); bucket 0 (stem / dark2 / dark3) is final last and is the small one",
                 "buckets_overlapped_with_backward": int(getattr(stepper, "last_overlapped", 0)),
+                "exposed_allreduce_ms": None if exposed is None else round(exposed, 4),
+                "exposed_note": "last timed step, rank 0: end of backward -> end of the gradient exchange incl. averaging (what backward did not hide)",
+                "rank_cores": pinned,
                 "rank_ms_per_step": [round(v, 4) for v in rank_ms]}
 
     cpu = None
@@ -515,11 +600,12 @@ def main():
             "value": value, "unit": "frames/s" if workload == "stream" else "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "step_ms": step_stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic" if not EMU_SELFTEST else "synthetic (SIMT-EMULATOR SELF-TEST on CPU: NOT a measurement)",
-            "config": {"workload": "StreamYOLO-%s %dx%d %s, %d frame pairs/GPU/step, %s"
+            "config": {"workload": "StreamYOLO-%s %dx%d %s, %d %s/GPU/step, %s"
                                    % (args.model, args.height, args.width,
                                       "training step: dual-frame forward + TAL loss + backward" if workload == "train"
                                       else ("streaming on_pipe forward + decode + NMS (conf 0.01, IoU 0.65)" if workload == "stream"
                                             else "eval forward off_pipe + decode"), B,
+                                      "frame(s)" if workload == "stream" else "frame pairs",
                                       "random-init synthetic weights (utils/synth.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "hipgraph": bool(args.train_graph if workload == "train" else args.graph == 1),
@@ -532,7 +618,11 @@ def main():
                                           if args.candidates == "all" else
                                           "%d of %d anchors pass conf 0.01 (objectness bias calibrated to ~1 %%, as a trained "
                                           "checkpoint)" % (n_candidates, plan.A)) if workload == "stream" else None,
-                       "host_launch_ms_per_step": round(host_ms, 3)},
+                       "launches_per_step": launches,
+                       "host_issue_ms_per_step": round(host_issue_ms, 3),
+                       "host_loop_ms_per_step": round(host_ms, 3),
+                       "host_note": "host_issue = one step issued into empty queues (median of 5); host_loop = per step inside the "
+                                    "timed loop, which includes blocking on full hardware queues while the GPU is the bottleneck"},
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras, "comm": comm,
         }
         print(json.dumps(line))

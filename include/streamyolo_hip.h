@@ -162,6 +162,14 @@ SY_API int sy_resize_nearest(const void* in, int N, int Hi, int Wi, int C, int l
 SY_API int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, void* argmax, int dtype,
                        void* stream);
 
+/* The head's output transform as a stand-alone in-place pass over out [B, A, 5+nc] fp32 (anchors level-major, row-major):
+ * flags & 1: boxes (xy + grid) * stride, exp(wh) * stride — TALHead.decode_outputs (exps/model/tal_head.py:245-260), what
+ * tools/eval.py:187-188 calls when the head ran with decode_in_inference = False; flags & 2: sigmoid of the objectness column
+ * (tal_head.py:197-199 applies it in both modes).  level_h / level_w / level_stride: HOST arrays of nlevels (<= 8) entries
+ * (copied into the launch by value), sum h*w == A. */
+SY_API int sy_head_decode(float* out, int B, int A, int nch, const int32_t* level_h, const int32_t* level_w,
+                          const float* level_stride, int nlevels, int flags, void* stream);
+
 /* Box decode + confidence filter + class-aware greedy NMS for a batch of images.
  * pred: [B, A, 5+nc] fp32 (cx,cy,w,h,obj,cls...) as produced by the head (tal_head.py:245-260).
  * Outputs per image i: out_count[i] kept detections; out_det[i][k][0..6] = x1,y1,x2,y2,obj,

@@ -98,6 +98,7 @@ SIGNATURES = {
     "sy_spp_pool": (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _I, _P]),
     "sy_spp_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _I, _P]),
     "sy_postprocess_workspace_bytes": (_L, [_I, _I]),
+    "sy_head_decode": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
     "sy_postprocess": (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
     "sy_sgd_ema_step": (_I, [_P, _I, _I, _F, _F, _F, _F, _I, _P]),
     "sy_pack_weights": (_I, [_P, _I, _I, _P]),
@@ -299,6 +300,19 @@ class NativeTape:
                 self.handle = None
         except Exception:
             pass
+
+
+def kernel_source_key():
+    """Hash of the kernel sources (csrc/*.hip, *.h) of this checkout: stamps everything measured on a particular build — the
+    tuner's persisted choices (ops._TuneStore) and the PMC traffic files bench.py quotes (tools/pmc_traffic.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for fn in sorted(os.listdir(src)) if os.path.isdir(src) else []:
+        if fn.endswith((".hip", ".h")):
+            with open(os.path.join(src, fn), "rb") as f:
+                h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def use_library(path):

@@ -262,7 +262,54 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(const float* p
     }
 }
 
+// ---- sy_head_decode: the head's box decode / objectness sigmoid as a stand-alone pass over [B, A, 5+nc] -------------------------
+struct DecodeLevels {
+    int n;
+    int a0[8], w[8];          // first anchor of the level, its grid width
+    float stride[8];
+};
+
+__global__ __launch_bounds__(256) void head_decode_kernel(float* out, int B, int A, int nch, DecodeLevels L, int flags) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * A) return;
+    const int a = (int)(i % A);
+    float* r = out + i * nch;
+    if (flags & 1) {
+        int l = 0;
+        while (l + 1 < L.n && a >= L.a0[l + 1]) ++l;
+        const int k = a - L.a0[l];
+        const float gx = (float)(k % L.w[l]), gy = (float)(k / L.w[l]), st = L.stride[l];
+        // (xy + grid) * stride, exp(wh) * stride: the reference's two statements, each rounded once (no contraction: -ffp-contract=off)
+        r[0] = (r[0] + gx) * st;
+        r[1] = (r[1] + gy) * st;
+        r[2] = expf(r[2]) * st;
+        r[3] = expf(r[3]) * st;
+    }
+    if (flags & 2) r[4] = 1.0f / (1.0f + expf(-r[4]));
+}
+
 }  // namespace
+
+extern "C" int sy_head_decode(float* out, int B, int A, int nch, const int32_t* level_h, const int32_t* level_w,
+                              const float* level_stride, int nlevels, int flags, void* stream) {
+    if (out == nullptr || B <= 0 || A <= 0 || nch < 5 || (flags & ~3) != 0) return SY_ERR_ARG;
+    DecodeLevels L;
+    L.n = 0;
+    if (flags & 1) {
+        if (level_h == nullptr || level_w == nullptr || level_stride == nullptr || nlevels < 1 || nlevels > 8) return SY_ERR_ARG;
+        int a0 = 0;
+        for (int l = 0; l < nlevels; ++l) {
+            if (level_h[l] <= 0 || level_w[l] <= 0) return SY_ERR_ARG;
+            L.a0[l] = a0; L.w[l] = level_w[l]; L.stride[l] = level_stride[l];
+            a0 += level_h[l] * level_w[l];
+        }
+        if (a0 != A) return SY_ERR_ARG;
+        L.n = nlevels;
+    }
+    const long long n = (long long)B * A;
+    SY_LAUNCH(head_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, B, A, nch, L, flags);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
 
 extern "C" int64_t sy_postprocess_workspace_bytes(int B, int A) {
     if (B <= 0 || A <= 0) return 0;

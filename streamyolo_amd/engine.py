@@ -571,7 +571,7 @@ class InferencePlan:
     def export_buffer(self):
         """The current frame's PRE-fusion PAN outputs as NCHW-shaped (channels-last memory) tensors:
         what the reference returns as `buffer_` (dfp_pafpn.py:226) and takes back next frame."""
-        return tuple(p.buf.clone().permute(0, 3, 1, 2) for p in self.cur_pans)
+        return tuple(p.export() for p in self.cur_pans)
 
     def run_head(self):
         head = self.ops[self.n_backbone_ops:]
@@ -579,7 +579,7 @@ class InferencePlan:
             self._run_op(op)
         if not self.decode:
             # decode_in_inference=False (tal_head.py:220-223): boxes stay raw, obj/cls are still sigmoids
-            self.out[..., 4].sigmoid_()
+            ops.head_decode(self.out, boxes=False, obj_sigmoid=True)
         return self.out
 
     def run(self, x, buffer=None):

@@ -53,12 +53,12 @@ class DFPPAFPN(nn.Module):
             assert input.size()[1] == 6
             plan = self._plans.inference(self, None, "off_pipe", input)
             fused = plan.run_backbone(input)
-            return tuple(f.buf.clone().permute(0, 3, 1, 2) for f in fused)
+            return tuple(f.export() for f in fused)
         elif mode == "on_pipe":
             if buffer is not None:
                 assert len(buffer) == 3
                 assert input.size()[1] == 3
             plan = self._plans.inference(self, None, "on_pipe", input)
             fused = plan.run_backbone(input, buffer)
-            return tuple(f.buf.clone().permute(0, 3, 1, 2) for f in fused), plan.export_buffer()
+            return tuple(f.export() for f in fused), plan.export_buffer()
         raise AssertionError(mode)

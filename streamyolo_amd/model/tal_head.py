@@ -70,16 +70,13 @@ class TALHead(nn.Module):
         return out.clone().to(x0.dtype if x0.dtype.is_floating_point else torch.float32)
 
     def decode_outputs(self, outputs, dtype):
-        """(xy + grid) * stride, exp(wh) * stride on a [B, A, 5+nc] tensor, in place
-        (tal_head.py:245-260; used by tools/eval.py when decode_in_inference is False)."""
-        grids, strides = [], []
-        for (hsize, wsize), stride in zip(self.hw, self.strides):
-            yv, xv = torch.meshgrid(torch.arange(hsize), torch.arange(wsize), indexing="ij")
-            grid = torch.stack((xv, yv), 2).view(1, -1, 2)
-            grids.append(grid)
-            strides.append(torch.full((1, grid.shape[1], 1), stride))
-        grids = torch.cat(grids, dim=1).to(outputs)
-        strides = torch.cat(strides, dim=1).to(outputs)
-        outputs[..., :2] = (outputs[..., :2] + grids) * strides
-        outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * strides
+        """(xy + grid) * stride, exp(wh) * stride on a [B, A, 5+nc] tensor (tal_head.py:245-260; used by tools/eval.py:187-188
+        when decode_in_inference is False): one sy_head_decode launch on the fp32 tensor; a 16-bit tensor (model.half()) is
+        widened for it and rounded back once."""
+        from .. import ops
+        if outputs.dtype == torch.float32 and outputs.is_contiguous():
+            return ops.head_decode(outputs, self.hw, self.strides)
+        wide = outputs.float().contiguous()
+        ops.head_decode(wide, self.hw, self.strides)
+        outputs.copy_(wide)
         return outputs

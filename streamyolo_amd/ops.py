@@ -83,6 +83,14 @@ class View:
         assert n0 == 0 and full.shape[0] == 2 * self.N
         return View(full, 2 * self.N, self.H, self.W, self.C, self.ld, self.c_off, self.bs_)
 
+    def export(self):
+        """A COPY of the view as an NCHW-shaped tensor in the storage dtype (channels-last memory): what the drop-in modules hand
+        back to their caller.  Honours the view's channel slice and row pitch — a fused feature that lives inside a wider
+        concatenation buffer exports only its own channels."""
+        assert self.bs_ is None
+        return self.buf.view(self.N, self.H, self.W, self.ld)[..., self.c_off:self.c_off + self.C] \
+            .clone(memory_format=torch.contiguous_format).permute(0, 3, 1, 2)
+
     def nchw(self):
         """Float32 NCHW copy (tests / debugging only)."""
         return self.buf.view(self.N, self.H, self.W, self.ld)[..., self.c_off:self.c_off + self.C] \
@@ -365,6 +373,23 @@ def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 
+def head_decode(out, hw=None, strides=None, boxes=True, obj_sigmoid=False):
+    """sy_head_decode in place on out [B, A, 5+nc] fp32 contiguous: boxes -> (xy + grid) * stride, exp(wh) * stride over the
+    levels hw = [(h, w)] with `strides`; obj_sigmoid -> sigmoid of column 4."""
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.dim() == 3
+    B, A, nch = out.shape
+    flags = (1 if boxes else 0) | (2 if obj_sigmoid else 0)
+    if boxes:
+        n = len(hw)
+        lh = (C.c_int32 * n)(*[int(h) for h, _ in hw])
+        lw = (C.c_int32 * n)(*[int(w) for _, w in hw])
+        ls = (C.c_float * n)(*[float(s) for s in strides])
+    else:
+        n, lh, lw, ls = 0, None, None, None
+    check(_lib.lib().sy_head_decode(out.data_ptr(), B, A, nch, lh, lw, ls, n, flags, stream_of(out)), "sy_head_decode")
+    return out
+
+
 class PostprocessWorkspace:
     """Device buffers reused across sy_postprocess calls for a given (B, A)."""
 
@@ -453,13 +478,8 @@ class _TuneStore:
 
     def _source_key(self, device):
         import hashlib
-        here = _os.path.dirname(_os.path.abspath(__file__))
         h = hashlib.sha256()
-        src = _os.path.join(here, "csrc")
-        for fn in sorted(_os.listdir(src)) if _os.path.isdir(src) else []:
-            if fn.endswith((".hip", ".h")):
-                with open(_os.path.join(src, fn), "rb") as f:
-                    h.update(fn.encode() + b"\0" + f.read())
+        h.update(_lib.kernel_source_key().encode())
         h.update(_lib.lib().sy_version())
         h.update(repr((HALO_TILES, HALO_S2_TILES, TILE_1X1K, WGRAD_EXTRA)).encode())          # candidate-set switches (A/B runs)
         # (no device name in the key: this library is gfx950-only, and torch reports an empty name under rocprofv3 — a profiled

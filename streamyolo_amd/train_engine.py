@@ -720,6 +720,10 @@ class TrainPlan:
     # for each, the position of the backward walk after which every gradient in the range is final; the walk emits
     # a "bucket" mark there and TrainStep starts that range's RCCL all-reduce while the rest of backward still runs.
     BUCKET_BYTES = 32 << 20
+    # The bucket at the FRONT of the arena (stem, dark2, dark3: the parameters whose gradients the backward walk finishes last)
+    # is the one whose all-reduce nothing can hide — everything behind it overlaps with the rest of backward — so it is kept
+    # small: a ring all-reduce of a few MB over xGMI is latency-bound (tens of microseconds), one of 32 MB is not.
+    FIRST_BUCKET_BYTES = 4 << 20
 
     def _backward_sequence(self):
         nf = self.n_frame_ops
@@ -740,7 +744,7 @@ class TrainPlan:
         for p in self.params:
             o += p.numel()
             ready = max(ready, last.get(id(p), -1))
-            if (o - lo) * 4 >= self.BUCKET_BYTES:
+            if (o - lo) * 4 >= (self.BUCKET_BYTES if self.buckets else min(self.FIRST_BUCKET_BYTES, self.BUCKET_BYTES)):
                 self.buckets.append((lo, o, ready))
                 lo, ready = o, -1
         if o > lo:
@@ -1119,7 +1123,7 @@ class _BackboneFunction(torch.autograd.Function):
         if ctx.counted:
             plan.pending += 1
         fused = plan.forward(x)
-        return tuple(f.buf.view(f.N, f.H, f.W, f.ld)[..., f.c_off:f.c_off + f.C].permute(0, 3, 1, 2).clone() for f in fused)
+        return tuple(f.export() for f in fused)
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -1216,8 +1220,17 @@ class TrainStep:
     """Sync-free training step for bench.py / a native trainer: forward + loss + backward (+ one RCCL
     all-reduce of the flat gradient arena when world_size > 1); parameters' .grad are arena views."""
 
-    def __init__(self, model, world_size=1, process_group=None, graph=None):
+    def __init__(self, model, world_size=1, process_group=None, graph=None, grad_comm_dtype=None):
+        """grad_comm_dtype: None / "fp32" = all-reduce the fp32 gradient arena as it is (what the reference's DDP does);
+        "bf16" (or STREAMYOLO_GRAD_COMM=bf16) = opt-in gradient compression: every bucket is rounded to bf16 into a persistent
+        communication buffer, reduced there (half the bytes over xGMI) and widened back into the arena — SURVEY.md 8(e)."""
         self.model, self.world, self.dist = model, world_size, process_group
+        gc_ = grad_comm_dtype if grad_comm_dtype is not None else os.environ.get("STREAMYOLO_GRAD_COMM", "fp32")
+        assert gc_ in ("fp32", "bf16"), gc_
+        self.comm_bf16 = gc_ == "bf16"
+        self._comm16 = None                         # bf16 mirror of the arena (grad_comm_dtype="bf16")
+        self._t_bwd_end, self._t_comm_end = None, None
+        self.exposed_allreduce_ms = None            # of the last step: all-reduce time NOT hidden behind backward
         self.plan = None
         # optional hipGraph replay of forward + loss + backward (STREAMYOLO_GRAPH=1 / graph=True).  Off by default:
         # on ROCm 7 replaying this ~1500-node graph costs MORE host time than the launch tapes (measured, DESIGN.md)
@@ -1287,19 +1300,47 @@ class TrainStep:
         if self.world > 1:
             # buckets whose all-reduce was not started during backward (the first two steps run the Python
             # wrappers / record the tape) go out now; then wait for all of them and average
-            for k, (lo, hi, _) in enumerate(plan.buckets):
+            cuda = plan.device.type == "cuda"
+            if cuda:
+                if self._t_bwd_end is None:
+                    self._t_bwd_end, self._t_comm_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self._t_bwd_end.record()                        # backward (all chains joined) is complete here on the main stream
+            t_host = __import__("time").perf_counter()
+            for k in range(len(plan.buckets)):
                 if k not in self._reduced:
-                    self._works.append(self.dist.all_reduce(plan.arena[lo:hi], async_op=True))
+                    self._reduce_bucket(k, None, None)
             for w in self._works:
-                w.wait()
-            plan.arena.div_(self.world)
+                w.wait()                                        # (cuda: the current stream waits for the collective)
+            if self.comm_bf16:
+                for lo, hi, _ in plan.buckets:                  # widen the reduced bf16 buckets back into the fp32 arena, averaged
+                    torch.div(self._comm16[lo:hi], self.world, out=plan.arena[lo:hi])
+            else:
+                plan.arena.div_(self.world)
+            if cuda:
+                self._t_comm_end.record()
+                self._exposed_pending = True                    # read lazily (exposed_allreduce): no synchronisation in the step
+            else:
+                self.exposed_allreduce_ms = (__import__("time").perf_counter() - t_host) * 1e3
         return out
+
+    def exposed_allreduce(self):
+        """ms of the last step between the end of backward and the end of the gradient exchange (all-reduce tail + averaging): the
+        part of the communication that backward did not hide.  Synchronises."""
+        if getattr(self, "_exposed_pending", False):
+            self._t_comm_end.synchronize()
+            self.exposed_allreduce_ms = self._t_bwd_end.elapsed_time(self._t_comm_end)
+            self._exposed_pending = False
+        return self.exposed_allreduce_ms
 
     def _reduce_bucket(self, k, main, side):
         """Start the RCCL all-reduce of gradient bucket k (its gradients are final on `main` and `side`); the
         collective runs beside the rest of the backward pass."""
         lo, hi, _ = self.plan.buckets[k]
         view = self.plan.arena[lo:hi]
+        if self.comm_bf16:
+            if self._comm16 is None or self._comm16.numel() != self.plan.arena.numel():
+                self._comm16 = torch.empty(self.plan.arena.numel(), dtype=torch.bfloat16, device=self.plan.device)
+            src, view = view, self._comm16[lo:hi]
         if main is not None:
             if self.comm is None:
                 self.comm = torch.cuda.Stream(device=self.plan.device)
@@ -1308,8 +1349,12 @@ class TrainStep:
                 if s_ is not None:
                     self.comm.wait_stream(s_)
             with torch.cuda.stream(self.comm):
+                if self.comm_bf16:
+                    view.copy_(src)                             # fp32 -> bf16 (round to nearest even) on the communication stream
                 self._works.append(self.dist.all_reduce(view, async_op=True))
         else:
+            if self.comm_bf16:
+                view.copy_(src)
             self._works.append(self.dist.all_reduce(view, async_op=True))
         self._reduced.add(k)
 

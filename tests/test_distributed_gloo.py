@@ -50,15 +50,27 @@ def _worker(rank, world, port, emu_lib, out_dir):
     # inside the backward walk (small buckets here so that several are in flight).
     from streamyolo_amd import train_engine
     train_engine.TrainPlan.BUCKET_BYTES = 256 << 10
+    train_engine.TrainPlan.FIRST_BUCKET_BYTES = 32 << 10
     m = fresh()
     st = TrainStep(m, world_size=world, process_group=dist)
     fasts = []
     for _ in range(3):
         m.load_state_dict(sd, strict=True)
         st.step(x, (lab, sup))
-        fasts.append((st.plan.arena.clone(), len(st._reduced)))
+        fasts.append((st.plan.arena.clone(), st.last_overlapped))
     fast = fasts[0][0]
     assert len(st.plan.buckets) >= 3 and fasts[0][1] == 0 and fasts[2][1] == len(st.plan.buckets)
+    # bucket layout: contiguous cover of the arena in parameter order; the FRONT bucket — stem / dark2, final at the very end of
+    # the backward walk, the only all-reduce nothing hides — is the small one; readiness moves towards the end of the walk as the
+    # buckets move towards the front of the arena
+    bk = st.plan.buckets
+    assert bk[0][0] == 0 and bk[-1][1] == st.plan.arena.numel() and all(bk[i][1] == bk[i + 1][0] for i in range(len(bk) - 1))
+    sizes = [(hi - lo) * 4 for lo, hi, _ in bk]
+    assert sizes[0] < train_engine.TrainPlan.BUCKET_BYTES and max(sizes[1:-1]) >= train_engine.TrainPlan.BUCKET_BYTES
+    assert sizes[0] <= min(sizes[1:-1])
+    ready = [r for _, _, r in bk]
+    assert ready[0] == max(ready) and all(ready[i] >= ready[i + 1] for i in range(len(ready) - 1))
+    assert st.exposed_allreduce() is not None and st.exposed_allreduce() >= 0.0
 
     # local (un-reduced) gradients of this rank, for the expected mean
     m1 = fresh()
@@ -70,6 +82,17 @@ def _worker(rank, world, port, emu_lib, out_dir):
     mean = sum(gathered) / world
     err_fast = max(float((f - mean).abs().max() / mean.abs().max()) for f, _ in fasts)
 
+    # (a') opt-in gradient compression: buckets rounded to bf16 for the exchange (half the bytes), widened back, averaged
+    m3 = fresh()
+    st16 = TrainStep(m3, world_size=world, process_group=dist, grad_comm_dtype="bf16")
+    errs16 = []
+    for _ in range(3):
+        m3.load_state_dict(sd, strict=True)
+        st16.step(x, (lab, sup))
+        errs16.append(float((st16.plan.arena - mean).abs().max() / mean.abs().max()))
+    assert st16._comm16 is not None and st16._comm16.dtype == torch.bfloat16 and st16.last_overlapped == len(st16.plan.buckets)
+    err_bf16 = max(errs16)
+
     # (b) drop-in path under DDP
     m2 = fresh()
     ddp = torch.nn.parallel.DistributedDataParallel(m2, broadcast_buffers=False)
@@ -80,7 +103,7 @@ def _worker(rank, world, port, emu_lib, out_dir):
     named2 = dict(m2.named_parameters())
     flat = torch.cat([named2[name_of[id(p)]].grad.reshape(-1) for p in s1.plan.params])
     err_ddp = float((flat - mean).abs().max() / mean.abs().max())
-    torch.save({"err_fast": err_fast, "err_ddp": err_ddp, "nonzero": bool(mean.abs().max() > 0)},
+    torch.save({"err_fast": err_fast, "err_ddp": err_ddp, "err_bf16": err_bf16, "nonzero": bool(mean.abs().max() > 0)},
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -96,6 +119,7 @@ def test_two_rank_gradient_allreduce_and_ddp(tmp_path):
         assert res["nonzero"]
         assert res["err_fast"] < 1e-5, res
         assert res["err_ddp"] < 1e-5, res
+        assert 1e-6 < res["err_bf16"] < 1.5e-2, res            # bf16 rounding of each rank's gradient (2^-9 relative), not more
 
 
 @pytest.mark.gpu
@@ -145,7 +169,7 @@ def test_bucketed_allreduce_streams_on_gpu_single_rank_rccl(golden_dir):
                 torch.cuda.synchronize()
                 err = float((st.plan.arena - 0.5 * local).abs().max() / local.abs().max())
                 assert err < 1e-4, (i, err)
-            assert len(st.plan.buckets) >= 3 and len(st._reduced) == len(st.plan.buckets)
+            assert len(st.plan.buckets) >= 3 and st.last_overlapped == len(st.plan.buckets)
         finally:
             train_engine.TrainPlan.BUCKET_BYTES = old
     finally:

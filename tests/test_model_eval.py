@@ -111,6 +111,29 @@ def test_three_channel_input_is_duplicated(backend):
     assert _rel(out.cpu(), ref) < 1e-3
 
 
+def test_decode_outputs_after_an_undecoded_forward_equals_the_decoding_forward(backend):
+    """tools/eval.py:187-188: with `decode_in_inference = False` the head returns raw boxes (obj / cls already sigmoids) and the
+    caller applies `head.decode_outputs` afterwards — sy_head_decode, one launch — which must give the decoding forward's
+    tensor; the fused features a DFPPAFPN returns are copies of exactly their own channels (View.export)."""
+    m, sd, cfg = _model("nano", backend)
+    m.set_compute_dtype("fp32")
+    x = synth_frames(2, 64, 96, seed=2).to(backend)
+    with torch.no_grad():
+        want = m(x).clone()
+        m.head.decode_in_inference = False
+        raw = m(x).clone()
+        assert _rel(raw[..., 4:].cpu(), want[..., 4:].cpu()) < 1e-6               # sigmoids in both modes
+        assert float((raw[..., :4] - want[..., :4]).abs().max()) > 1.0           # ... boxes are not decoded yet
+        got = m.head.decode_outputs(raw, raw.dtype)
+        m.head.decode_in_inference = True
+        feats = m.backbone(x)
+    assert _rel(got.cpu(), want.cpu()) < 1e-6
+    half = m.head.decode_outputs(raw.clone().half() * 0 + want.new_zeros(()).half(), torch.float16)   # 16-bit tensors: widened, rounded back once
+    assert half.dtype == torch.float16 and bool(torch.isfinite(half).all())
+    for f, c in zip(feats, (int(256 * cfg.width), int(512 * cfg.width), int(1024 * cfg.width))):
+        assert f.shape[1] == c and f.permute(0, 2, 3, 1).is_contiguous()
+
+
 def test_postprocess_dropin_on_reference_decoded(backend, golden_dir):
     z = np.load(os.path.join(golden_dir, "nano_eval_2x64x96.npz"))
     dec = torch.from_numpy(z["decoded"]).to(backend)

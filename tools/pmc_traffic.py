@@ -72,7 +72,9 @@ def main():
             commit = open(os.path.join(ROOT, "tools", ".head_commit")).read().strip()
         except OSError:
             commit = None
-    res = {"commit": commit, "bench_args": bench_args, "units": "bytes per step", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950)",
+    sys.path.insert(0, ROOT)
+    from streamyolo_amd import _lib
+    res = {"commit": commit, "kernel_source_key": _lib.kernel_source_key(), "bench_args": bench_args, "units": "bytes per step", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950)",
            "write_correction": "WRITE_SIZE KiB x 1024 (uncalibrated)", "families": {}}
     with tempfile.TemporaryDirectory(dir="/tmp") as wd:
         for counter, scale, key in (("FETCH_SIZE", 2048.0, "read"), ("WRITE_SIZE", 1024.0, "write")):
@@ -86,7 +88,7 @@ def main():
     res["total_read"] = sum(f["read"] for f in res["families"].values())
     res["total_write"] = sum(f["write"] for f in res["families"].values())
     mf = [res["families"].get(k, {"read": 0, "write": 0})
-          for k in ("conv_igemm", "conv_halo", "conv_stream1x1", "conv_tile1x1", "conv_wgrad", "conv_wgrad9", "wgrad_fold")]
+          for k in ("conv_igemm", "conv_halo", "conv_tile1x1", "conv_wgrad", "conv_wgrad9", "wgrad_fold")]
     res["mfma_kernels_bytes"] = sum(f["read"] + f["write"] for f in mf)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as fh:
