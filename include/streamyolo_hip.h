@@ -290,7 +290,9 @@ SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda
  * raw [B, A, 5+nc] fp32 raw head logits (reg4, obj, cls); labels/support [B, max_labels, 5] fp32 rows
  * (cls, cx, cy, w, h) zero padded; level_h/w/stride describe the anchor grid (level-major, row-major).
  * Outputs: d_raw [B, A, 5+nc] = d total_loss / d raw; losses[8] = total, 5*iou, l1, conf, cls,
- * num_fg/num_gt, num_fg, num_gt (device); optional fg_mask [B, A] int32.
+ * num_fg/num_gt, num_fg, num_gt (device); optional fg_mask [B, A] int32; optional d_pad [B, A, 16] in `pad_dtype` (SY_DT_*,
+ * num_classes <= 8): the same gradient as columns [reg 4 | obj | 5..7 untouched | cls nc | rest untouched] — the operand layout
+ * of the prediction convolutions' data / weight gradients, so that no repacking pass stands between the loss and the backward.
  * Replaces TALHead.get_losses / get_assignments / dynamic_k_matching (exps/model/tal_head.py:262-712)
  * and autograd's backward over them. */
 SY_API int64_t sy_tal_loss_workspace_bytes(int B, int A, int max_gt);
@@ -298,7 +300,7 @@ SY_API int sy_tal_loss(const float* raw, int B, int A, int num_classes, const fl
                        const float* support, int max_labels, const int32_t* level_h,
                        const int32_t* level_w, const float* level_stride, int nlevels, float gamma,
                        float ignore_thr, float ignore_value, int use_l1, float* d_raw, float* losses,
-                       int32_t* fg_mask, void* workspace, void* stream);
+                       int32_t* fg_mask, void* workspace, void* d_pad, int pad_dtype, void* stream);
 
 /* elementwise helpers on views: out (+)= in */
 SY_API int sy_view_copy(const void* in, int ldi, void* out, int ldo, int64_t pixels, int C, int dtype,

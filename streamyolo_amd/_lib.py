@@ -109,7 +109,7 @@ SIGNATURES = {
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
-    "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P]),
+    "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _I, _P]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_splitk_epilogue": (_I, [_P, _I, _L, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sy_rows_add_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
     const int l31 = lane & 31;
     const int half = lane >> 5;
     const sy_block_id bid = sy_xcd_block_id();   // x: channel tile (fastest: the channel tiles of a pixel tile share its rows in L2)
+    sy_probe(0);
     const int HW = p.HoWo;
     const int m_end = p.seg_M > 0 ? (bid.z + 1) * p.seg_M : p.M;
     const int m0 = bid.z * (p.seg_M > 0 ? p.seg_M : 0) + bid.y * PT;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
         });
     };
     burst(0);
+    sy_probe(1);
 
     f32x16 acc[TC][TP];
 #pragma unroll
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
         // VMEM operations issued after the last piece of this group: its own last slab's fragments + everything of the later slabs
         sy_wait_vmcnt<2 * TC + (NS - (GI + 1) * SPG) * (PW + 2 * TC)>();
         sy_barrier();
+        if constexpr (GI == 0) sy_probe(2);
         uint4 b[BD][TP];
         auto read_step = [&](auto s_) {          // step = (slab, k-half) inside the group
             constexpr int ST = decltype(s_)::value;
@@ -143,11 +146,13 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
     });
     }
 
+    sy_probe(3);
     SY_LATE_ARGS(ConvArgs, p);
     int e_bx = bid.x, e_by = bid.y, e_bz = bid.z;
     SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_by); SY_LAUNDER_INT(e_bz);
     const LinearPixels mp(p_late, e_by, e_bz, PT);
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+    sy_probe(6);
 }
 
 // (A persistent variant — weights loaded once per workgroup, pixel tiles walked through two tile buffers, BatchNorm sums carried

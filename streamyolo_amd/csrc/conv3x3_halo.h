@@ -298,11 +298,14 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
         }
     }
 
+    sy_probe(0);
     sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, cs_begin); });
     sy_static_for<0, 9>([&](auto t_) { fetch(t_, cs_begin); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
+    sy_probe(1);
     for (int cs = cs_begin; cs < ncs; ++cs) {
         sy_wait_vmcnt<(9 - NI) * 2 * TC>();      // the slab's DMA pieces (older than the last (9 - NI) taps of fragment loads)
         sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
+        if (cs == cs_begin) sy_probe(2);
         const unsigned hbo = (unsigned)((cs & 1) * BUF);
         uint4 b[BD][TP];
         auto read_step = [&](auto s_) {
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     sy_barrier();
 
     SY_LATE_ARGS(ConvArgs, p);
+    sy_probe(3);
     int e_bx = bid.x, e_n = n + kz * p.N, e_h0 = h0, e_w0 = w0, e_by = bid.y;      // split z: partial "images" [z*N, (z+1)*N)
     SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_n); SY_LAUNDER_INT(e_h0); SY_LAUNDER_INT(e_w0); SY_LAUNDER_INT(e_by);
     TilePixels mp;
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
         }
     }
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+    sy_probe(6);
 }
 
 template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int S2 = 0>

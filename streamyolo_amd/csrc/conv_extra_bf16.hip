@@ -9,3 +9,4 @@ template int launch_halo_typed<BF16>(const ConvArgs&, void*);
 template int launch_s2dgrad<BF16>(const ConvArgs&, void*);
 template int launch_1x1_tile<BF16>(const ConvArgs&, void*);
 }  // namespace sy_conv
+SY_PROBE_READER(sy_probe_read_conv_extra)

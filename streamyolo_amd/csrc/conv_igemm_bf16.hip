@@ -3,3 +3,4 @@
 #include "conv_igemm_impl.h"
 
 int sy_conv_launch_bf16(const sy_conv::ConvArgs& a, void* stream) { return sy_conv::launch_typed<BF16>(a, stream); }
+SY_PROBE_READER(sy_probe_read_conv_igemm)

@@ -856,6 +856,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
         }
     });
     if (want_stats || (kCanStage && stage_out)) __syncthreads();
+    sy_probe(4);
     if (kCanStage && stage_out) {
         constexpr int CPR = CT / 8;                             // 16-byte chunks per staged pixel row
         for (int i = tid; i < PT * CPR; i += kThreads) {
@@ -879,6 +880,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             *dst = v;
         }
     }
+    sy_probe(5);
     if (want_stats && !(p.ablate & 8)) {
         const float* red = reinterpret_cast<const float*>(smem);
         const int copy = mp.seg * p.stat_copies + (int)((unsigned)mp.rep % (unsigned)p.stat_copies);

@@ -578,11 +578,14 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
     const int x_lane = ((lane >> 4) & 1) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
     const int y_lane = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 
+    sy_probe(0);
     for (int j = 0; j < STG - 1; ++j) issue_slab();
+    sy_probe(1);
     int stage_r = 0;
     for (int s = 0; s < nslab; ++s) {
         sy_wait_vmcnt<4 * (STG - 2)>();           // slab s landed; the STG - 2 slabs behind it stay in flight
         sy_barrier();                             // ... for every wave; everyone is past slab s - 1
+        if (s == 0) sy_probe(2);
         issue_slab();
         const unsigned char* const xb = smem + stage_r * STAGE + x_lane;
         const unsigned char* const yb = smem + stage_r * STAGE + 2 * kXSub + (wv * 2) * kSubPitch + y_lane;
@@ -610,6 +613,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
         });
     }
     sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
+    sy_probe(3);
 
     // ---- epilogue: D[row = (tap, ci)][col = co]; partial slab of this split, or += into dW (one split)
     const int l31 = lane & 31, half = lane >> 5;
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
                 *dst = o;
             }
         }
+    sy_probe(6);
 }
 
 // dW (+)= sum over splits of the partial slabs; also applies the slab -> packed / OIHW layout change.
@@ -860,3 +865,4 @@ extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
         default: return launch_wgrad_typed<F32>(a, wsb, stream);
     }
 }
+SY_PROBE_READER(sy_probe_read_wgrad)

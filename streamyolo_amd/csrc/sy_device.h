@@ -351,6 +351,30 @@ __device__ __forceinline__ sy_block_id sy_xcd_block_id() {
     return b;
 }
 
+// ---- in-kernel timeline probe (development builds only: `make probe`, tools/kernel_timeline.py) --------------------------------
+// sy_probe(slot): thread 0 of the workgroup stamps the device's constant 100 MHz clock (s_memrealtime) into slot `slot` of its
+// workgroup's row; one buffer per translation unit, read back through that unit's SY_PROBE_READER entry point.  Compiled out of
+// the product library.
+#if defined(SY_PROBE) && !defined(SY_EMU)
+constexpr int kProbeWG = 8192, kProbeSlots = 8;
+static __device__ unsigned long long sy_probe_buf[kProbeWG * kProbeSlots];
+__device__ __forceinline__ void sy_probe(int slot) {
+    if (threadIdx.x == 0) {
+        const unsigned w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (w < (unsigned)kProbeWG) sy_probe_buf[w * kProbeSlots + slot] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+#define SY_PROBE_READER(name)                                                                                          \
+    extern "C" __attribute__((visibility("default"))) int name(unsigned long long* dst, int clear) {                 \
+        if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(sy_probe_buf), sizeof(sy_probe_buf)) != hipSuccess) return 2;          \
+        if (clear) { static unsigned long long z[kProbeWG * kProbeSlots]; (void)hipMemcpyToSymbol(HIP_SYMBOL(sy_probe_buf), z, sizeof(z)); } \
+        return 0;                                                                                                    \
+    }
+#else
+#define sy_probe(slot) ((void)0)
+#define SY_PROBE_READER(name)
+#endif
+
 // ---- late kernel arguments -----------------------------------------------------------------------------------
 // hipcc loads every field of a by-value argument struct into SGPRs at kernel entry and keeps the ones the epilogue
 // needs alive across the main loop, where they crowd out (spill) the loop's own uniforms.  SY_LATE_ARGS re-reads the

@@ -6,16 +6,19 @@
 // of ~50 tiny kernels with `.item()` / `int()` host syncs and a `torch.cuda.empty_cache()` per image
 // (:306-307, :376, :690, :702), followed by autograd's backward over the same small tensors.
 //
-//   kernel 1  tal_assign   one 1024-thread workgroup per image
-//       candidates  = anchors whose centre lies in any GT box or in any GT's 2.5-stride centre square
-//                     (:644-672), compacted in ascending anchor order (wave ballots + LDS scan)
-//       cost[g][c]  = BCE(sqrt(sigmoid(cls)*sigmoid(obj)), onehot_g) + 3*(-log(IoU+1e-8)) + 1e5*[not in both]
+//   kernel 1a tal_prep     grid over anchors x images
+//       candidates  = anchors whose centre lies in any GT box or in any GT's 2.5-stride centre square (:644-672); their decoded
+//                     box, objectness and class-cost base; the GT bookkeeping incl. the trend weights (:394-406)
+//   kernel 1b tal_match    one workgroup per (GT, image)
+//       cost[g][a]  = BCE(sqrt(sigmoid(cls)*sigmoid(obj)), onehot_g) + 3*(-log(IoU+1e-8)) + 1e5*[not in both]
 //                     (:534-553; BCE log terms clamped at -100 like F.binary_cross_entropy)
-//       dynamic k   = clamp(int(sum of the 10 largest IoUs of g), 1)        (:685-687)   -- one wave per GT:
-//       matching    = the k_g cheapest candidates of each GT                 (:688-692)      iterated wave arg-min/max
+//       dynamic k   = clamp(int(sum of the 10 largest IoUs of g), 1)        (:685-687)
+//       matching    = the k_g cheapest candidates of the GT                  (:688-692)
+//   kernel 1c tal_resolve  one workgroup per image
 //       conflicts   = an anchor claimed by several GTs keeps the arg-min cost over ALL GTs  (:696-700)
-//       trend       = per GT max IoU with the support-frame GTs, < ignore_thr -> ignore_value (:394-406)
 //       plus per-image partial sums of the IoU / L1 losses needed by the TAL weight normalisation (:429-438)
+//   (Round 4: the three were ONE 1024-thread workgroup per image — 0.25 ms with eight workgroups on a 256-CU chip and nothing else
+//    runnable between the forward and the backward pass; now ~0.04 ms.)
 //   kernel 2  tal_grad     grid-stride over B*A anchors
 //       loss = 5 * sum(w_iou (1 - IoU^2))/N + sum BCE(obj)/N + sum BCE(cls | fg)/N + sum(w_l1 |l1|)/N  (:441-461)
 //       and its closed-form gradient w.r.t. the RAW head output (decode chain rule included: xy*stride,
@@ -47,12 +50,12 @@ inline TalLayout tal_layout(int A, int max_gt) {
     long long o = 0;
     L.acap = (A + 63) / 64 * 64;
     auto take = [&](long long bytes) { long long r = o; o += (bytes + 255) / 256 * 256; return r; };
-    L.cand_idx = take(4LL * L.acap);
+    L.cand_idx = take(4LL * L.acap);    // per ANCHOR: 1 = candidate (centre in a GT box or centre square)
     L.cbox = take(16LL * L.acap);
     L.cobj = take(4LL * L.acap);
     L.csum = take(4LL * L.acap);
-    L.cost = take(4LL * L.acap * max_gt);
-    L.iou = take(4LL * L.acap * max_gt);
+    L.cost = 0;                         // (the pairwise cost / IoU matrices of the single-workgroup version are gone: the per-GT
+    L.iou = 0;                          //  workgroups select in one pass, conflicts recompute their few rows)
     L.mcnt = take(4LL * L.acap);
     L.mgt = take(4LL * L.acap);
     L.agt = take(4LL * L.acap);         // per ANCHOR: matched GT index or -1
@@ -93,234 +96,271 @@ __device__ __forceinline__ void wave_argmin(float& v, int& i) {
     }
 }
 
-__global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float* raw, int A, int nc, const float* labels,
-                                                                    const float* support, int max_labels, TalGeom geom,
-                                                                    float gamma, float ignore_thr, float ignore_value,
-                                                                    int use_l1, unsigned char* ws, TalLayout L) {
+// ---- shared pieces of the three assignment kernels -------------------------------------------------------------------------------
+struct TalWs {            // typed views of one image's workspace slice
+    int* cand; float* cbox; float* cobj; float* csum; int* mcnt; int* mgt; int* agt; float* aiou; float* part;
+    __device__ __forceinline__ TalWs(unsigned char* wsi, const TalLayout& L)
+        : cand((int*)(wsi + L.cand_idx)), cbox((float*)(wsi + L.cbox)), cobj((float*)(wsi + L.cobj)), csum((float*)(wsi + L.csum)),
+          mcnt((int*)(wsi + L.mcnt)), mgt((int*)(wsi + L.mgt)), agt((int*)(wsi + L.agt)), aiou((float*)(wsi + L.aiou)),
+          part((float*)(wsi + L.part)) {}
+};
+
+// nlabel = #rows with sum > 0; the FIRST nlabel rows are used (:285, :317-319).  Called by every thread of the workgroup.
+__device__ __forceinline__ int tal_count_rows(const float* rows, int max_labels, int* s_cnt) {
+    if (threadIdx.x == 0) *s_cnt = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < max_labels; t += blockDim.x) {
+        const float* r = rows + t * 5;
+        if (r[0] + r[1] + r[2] + r[3] + r[4] > 0.0f) atomicAdd(s_cnt, 1);
+    }
+    __syncthreads();
+    const int n = *s_cnt;
+    __syncthreads();
+    return n;
+}
+
+// centre of anchor (gx, gy, stride st) inside GT box / inside its 2.5-stride centre square (:644-672)
+__device__ __forceinline__ void tal_in_box(float gx, float gy, float st, float bx, float by, float bw, float bh, bool& inb, bool& inc) {
+    const float xc = gx * st + 0.5f * st, yc = gy * st + 0.5f * st, rad = 2.5f * st;
+    inb = fminf(fminf(xc - (bx - 0.5f * bw), yc - (by - 0.5f * bh)), fminf((bx + 0.5f * bw) - xc, (by + 0.5f * bh) - yc)) > 0.0f;
+    inc = fminf(fminf(xc - (bx - rad), yc - (by - rad)), fminf((bx + rad) - xc, (by + rad) - yc)) > 0.0f;
+}
+
+// IoU and SimOTA cost of candidate anchor `a` against one GT (:534-553).  A diverged step (exp(raw) -> inf) makes IoU / cost NaN,
+// and NaN fails every comparison of the selections: NaN IoU counts as 0 and NaN cost as +huge, so every selection still finds a
+// candidate (the reference would carry the NaN into the loss; here the loss terms computed from the raw tensor stay NaN, only the
+// indexing is safe).
+__device__ __forceinline__ void tal_pair(const TalGeom& geom, int a, const float* r, const TalWs& W, float bx, float by, float bw,
+                                         float bh, int gcls, float& iou_s, float& cst) {
+    float gx, gy, st;
+    anchor_geom(geom, a, gx, gy, st);
+    bool inb, inc;
+    tal_in_box(gx, gy, st, bx, by, bw, bh, inb, inc);
+    const float iou = iou_cxcywh(bx, by, bw, bh, W.cbox[a * 4], W.cbox[a * 4 + 1], W.cbox[a * 4 + 2], W.cbox[a * 4 + 3]);
+    const float p = sqrtf((1.0f / (1.0f + expf(-r[5 + gcls]))) * W.cobj[a]);
+    const float cls_cost = W.csum[a] - (-clamp_log(1.0f - p)) + (-clamp_log(p));
+    iou_s = (iou == iou) ? iou : 0.0f;
+    const float c = cls_cost + 3.0f * (-logf(iou_s + 1e-8f)) + ((inb && inc) ? 0.0f : 100000.0f);
+    cst = (c == c) ? c : 3.0e38f;
+}
+
+// ---- kernel 1a: per anchor — candidate test, decoded box / objectness / class-cost base of the candidates, cleared match state;
+//      block (0, img) also does the GT bookkeeping (trend weights, :394-406, :429).  Grid (ceil(A / 256), B).
+__global__ __launch_bounds__(256) void tal_prep_kernel(const float* raw, int A, int nc, const float* labels, const float* support,
+                                                       int max_labels, TalGeom geom, float gamma, float ignore_thr,
+                                                       float ignore_value, unsigned char* ws, TalLayout L) {
+    __shared__ float s_gt[kMaxGT][4];
+    __shared__ int s_cnt;
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int nch = 5 + nc;
+    const float* R = raw + (long long)img * A * nch;
+    const float* LB = labels + (long long)img * max_labels * 5;
+    const float* SP = support + (long long)img * max_labels * 5;
+    const TalWs W(ws + (long long)img * L.image_bytes, L);
+    int G = tal_count_rows(LB, max_labels, &s_cnt);
+    if (G > kMaxGT) G = kMaxGT;
+    for (int g = tid; g < G; g += 256) {
+        const float* r = LB + g * 5;
+        s_gt[g][0] = r[1]; s_gt[g][1] = r[2]; s_gt[g][2] = r[3]; s_gt[g][3] = r[4];
+    }
+    if (blockIdx.x == 0) {
+        const int S = tal_count_rows(SP, max_labels, &s_cnt);
+        if (tid < 16) W.part[tid] = (tid == 5) ? (float)G : 0.0f;
+        for (int g = tid; g < G; g += 256) {
+            const float* r = LB + g * 5;
+            float tr = 1.0f;
+            if (S > 0) {
+                tr = -INFINITY;
+                for (int s = 0; s < S; ++s) {
+                    const float* q = SP + s * 5;
+                    tr = fmaxf(tr, iou_cxcywh(r[1], r[2], r[3], r[4], q[1], q[2], q[3], q[4]));
+                }
+                if (tr < ignore_thr) tr = ignore_value;
+            }
+            W.part[16 + g] = 1.0f / (powf(tr, gamma) + 1e-8f);
+        }
+    }
+    __syncthreads();
+    const int a = blockIdx.x * 256 + tid;
+    if (a >= A) return;
+    bool is_cand = false;
+    float gx, gy, st;
+    anchor_geom(geom, a, gx, gy, st);
+    for (int g = 0; g < G && !is_cand; ++g) {
+        bool inb, inc;
+        tal_in_box(gx, gy, st, s_gt[g][0], s_gt[g][1], s_gt[g][2], s_gt[g][3], inb, inc);
+        is_cand = inb || inc;
+    }
+    W.cand[a] = is_cand ? 1 : 0;
+    W.mcnt[a] = 0;
+    W.mgt[a] = -1;
+    W.agt[a] = -1;
+    W.aiou[a] = 0.0f;
+    if (is_cand) {
+        const float* r = R + (long long)a * nch;
+        W.cbox[a * 4 + 0] = (r[0] + gx) * st;
+        W.cbox[a * 4 + 1] = (r[1] + gy) * st;
+        W.cbox[a * 4 + 2] = expf(r[2]) * st;
+        W.cbox[a * 4 + 3] = expf(r[3]) * st;
+        const float so = 1.0f / (1.0f + expf(-r[4]));
+        W.cobj[a] = so;
+        float acc = 0.0f;
+        for (int k = 0; k < nc; ++k) {
+            const float p = sqrtf((1.0f / (1.0f + expf(-r[5 + k]))) * so);
+            acc += -clamp_log(1.0f - p);
+        }
+        W.csum[a] = acc;
+    }
+}
+
+// ---- kernel 1b: dynamic k + matching, one 256-thread workgroup per (GT row, image); rows >= nlabel exit at once.
+// Both selections need at most ten entries of the GT's (IoU | cost) row over the candidates (k = int(sum of the ten largest IoUs) <=
+// 10), in (value, smaller anchor index first) order — the candidates are visited in ascending anchor order in the reference, so the
+// anchor index IS its tie-break order.  One pass: every thread keeps the ten best of its own anchors for both keys (sorted, in
+// registers), each wave merges its lanes' heads entry by entry (wave_argmin) into its own top ten, wave 0 merges the four lists.
+__global__ __launch_bounds__(256) void tal_match_kernel(const float* raw, int A, int nc, const float* labels, int max_labels,
+                                                        TalGeom geom, unsigned char* ws, TalLayout L) {
+    __shared__ int s_cnt;
+    __shared__ int s_wcnt[4];
+    __shared__ float s_v[2][4][10];
+    __shared__ int s_i[2][4][10];
+    const int img = blockIdx.y, g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = 5 + nc;
+    const float* R = raw + (long long)img * A * nch;
+    const float* LB = labels + (long long)img * max_labels * 5;
+    const TalWs W(ws + (long long)img * L.image_bytes, L);
+    int G = tal_count_rows(LB, max_labels, &s_cnt);
+    if (G > kMaxGT) G = kMaxGT;
+    if (g >= G) return;
+    const float* lb = LB + g * 5;
+    const int gcls = (int)lb[0];
+    const float bx = lb[1], by = lb[2], bw = lb[3], bh = lb[4];
+
+    float tv[2][10];
+    int ti[2][10];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { tv[q][j] = INFINITY; ti[q][j] = 0x7fffffff; }
+    auto insert = [&](auto q_, float v, int i) {
+        constexpr int Q = decltype(q_)::value;
+        if (!(v < tv[Q][9] || (v == tv[Q][9] && i < ti[Q][9]))) return;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {                    // pass the entry through the sorted list
+            const bool lt = v < tv[Q][j] || (v == tv[Q][j] && i < ti[Q][j]);
+            const float ov = tv[Q][j];
+            const int oi = ti[Q][j];
+            tv[Q][j] = lt ? v : ov; ti[Q][j] = lt ? i : oi;
+            v = lt ? ov : v; i = lt ? oi : i;
+        }
+    };
+    int mine = 0;
+    for (int a = tid; a < A; a += 256) {
+        if (!W.cand[a]) continue;
+        ++mine;
+        float iou_s, cst;
+        tal_pair(geom, a, R + (long long)a * nch, W, bx, by, bw, bh, gcls, iou_s, cst);
+        insert(sy_int<0>(), -iou_s, a);                   // ten largest IoUs
+        insert(sy_int<1>(), cst, a);                      // ten smallest costs
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) s_wcnt[wave] = mine;
+    // the wave's own top ten of both keys -> LDS
+    sy_static_for<0, 2>([&](auto q_) {
+        constexpr int Q = decltype(q_)::value;
+        for (int it = 0; it < 10; ++it) {
+            float bv = tv[Q][0];
+            int bi = ti[Q][0];
+            const float mv = bv;
+            const int mi = bi;
+            wave_argmin(bv, bi);
+            if (mv == bv && mi == bi && bi != 0x7fffffff) {   // this lane's head was taken: drop it
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { tv[Q][j] = tv[Q][j + 1]; ti[Q][j] = ti[Q][j + 1]; }
+                tv[Q][9] = INFINITY; ti[Q][9] = 0x7fffffff;
+            }
+            if (lane == 0) { s_v[Q][wave][it] = bv; s_i[Q][wave][it] = bi; }
+        }
+    });
+    __syncthreads();
+    if (wave != 0) return;
+    const int C = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (C == 0) return;
+    const int nk = C < 10 ? C : 10;
+    float v = lane < 40 ? s_v[0][lane / 10][lane % 10] : INFINITY;
+    int i = lane < 40 ? s_i[0][lane / 10][lane % 10] : 0x7fffffff;
+    float sum = 0.0f;
+    for (int it = 0; it < nk; ++it) {
+        float bv = v;
+        int bi = i;
+        wave_argmin(bv, bi);
+        if (bi == 0x7fffffff) break;
+        if (v == bv && i == bi) { v = INFINITY; i = 0x7fffffff; }
+        sum += -bv;
+    }
+    int kg = (sum == sum && sum < 1.0e9f) ? (int)sum : 1;    // dynamic k = clamp(int(sum of the 10 largest IoUs), 1)  (:685-687)
+    if (kg < 1) kg = 1;
+    if (kg > C) kg = C;
+    v = lane < 40 ? s_v[1][lane / 10][lane % 10] : INFINITY;
+    i = lane < 40 ? s_i[1][lane / 10][lane % 10] : 0x7fffffff;
+    for (int it = 0; it < kg && it < 10; ++it) {            // the k_g cheapest candidates of this GT (:688-692)
+        float bv = v;
+        int bi = i;
+        wave_argmin(bv, bi);
+        if (bi == 0x7fffffff) break;
+        if (v == bv && i == bi) { v = INFINITY; i = 0x7fffffff; }
+        if (lane == 0) { atomicAdd(&W.mcnt[bi], 1); W.mgt[bi] = g; }
+    }
+}
+
+// ---- kernel 1c: conflicts (an anchor claimed by several GTs keeps the arg-min cost over ALL GTs, :696-700), foreground list and the
+//      per-image partial sums of the IoU / L1 losses needed by the TAL weight normalisation (:429-438).  One workgroup per image.
+__global__ __launch_bounds__(kAssignThreads) void tal_resolve_kernel(const float* raw, int A, int nc, const float* labels,
+                                                                     int max_labels, TalGeom geom, int use_l1, unsigned char* ws,
+                                                                     TalLayout L) {
     __shared__ float s_gt[kMaxGT][4];
     __shared__ int s_gcls[kMaxGT];
     __shared__ float s_w[kMaxGT];
-    __shared__ int s_k[kMaxGT];
-    __shared__ int s_wave_cnt[kAssignThreads / 64];
-    __shared__ int s_base, s_G, s_S;
+    __shared__ int s_cnt;
     __shared__ float s_red[kAssignThreads / 64][8];
-
     const int img = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kAssignThreads / 64;
     const int nch = 5 + nc;
     const float* R = raw + (long long)img * A * nch;
     const float* LB = labels + (long long)img * max_labels * 5;
-    const float* SP = support + (long long)img * max_labels * 5;
-    unsigned char* wsi = ws + (long long)img * L.image_bytes;
-    int* cand_idx = (int*)(wsi + L.cand_idx);
-    float* cbox = (float*)(wsi + L.cbox);
-    float* cobj = (float*)(wsi + L.cobj);
-    float* csum = (float*)(wsi + L.csum);
-    float* cost = (float*)(wsi + L.cost);
-    float* ioum = (float*)(wsi + L.iou);
-    int* mcnt = (int*)(wsi + L.mcnt);
-    int* mgt = (int*)(wsi + L.mgt);
-    int* agt = (int*)(wsi + L.agt);
-    float* aiou = (float*)(wsi + L.aiou);
-    float* part = (float*)(wsi + L.part);
-
-    // ---- GT bookkeeping: nlabel = #rows with sum > 0; the FIRST nlabel rows are used (:285, :317-319)
-    if (tid == 0) { s_G = 0; s_S = 0; s_base = 0; }
-    __syncthreads();
-    if (tid < max_labels) {
-        const float* r = LB + tid * 5;
-        if (r[0] + r[1] + r[2] + r[3] + r[4] > 0.0f) atomicAdd(&s_G, 1);
-        const float* q = SP + tid * 5;
-        if (q[0] + q[1] + q[2] + q[3] + q[4] > 0.0f) atomicAdd(&s_S, 1);
-    }
-    for (int a = tid; a < A; a += kAssignThreads) { agt[a] = -1; aiou[a] = 0.0f; }
-    __syncthreads();
-    const int G = s_G < kMaxGT ? s_G : kMaxGT;
-    const int S = s_S;
+    const TalWs W(ws + (long long)img * L.image_bytes, L);
+    int G = tal_count_rows(LB, max_labels, &s_cnt);
+    if (G > kMaxGT) G = kMaxGT;
+    if (G == 0) return;
     if (tid < G) {
         const float* r = LB + tid * 5;
         s_gcls[tid] = (int)r[0];
         s_gt[tid][0] = r[1]; s_gt[tid][1] = r[2]; s_gt[tid][2] = r[3]; s_gt[tid][3] = r[4];
-        // trend weight (:394-406, :429)
-        float tr = 1.0f;
-        if (S > 0) {
-            tr = -INFINITY;
-            for (int s = 0; s < S; ++s) {
-                const float* q = SP + s * 5;
-                tr = fmaxf(tr, iou_cxcywh(r[1], r[2], r[3], r[4], q[1], q[2], q[3], q[4]));
-            }
-            if (tr < ignore_thr) tr = ignore_value;
-        }
-        s_w[tid] = 1.0f / (powf(tr, gamma) + 1e-8f);
+        s_w[tid] = W.part[16 + tid];
     }
     __syncthreads();
-    if (tid < 16) part[tid] = (tid == 5) ? (float)G : 0.0f;
-    if (tid < G) part[16 + tid] = s_w[tid];
-    if (G == 0) return;
-
-    // ---- candidates, ascending anchor order -------------------------------------------------------
-    for (int a0 = 0; a0 < A; a0 += kAssignThreads) {
-        const int a = a0 + tid;
-        bool is_cand = false;
-        float gx = 0, gy = 0, st = 1;
-        if (a < A) {
-            anchor_geom(geom, a, gx, gy, st);
-            const float xc = gx * st + 0.5f * st, yc = gy * st + 0.5f * st;
-            const float rad = 2.5f * st;
-            for (int g = 0; g < G && !is_cand; ++g) {
-                const float bx = s_gt[g][0], by = s_gt[g][1], bw = s_gt[g][2], bh = s_gt[g][3];
-                const float bl = xc - (bx - 0.5f * bw), bt = yc - (by - 0.5f * bh);
-                const float br = (bx + 0.5f * bw) - xc, bb = (by + 0.5f * bh) - yc;
-                const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
-                const float cl = xc - (bx - rad), ct = yc - (by - rad), cr = (bx + rad) - xc, cbm = (by + rad) - yc;
-                const bool inc = fminf(fminf(cl, ct), fminf(cr, cbm)) > 0.0f;
-                is_cand = inb || inc;
-            }
-        }
-        const unsigned long long bal = __ballot(is_cand ? 1 : 0);
-        if (lane == 0) s_wave_cnt[wave] = __popcll(bal);
-        __syncthreads();
-        int before = s_base;
-        for (int w = 0; w < wave; ++w) before += s_wave_cnt[w];
-        if (is_cand) {
-            const int c = before + __popcll(bal & ((1ull << lane) - 1ull));
-            const float* r = R + (long long)a * nch;
-            cand_idx[c] = a;
-            cbox[c * 4 + 0] = (r[0] + gx) * st;
-            cbox[c * 4 + 1] = (r[1] + gy) * st;
-            cbox[c * 4 + 2] = expf(r[2]) * st;
-            cbox[c * 4 + 3] = expf(r[3]) * st;
-            const float so = 1.0f / (1.0f + expf(-r[4]));
-            cobj[c] = so;
-            float acc = 0.0f;
-            for (int k = 0; k < nc; ++k) {
-                const float p = sqrtf((1.0f / (1.0f + expf(-r[5 + k]))) * so);
-                acc += -clamp_log(1.0f - p);
-            }
-            csum[c] = acc;
-            mcnt[c] = 0;
-            mgt[c] = -1;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int t = s_base;
-            for (int w = 0; w < NW; ++w) t += s_wave_cnt[w];
-            s_base = t;
-        }
-        __syncthreads();
-    }
-    const int C = s_base;
-    if (C == 0) return;
-
-    // ---- pairwise IoU and cost ------------------------------------------------------------------------
-    for (long long i = tid; i < (long long)G * C; i += kAssignThreads) {
-        const int g = (int)(i / C), c = (int)(i - (long long)g * C);
-        const int a = cand_idx[c];
-        float gx, gy, st;
-        anchor_geom(geom, a, gx, gy, st);
-        const float xc = gx * st + 0.5f * st, yc = gy * st + 0.5f * st, rad = 2.5f * st;
-        const float bx = s_gt[g][0], by = s_gt[g][1], bw = s_gt[g][2], bh = s_gt[g][3];
-        const bool inb = fminf(fminf(xc - (bx - 0.5f * bw), yc - (by - 0.5f * bh)),
-                               fminf((bx + 0.5f * bw) - xc, (by + 0.5f * bh) - yc)) > 0.0f;
-        const bool inc = fminf(fminf(xc - (bx - rad), yc - (by - rad)), fminf((bx + rad) - xc, (by + rad) - yc)) > 0.0f;
-        const float iou = iou_cxcywh(bx, by, bw, bh, cbox[c * 4], cbox[c * 4 + 1], cbox[c * 4 + 2], cbox[c * 4 + 3]);
-        const float* r = R + (long long)a * nch;
-        const float p = sqrtf((1.0f / (1.0f + expf(-r[5 + s_gcls[g]]))) * cobj[c]);
-        const float cls_cost = csum[c] - (-clamp_log(1.0f - p)) + (-clamp_log(p));
-        // a diverged step (exp(raw) -> inf) makes IoU / cost NaN, and NaN fails every comparison of the sweeps below:
-        // NaN IoU counts as 0 and NaN cost as +huge, so every sweep still finds a candidate (the reference would carry
-        // the NaN into the loss; here the loss terms computed from the raw tensor stay NaN, only the indexing is safe)
-        const float iou_s = (iou == iou) ? iou : 0.0f;
-        const float cst = cls_cost + 3.0f * (-logf(iou_s + 1e-8f)) + ((inb && inc) ? 0.0f : 100000.0f);
-        ioum[(long long)g * L.acap + c] = iou_s;
-        cost[(long long)g * L.acap + c] = (cst == cst) ? cst : 3.0e38f;
-    }
-    __syncthreads();
-
-    // ---- dynamic k + matching: one wave per GT -----------------------------------------------------------
-    // Both selections need at most ten entries of a row (k = int(sum of the ten largest IoUs) <= 10), in (value, index) order.
-    // The rows live in global memory and a sweep per selected entry (twenty dependent passes of C / 64 loads per lane, each
-    // exposed to L2 latency) was this kernel's whole time — 0.32 ms on the step's critical path with 8 workgroups on the chip.
-    // Now ONE pass per row: every lane keeps the ten best of its own C / 64 entries in registers (sorted), and the wave
-    // merges the lanes' heads entry by entry (wave_argmin).  Same (value, smaller index first) order as the sweeps had.
-    for (int g = wave; g < G; g += NW) {
-        const float* irow = ioum + (long long)g * L.acap;
-        const float* crow = cost + (long long)g * L.acap;
-        const int nk = C < 10 ? C : 10;
-        float tv[10];
-        int ti[10];
-        auto collect = [&](const float* row, float sign) {
-#pragma unroll
-            for (int j = 0; j < 10; ++j) { tv[j] = INFINITY; ti[j] = 0x7fffffff; }
-            for (int c = lane; c < C; c += 64) {
-                float v = sign * row[c];
-                int i = c;
-                if (!(v < tv[9] || (v == tv[9] && i < ti[9]))) continue;
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {            // pass the entry through the sorted list
-                    const bool lt = v < tv[j] || (v == tv[j] && i < ti[j]);
-                    const float ov = tv[j];
-                    const int oi = ti[j];
-                    tv[j] = lt ? v : ov; ti[j] = lt ? i : oi;
-                    v = lt ? ov : v; i = lt ? oi : i;
-                }
-            }
-        };
-        auto pop = [&](float& bv, int& bi) {              // smallest remaining entry of the wave; its lane drops it
-            bv = tv[0]; bi = ti[0];
-            const float mine_v = bv;
-            const int mine_i = bi;
-            wave_argmin(bv, bi);
-            if (mine_v == bv && mine_i == bi && bi != 0x7fffffff) {
-#pragma unroll
-                for (int j = 0; j < 9; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
-                tv[9] = INFINITY; ti[9] = 0x7fffffff;
-            }
-        };
-        collect(irow, -1.0f);                            // ten largest IoUs
-        float sum = 0.0f;
-        for (int it = 0; it < nk; ++it) {
-            float bv;
-            int bi;
-            pop(bv, bi);
-            if (bi >= C) break;                           // no candidate left (cannot happen with sanitised IoUs; bounds the index)
-            sum += -bv;
-        }
-        int kg = (sum == sum && sum < 1.0e9f) ? (int)sum : 1;
-        if (kg < 1) kg = 1;
-        if (kg > C) kg = C;
-        if (lane == 0) s_k[g] = kg;
-        collect(crow, 1.0f);                             // kg (<= 10) smallest costs
-        for (int it = 0; it < kg && it < 10; ++it) {
-            float bv;
-            int bi;
-            pop(bv, bi);
-            if (bi >= C) break;                           // uniform: fewer comparable candidates than k
-            if (lane == 0) { atomicAdd(&mcnt[bi], 1); mgt[bi] = g; }
-        }
-    }
-    __syncthreads();
-
-    // ---- conflicts, foreground list, per-image partial sums ----------------------------------------------
     float p_iou = 0, p_wiou = 0, p_l1 = 0, p_wl1 = 0, p_nfg = 0;
-    for (int c = tid; c < C; c += kAssignThreads) {
-        const int cnt = mcnt[c];
+    for (int a = tid; a < A; a += kAssignThreads) {
+        const int cnt = W.mcnt[a];
         if (cnt == 0) continue;
-        int g = mgt[c];
+        int g = W.mgt[a];
+        const float* r = R + (long long)a * nch;
         if (cnt > 1) {
             float bv = INFINITY;
             for (int gg = 0; gg < G; ++gg) {
-                const float v = cost[(long long)gg * L.acap + c];
+                float iou_s, v;
+                tal_pair(geom, a, r, W, s_gt[gg][0], s_gt[gg][1], s_gt[gg][2], s_gt[gg][3], s_gcls[gg], iou_s, v);
                 if (v < bv) { bv = v; g = gg; }
             }
         }
-        const int a = cand_idx[c];
-        const float miou = ioum[(long long)g * L.acap + c];
-        agt[a] = g;
-        aiou[a] = miou;
+        float miou, unused;
+        tal_pair(geom, a, r, W, s_gt[g][0], s_gt[g][1], s_gt[g][2], s_gt[g][3], s_gcls[g], miou, unused);
+        W.agt[a] = g;
+        W.aiou[a] = miou;
         // IoU loss of this foreground anchor (IOUloss: +1e-16 in the denominator) and its L1 loss
-        const float px = cbox[c * 4], py = cbox[c * 4 + 1], pw = cbox[c * 4 + 2], ph = cbox[c * 4 + 3];
+        const float px = W.cbox[a * 4], py = W.cbox[a * 4 + 1], pw = W.cbox[a * 4 + 2], ph = W.cbox[a * 4 + 3];
         const float tx = s_gt[g][0], ty = s_gt[g][1], tw = s_gt[g][2], th = s_gt[g][3];
         const float lx = fmaxf(px - pw / 2, tx - tw / 2), ly = fmaxf(py - ph / 2, ty - th / 2);
         const float rx = fminf(px + pw / 2, tx + tw / 2), ry = fminf(py + ph / 2, ty + th / 2);
@@ -335,7 +375,6 @@ __global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float*
         if (use_l1) {
             float gx, gy, st;
             anchor_geom(geom, a, gx, gy, st);
-            const float* r = R + (long long)a * nch;
             const float l1 = fabsf(r[0] - (tx / st - gx)) + fabsf(r[1] - (ty / st - gy)) +
                              fabsf(r[2] - logf(tw / st + 1e-8f)) + fabsf(r[3] - logf(th / st + 1e-8f));
             p_l1 += l1;
@@ -353,14 +392,14 @@ __global__ __launch_bounds__(kAssignThreads) void tal_assign_kernel(const float*
     if (tid < 5) {
         float v = 0.0f;
         for (int w = 0; w < NW; ++w) v += s_red[w][tid];
-        part[tid] = v;
+        W.part[tid] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, int A, int nc, const float* labels,
                                                        int max_labels, TalGeom geom, float gamma, int use_l1,
                                                        const unsigned char* ws, TalLayout L,
-                                                       float* d_raw, float* losses, int* fg_mask) {
+                                                       float* d_raw, float* losses, int* fg_mask, void* d_pad, int pad_dtype) {
     __shared__ float s_tot[8];
     __shared__ float s_acc[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -383,17 +422,28 @@ __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, 
         const unsigned char* wsi = ws + (long long)b * L.image_bytes;
         const int g = ((const int*)(wsi + L.agt))[a];
         const float* r = raw + i * nch;
-        float* d = d_raw + i * nch;
+        float* const d_row = d_raw + i * nch;
+        // d(total)/d(raw) of channel k: the fp32 row, and (optional) the same value in the MFMA operand layout of the backward pass's
+        // first kernels, [reg 4 | obj | 0 0 0 | cls nc] x 16 in the compute dtype (the columns in between stay zero)
+        auto put = [&](int k, float v) {
+            d_row[k] = v;
+            if (d_pad != nullptr) {
+                const long long o = i * 16 + (k < 5 ? k : 3 + k);
+                if (pad_dtype == SY_DT_BF16) ((BF16::elem*)d_pad)[o] = BF16::from_f32(v);
+                else if (pad_dtype == SY_DT_F16) ((F16::elem*)d_pad)[o] = F16::from_f32(v);
+                else ((float*)d_pad)[o] = v;
+            }
+        };
         const float tobj = g >= 0 ? 1.0f : 0.0f;
         if (fg_mask != nullptr) fg_mask[i] = g >= 0 ? 1 : 0;
         {   // objectness BCE-with-logits on every anchor (:445-447)
             const float z = r[4];
             l_obj += fmaxf(z, 0.0f) - z * tobj + log1pf(expf(-fabsf(z)));
-            d[4] = (1.0f / (1.0f + expf(-z)) - tobj) * inv_nf;
+            put(4, (1.0f / (1.0f + expf(-z)) - tobj) * inv_nf);
         }
         if (g < 0) {
-            d[0] = 0.0f; d[1] = 0.0f; d[2] = 0.0f; d[3] = 0.0f;
-            for (int k = 0; k < nc; ++k) d[5 + k] = 0.0f;
+            put(0, 0.0f); put(1, 0.0f); put(2, 0.0f); put(3, 0.0f);
+            for (int k = 0; k < nc; ++k) put(5 + k, 0.0f);
             continue;
         }
         const float miou = ((const float*)(wsi + L.aiou))[a];
@@ -404,7 +454,7 @@ __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, 
             const float z = r[5 + k];
             const float t = (k == gcls) ? miou : 0.0f;
             l_cls += fmaxf(z, 0.0f) - z * t + log1pf(expf(-fabsf(z)));
-            d[5 + k] = (1.0f / (1.0f + expf(-z)) - t) * inv_nf;
+            put(5 + k, (1.0f / (1.0f + expf(-z)) - t) * inv_nf);
         }
         float gx, gy, st;
         anchor_geom(geom, a, gx, gy, st);
@@ -449,7 +499,7 @@ __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, 
             d2 += c1 * ((e2 > 0.0f) - (e2 < 0.0f));
             d3 += c1 * ((e3 > 0.0f) - (e3 < 0.0f));
         }
-        d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3;
+        put(0, d0); put(1, d1); put(2, d2); put(3, d3);
     }
     float vals[4] = {l_iou, l_obj, l_cls, l_l1};
 #pragma unroll
@@ -489,12 +539,13 @@ extern "C" int64_t sy_tal_loss_workspace_bytes(int B, int A, int max_gt) {
 extern "C" int sy_tal_loss(const float* raw, int B, int A, int num_classes, const float* labels, const float* support,
                            int max_labels, const int32_t* level_h, const int32_t* level_w, const float* level_stride,
                            int nlevels, float gamma, float ignore_thr, float ignore_value, int use_l1, float* d_raw,
-                           float* losses, int32_t* fg_mask, void* workspace, void* stream) {
+                           float* losses, int32_t* fg_mask, void* workspace, void* d_pad, int pad_dtype, void* stream) {
     if (raw == nullptr || labels == nullptr || support == nullptr || d_raw == nullptr || losses == nullptr ||
         workspace == nullptr || level_h == nullptr || level_w == nullptr || level_stride == nullptr)
         return SY_ERR_ARG;
     if (B <= 0 || A <= 0 || num_classes <= 0 || nlevels <= 0 || nlevels > kMaxLevels) return SY_ERR_ARG;
     if (max_labels <= 0 || max_labels > kMaxGT) return SY_ERR_UNSUPPORTED;
+    if (d_pad != nullptr && (num_classes > 8 || pad_dtype < SY_DT_BF16 || pad_dtype > SY_DT_F32)) return SY_ERR_UNSUPPORTED;
     TalGeom g;
     g.nlevels = nlevels;
     int a0 = 0;
@@ -507,13 +558,17 @@ extern "C" int sy_tal_loss(const float* raw, int B, int A, int num_classes, cons
     if (a0 != A) return SY_ERR_ARG;
     TalLayout L = tal_layout(A, max_labels);
     SY_LAUNCH(tal_zero_losses_kernel, dim3(1), dim3(64), 0, stream, losses);
-    SY_LAUNCH(tal_assign_kernel, dim3(B), dim3(kAssignThreads), 0, stream, raw, A, num_classes, labels, support,
-              max_labels, g, gamma, ignore_thr, ignore_value, use_l1, (unsigned char*)workspace, L);
+    SY_LAUNCH(tal_prep_kernel, dim3((A + 255) / 256, B), dim3(256), 0, stream, raw, A, num_classes, labels, support, max_labels, g,
+              gamma, ignore_thr, ignore_value, (unsigned char*)workspace, L);
+    SY_LAUNCH(tal_match_kernel, dim3(max_labels, B), dim3(256), 0, stream, raw, A, num_classes, labels, max_labels, g,
+              (unsigned char*)workspace, L);
+    SY_LAUNCH(tal_resolve_kernel, dim3(B), dim3(kAssignThreads), 0, stream, raw, A, num_classes, labels, max_labels, g, use_l1,
+              (unsigned char*)workspace, L);
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
     long long work = (long long)B * A;
     int blocks = (int)((work + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     SY_LAUNCH(tal_grad_kernel, dim3(blocks), dim3(256), 0, stream, raw, B, A, num_classes, labels, max_labels, g, gamma,
-              use_l1, (const unsigned char*)workspace, L, d_raw, losses, fg_mask);
+              use_l1, (const unsigned char*)workspace, L, d_raw, losses, fg_mask, d_pad, pad_dtype);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }

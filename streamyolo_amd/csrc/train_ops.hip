@@ -531,6 +531,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         y += ro * ldy; da += ro * ldda; scale += ao; shift += ao; mean += ao; invstd += ao;
         sums += (long long)blockIdx.y * copies * 2 * C;
     }
+    sy_probe(0);
     const long long first = pr < rows ? (long long)blockIdx.x * rows + pr : pixels;     // idle tail threads skip the loop
     const long long step = (long long)gridDim.x * rows;
     constexpr int D = SY_BN_ROWS_IN_FLIGHT;   // rows in flight per thread; the first rows' loads go out before the parameters'
@@ -546,6 +547,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
         s0[j] = 0.0f; s1[j] = 0.0f;
     }
+    sy_probe(1);
     for (long long pix = first; pix < pixels; pix += step) {
         const Chunk<T> yv = yq[0], gv = gq[0];
 #pragma unroll
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
             s1[j] += dz * ((yy - mu[j]) * is[j]);
         }
     }
+    sy_probe(3);
 #pragma unroll
     for (int j = 0; j < T::kEPC; ++j) {
         red[(j * 2 + 0) * kBlock + threadIdx.x] = s0[j];
@@ -573,6 +576,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         for (int r = 0; r < rows; ++r) v += red[(j * 2 + kind) * kBlock + r * cpp + ch];
         atomicAdd(sums + (long long)(blockIdx.x % copies) * 2 * C + kind * C + cb + ch * T::kEPC + j, v);
     }
+    sy_probe(6);
 }
 
 template <typename T>
@@ -839,3 +843,4 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,
                                        dgamma, dbeta, seg_sum_stride, (typename T::elem*)dres, lddres, dres_accumulate));
 }
+SY_PROBE_READER(sy_probe_read_train_ops)

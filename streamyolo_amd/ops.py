@@ -432,9 +432,10 @@ class TalLossWorkspace:
         self.nlevels = len(hw_list)
 
 
-def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value, use_l1, ws):
+def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value, use_l1, ws, d_pad=None):
     """SimOTA + Trend-Aware loss forward and gradient (sy_tal_loss).  raw [B,A,5+nc] fp32 contiguous;
-    labels/support [B, max_labels, 5] fp32.  Returns (losses[8], d_raw, fg_mask) device tensors."""
+    labels/support [B, max_labels, 5] fp32.  Returns (losses[8], d_raw, fg_mask) device tensors.
+    d_pad: optional [B, A, 16] tensor (bf16 / fp16 / fp32) that receives the gradient in the backward pass's operand layout."""
     assert raw.dtype == torch.float32 and raw.is_contiguous()
     # wider label rows (the reference's mixup branch, tal_head.py:277-283, slices [..., :5] itself): the kernel's row pitch is 5
     labels = labels[..., :5].to(raw.device, torch.float32).contiguous()
@@ -444,7 +445,8 @@ def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value,
                                  ws.max_labels, C.cast(ws.lh, C.c_void_p), C.cast(ws.lw, C.c_void_p),
                                  C.cast(ws.ls, C.c_void_p), ws.nlevels, float(gamma), float(ignore_thr),
                                  float(ignore_value), 1 if use_l1 else 0, ws.d_raw.data_ptr(), ws.losses.data_ptr(),
-                                 ws.fg.data_ptr(), ws.ws.data_ptr(), stream_of(raw)), "sy_tal_loss")
+                                 ws.fg.data_ptr(), ws.ws.data_ptr(), _p(d_pad), 0 if d_pad is None else DTYPE_CODE[d_pad.dtype],
+                                 stream_of(raw)), "sy_tal_loss")
     return ws.losses, ws.d_raw, ws.fg
 
 

@@ -369,6 +369,7 @@ class TrainPlan:
                 op.argmax = torch.empty((op.v.N, op.v.H, op.v.W, 3, op.v.C // 4), dtype=torch.uint8, device=device)
         self.cache = StagedWeights(self.ops, self.dtype, device)
         self.loss_ws = None
+        self._zeroed, self._zero_ev, self._packed_for = None, None, None
         self.run_table = None
         self.grads = _GradSpace()
         self.grads.py = self._py
@@ -686,8 +687,14 @@ class TrainPlan:
         if self.loss_ws is None or self.loss_ws.max_labels != labels.shape[1]:
             self.loss_ws = ops.TalLossWorkspace(self.B, self.A, 5 + self.nc, self.hw, head.strides, self.device,
                                                 max_labels=labels.shape[1])
+        # d(total)/d(raw) also lands in `dpad`, the operand layout of the prediction convs' gradients ([reg 4 | obj | 0 0 0 | cls nc] in
+        # the compute dtype): backward() starts its tape without a repacking pass when it is handed this very d_raw (the fast path;
+        # the drop-in path scales d_raw by the incoming gradient — GradScaler — and repacks)
+        pad = self.dpad if self.nc <= 8 else None
+        self._zero_gradient_arenas()
         losses, d_raw, _ = ops.tal_loss(self.raw, labels, support, self.nc, head.gamma, head.ignore_thr,
-                                        head.ignore_value, head.use_l1, self.loss_ws)
+                                        head.ignore_value, head.use_l1, self.loss_ws, d_pad=pad)
+        self._packed_for = d_raw if pad is not None else None
         out = {"total_loss": losses[0], "iou_loss": losses[1], "l1_loss": losses[2], "conf_loss": losses[3],
                "cls_loss": losses[4], "num_fg": losses[5]}
         return out, d_raw
@@ -697,19 +704,51 @@ class TrainPlan:
         """d_raw [B, A, 5+nc] fp32 -> parameter gradients accumulated into self.arena (zeroed here).
         parts == "backbone": d_raw is None and d_fused = gradients of the three fused features (NCHW-shaped tensors);
         parts == "head": afterwards self.fused_grads() holds the gradients of the fused inputs."""
-        self.arena.zero_()
-        self.bwd_arena.zero_()
+        self._zero_gradient_arenas(wait=True)
         nc = self.nc
-        if self.head is not None:
-            # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels
+        if self.head is not None and getattr(self, "_packed_for", None) is not d_raw:
+            # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels (sy_tal_loss wrote it already
+            # when d_raw is the loss's own, unscaled, tensor)
             self.dpad[..., 0:5] = d_raw[..., 0:5]
             self.dpad[..., 8:8 + nc] = d_raw[..., 5:]
+        self._packed_for = None
         self._seed = d_fused
         self._run("bwd", lambda: self._backward_ops(d_raw), key=None if d_raw is None else d_raw.data_ptr())
         if not self.tuned:
             self.tuned = True                                        # kernels are tuned after the first full step
             ops.save_tuned()                                         # ... and the choices persisted (next plan / process)
         return self.arena
+
+    def _zero_gradient_arenas(self, wait=False):
+        """The flat gradient arena (l: 219 MB) and the BatchNorm-backward sums are cleared once per step.  On the GPU the two
+        memsets are issued when the LOSS starts, on a stream that idles between the passes: the assignment kernel keeps eight
+        workgroups busy for ~0.25 ms and nothing else can run beside it — the 60 us of memsets used to sit in front of the backward
+        pass.  backward() (wait=True) orders its streams behind them, or clears the arenas itself when no loss call did (the
+        sub-module plans, a caller that skips loss())."""
+        st = self.side_w.get(3) or self.side2 or self.side
+        if wait:
+            if self._zeroed is None:
+                self.arena.zero_()
+                self.bwd_arena.zero_()
+            elif self._zeroed is not True:
+                torch.cuda.current_stream(self.device).wait_event(self._zeroed)
+            self._zeroed = None
+            return
+        if self._zeroed is not None:
+            return                                               # loss() called twice before a backward: already clear
+        if st is None or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            self.arena.zero_()
+            self.bwd_arena.zero_()
+            self._zeroed = True
+            return
+        st.wait_stream(torch.cuda.current_stream(self.device))   # whoever read the gradients last (optimizer, all-reduce) is done
+        with torch.cuda.stream(st):
+            self.arena.zero_()
+            self.bwd_arena.zero_()
+            if self._zero_ev is None:
+                self._zero_ev = torch.cuda.Event()
+            self._zero_ev.record()
+        self._zeroed = self._zero_ev
 
     def fused_grads(self):
         return tuple(self.grads.view(f).nchw() for f in self.fused)
