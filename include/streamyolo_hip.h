@@ -46,6 +46,7 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
        SY_TILE_WR = 80,   /* add: register-staged pixels + fragment-packed weights loaded straight into VGPRs */
        SY_TILE_HALO = 112, /* 114..118 (HALO + 2..6): 3x3 stride-1 kernel with the input tile + halo resident in LDS (csrc/conv3x3_halo.h;
                              needs wfrag): 128 ch x 2 rows x 32 px (8 waves) | 128 x 2 | 64 x 8 | 128 x 2 and 128 x 4 software-pipelined;
+                             119: FUSED Bottleneck forward (1x1 -> 3x3, the hidden activation kept in LDS; sy_conv_desc::pre_*);
                              110: STRIDE 2 forward, 128 ch x 2 output rows x 32 px, input window split by column parity;
                              108: STRIDE 2 data gradient (csrc/conv3x3_s2dgrad.h), four output-parity classes */
        SY_TILE_1X1K = 121 /* 121..123: 1x1 stride-1 kernel with the tile's whole K extent requested in one burst (csrc/conv1x1_tile.h; needs
@@ -92,7 +93,17 @@ typedef struct sy_conv_desc {
        y (which must hold S*N images, batch stride ybs).  sy_splitk_epilogue sums the partials and applies the epilogue.  For the
        deep small-map layers of the batch-1 streaming step: 36-72 workgroups become 144-288. */
     int32_t k_splits;
-    int32_t reserved;
+    /* Fused Bottleneck forward (tile 119, eval epilogues only; csrc/bottleneck_fused.h): this 3x3 stride-1 launch first computes its
+       own input h = silu(pre_scale * (pre_w x) + pre_shift) — the 1x1 BaseConv in front of it — for the tile's halo window and keeps
+       it in LDS.  x is then the 1x1 convolution's input ([N, H, W, pre_cin]); Cin stays the 3x3 convolution's input width (the hidden
+       channels); pre_w: that 1x1 convolution's weights in MFMA-fragment order ([Cin][pre_cin], as `wfrag` of a 1x1 launch);
+       pre_scale / pre_shift: its folded BatchNorm affine, fp32 [Cin].  pre_cin + Cin <= 544, both multiples of 32.
+       Replaces yolox Bottleneck.conv1 -> conv2 (+ x) as two launches. */
+    int32_t pre_cin;
+    const void* pre_w;
+    int64_t pre_w_bytes;
+    const float* pre_scale;
+    const float* pre_shift;
 } sy_conv_desc;
 
 /* Implicit-GEMM convolution on the MFMA units with the fused epilogue.

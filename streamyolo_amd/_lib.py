@@ -38,7 +38,8 @@ class ConvDesc(C.Structure):
         ("xbs", C.c_int64), ("ybs", C.c_int64), ("rbs", C.c_int64),
         ("dtype", C.c_int32), ("y_f32", C.c_int32), ("mode", C.c_int32), ("epilogue", C.c_int32),
         ("accumulate", C.c_int32), ("dec_stride", C.c_float), ("stat_copies", C.c_int32), ("stat_segments", C.c_int32), ("tile", C.c_int32), ("x_bytes", C.c_int64), ("w_bytes", C.c_int64), ("wfrag", C.c_void_p), ("wfrag_bytes", C.c_int64),
-        ("k_splits", C.c_int32), ("reserved", C.c_int32),
+        ("k_splits", C.c_int32), ("pre_cin", C.c_int32), ("pre_w", C.c_void_p), ("pre_w_bytes", C.c_int64),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p),
     ]
 
 

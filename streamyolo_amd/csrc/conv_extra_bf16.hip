@@ -3,10 +3,12 @@
 #include "conv3x3_halo.h"
 #include "conv3x3_s2dgrad.h"
 #include "conv1x1_tile.h"
+#include "bottleneck_fused.h"
 
 namespace sy_conv {
 template int launch_halo_typed<BF16>(const ConvArgs&, void*);
 template int launch_s2dgrad<BF16>(const ConvArgs&, void*);
 template int launch_1x1_tile<BF16>(const ConvArgs&, void*);
+template int launch_bottleneck_fused<BF16>(const ConvArgs&, void*);
 }  // namespace sy_conv
 SY_PROBE_READER(sy_probe_read_conv_extra)

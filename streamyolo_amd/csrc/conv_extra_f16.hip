@@ -3,9 +3,11 @@
 #include "conv3x3_halo.h"
 #include "conv3x3_s2dgrad.h"
 #include "conv1x1_tile.h"
+#include "bottleneck_fused.h"
 
 namespace sy_conv {
 template int launch_halo_typed<F16>(const ConvArgs&, void*);
 template int launch_s2dgrad<F16>(const ConvArgs&, void*);
 template int launch_1x1_tile<F16>(const ConvArgs&, void*);
+template int launch_bottleneck_fused<F16>(const ConvArgs&, void*);
 }  // namespace sy_conv

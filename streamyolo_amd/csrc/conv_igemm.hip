@@ -39,6 +39,9 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     a.w_extent = (d->w_bytes > 0 && d->w_bytes < 0xFFFFFFF0LL) ? (unsigned)d->w_bytes : 0u;
     a.wfrag = (const unsigned char*)d->wfrag;
     a.wfrag_extent = (d->wfrag != nullptr && d->wfrag_bytes > 0 && d->wfrag_bytes < 0xFFFFFFF0LL) ? (unsigned)d->wfrag_bytes : 0u;
+    a.pre_w = (const unsigned char*)d->pre_w; a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.pre_cin = d->pre_cin;
+    a.pre_w_extent = (d->pre_w != nullptr && d->pre_w_bytes > 0 && d->pre_w_bytes < 0xFFFFFFF0LL) ? (unsigned)d->pre_w_bytes : 0u;
+    if ((d->pre_w != nullptr) != ((d->tile & 0xff) == 119)) return SY_ERR_ARG;       // the fused Bottleneck kernel, and only it, takes pre_*
     a.ksplit = 0;
     if (d->k_splits > 1) {
         if (((d->tile & 0xff) != 117 && (d->tile & 0xff) != 118) || d->mode != SY_CONV_FWD || !d->y_f32 || d->epilogue != SY_EPI_LINEAR ||

@@ -59,6 +59,11 @@ struct ConvArgs {
     unsigned x_extent, w_extent; // bytes addressable from x / w (FAST loader's buffer bounds)
     const unsigned char* wfrag; // fragment-packed weights (STG 5), [Cout/32][slab][2][64 lanes][16 B]
     unsigned wfrag_extent;
+    const unsigned char* pre_w; // fused Bottleneck (bottleneck_fused.h, tile 119): fragment-packed 1x1 weights [Cin][pre_cin] of the conv in front
+    unsigned pre_w_extent;
+    const float* pre_scale;     // ... its folded BatchNorm affine [Cin]
+    const float* pre_shift;
+    int pre_cin;                // ... and its input channels (x has pre_cin channels then, Cin = the hidden width)
     int ksplit;                 // > 1: split-K over channel-slab ranges (conv3x3_halo2_kernel), gridDim.z splits, fp32 partial outputs
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads, 8 = no statistics atomics, 16 = no cross-lane statistics reduction
 };
@@ -941,10 +946,12 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
 template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 110, 114..118)
 template <typename T> int launch_s2dgrad(const ConvArgs& a, void* stream);         // conv3x3_s2dgrad.h (tile code 108)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..123)
+template <typename T> int launch_bottleneck_fused(const ConvArgs& a, void* stream); // bottleneck_fused.h (tile code 119)
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
     if (a.tile == 110 || (a.tile >= 114 && a.tile <= 118)) return launch_halo_typed<T>(a, stream);
+    if (a.tile == 119) return launch_bottleneck_fused<T>(a, stream);
     if (a.tile == 108) return launch_s2dgrad<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 123) return launch_1x1_tile<T>(a, stream);
     // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide

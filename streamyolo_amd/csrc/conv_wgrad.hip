@@ -809,6 +809,7 @@ template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
     if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
     if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
+    // (rings of 6 / 8 slabs — one workgroup per CU leaves the LDS free — measured in round 4: no faster, the kernel is issue-bound)
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128
         case 2: return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);   // 128 x  64

@@ -41,6 +41,8 @@ class ConvOp:
         self.yraw = None
         self.stat = None
         self._tiles = {}
+        self.pre_op = None          # a Bottleneck's 3x3 conv: the 1x1 ConvOp in front of it (its ONLY reader) — inference plans may fuse
+        self.fused_into = None      # ... and that 1x1 op: the 3x3 op that computes it inside its own launch when the tuner says so
 
     def tile(self, kind):
         """Tuned kernel variant for this op: kind = 'fwd' (eval epilogue), 'fwd_stats' (training) or 'dgrad'."""
@@ -92,6 +94,10 @@ class FocusOp:
 # ------------------------------------------------------------------------------------------------
 # (streaming head level 0 beside levels 1-2 on a second stream: 1.883 vs 1.849 ms per frame on one stream — profiles/r03/c_* — at
 #  batch 1 the frame is bound by dispatch, not by idle CUs; removed in round 4)
+# Bottleneck 1x1 -> 3x3 as one launch where the plan's tuner finds it faster than the two launches (inference / streaming plans;
+# csrc/bottleneck_fused.h).  "0": never; "force": wherever the kernel applies (tests, the emulator has no tuner).
+FUSE_BOTTLENECKS = os.environ.get("STREAMYOLO_FUSE_BOTTLENECKS", "1")
+FUSE_BOTTLENECKS = False if FUSE_BOTTLENECKS == "0" else FUSE_BOTTLENECKS
 # test hook: "S,tile" forces a split-K decision for every eligible layer (the emulator has no tuner)
 FORCE_SPLIT_K = tuple(int(v) for v in os.environ["STREAMYOLO_FORCE_SPLIT_K"].split(",")) if os.environ.get("STREAMYOLO_FORCE_SPLIT_K") else None
 
@@ -154,6 +160,7 @@ class _Builder:
             u = self.conv(b.conv1, a, tag="%s.m.%d.conv1" % (tag, i))
             dst = cat.slice(0, hid) if i == n - 1 else None
             a = self.conv(b.conv2, u, dst, res=a if b.use_add else None, tag="%s.m.%d.conv2" % (tag, i))
+            self.ops[-1].pre_op, self.ops[-2].fused_into = self.ops[-2], self.ops[-1]       # u has no other reader
         return self.conv(mod.conv3, cat, out, tag=tag + ".conv3")
 
 
@@ -405,6 +412,8 @@ class InferencePlan:
         need = 0
         for op in self.ops:
             if op.kind == "conv":
+                if op.pre_op is not None:
+                    self._fuse_decision(op)
                 dec = self._split_decision(op, op.tile("fwd"))
                 if dec[0] > 1:
                     need = max(need, dec[0] * op.y.pixels * op.y.C)
@@ -415,8 +424,29 @@ class InferencePlan:
             self._stream_tape = None
 
     # -- execution --------------------------------------------------------------------------------
+    def _fuse_decision(self, op):
+        """True: this Bottleneck 3x3 conv computes its 1x1 predecessor inside its own launch (csrc/bottleneck_fused.h).  Decided once
+        per op by measurement against the two launches (ops.tuned_bottleneck) — it pays only where the step is latency-bound."""
+        pre = op.pre_op
+        if pre is None or not FUSE_BOTTLENECKS or op.x.dtype == ops.DT_F32 or op.x.bs_ is not None or pre.x.bs_ is not None:
+            return False
+        dec = op._tiles.get("fuse")
+        if dec is None:
+            dec = op._tiles["fuse"] = bool(ops.tuned_bottleneck(op.x.dtype, op.x.N, op.x.H, op.x.W, pre.x.C, op.x.C, op.y.C,
+                                                                op.res is not None, self.device, pre.tile("fwd"), op.tile("fwd")))
+        return dec
+
     def _run_op(self, op):
         if op.kind == "conv":
+            if op.fused_into is not None and self._fuse_decision(op.fused_into):
+                return                                                  # computed inside the 3x3 launch that reads it
+            if op.pre_op is not None and self._fuse_decision(op):
+                pre = op.pre_op
+                w, scale, shift = self.cache.conv_eval(op.mod)
+                _, s1, b1 = self.cache.conv_eval(pre.mod)
+                ops.conv2d(pre.x, w, op.y, 3, 1, scale, shift, res=op.res, epilogue=EPI_SILU, tile=119,
+                           wfrag=self.cache.conv_weight_frag(op.mod), pre=(self.cache.conv_weight_frag(pre.mod), s1, b1))
+                return
             w, scale, shift = self.cache.conv_eval(op.mod)
             t = op.tile("fwd")
             dec = self._split_decision(op, t) if self._in_stream else (1, t)

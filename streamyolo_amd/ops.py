@@ -126,7 +126,7 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None, segments=1, k_splits=0):
+           cout=None, tile=0, wfrag=None, segments=1, k_splits=0, pre=None):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
     y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
     d = ConvDesc()
@@ -160,6 +160,11 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     if wfrag is not None:
         d.wfrag, d.wfrag_bytes = wfrag.data_ptr(), wfrag.numel() * wfrag.element_size()
     d.k_splits = int(k_splits)          # > 1: fp32 partial sums per channel-slab range (see sy_splitk_epilogue)
+    if pre is not None:                 # fused Bottleneck (tile 119): (1x1 fragment-packed weights, scale, shift); x = the 1x1 conv's input
+        pw, ps, ph = pre
+        d.pre_w, d.pre_w_bytes, d.pre_scale, d.pre_shift = pw.data_ptr(), pw.numel() * pw.element_size(), ps.data_ptr(), ph.data_ptr()
+        d.pre_cin = x.C
+        d.Cin = ps.numel()              # the 3x3 convolution's input width = the hidden channels
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
@@ -664,6 +669,79 @@ def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile):
     _tile_cache[key] = best[0] * 1000 + best[1] if best[0] > 1 else 1
     _tune_store.dirty = True
     return best
+
+
+def tuned_bottleneck(dtype, N, H, W, cin, hid, cout, shortcut, device, tile1, tile3):
+    """True when the fused Bottleneck launch (tile 119: 1x1 -> 3x3, hidden activation in LDS) beats the two launches (tiles `tile1`,
+    `tile3`, the plan's tuned choices) on this shape — measured on dummy tensors, each candidate replayed from a hipGraph of 8
+    repetitions (no host time between the launches, as in the plans' graphs / tapes).  Cached and persisted like the tile choices."""
+    import os
+    from .engine import FUSE_BOTTLENECKS
+    code = dtype_code(dtype)
+    if code == DT_F32 or cin % 32 or hid % 32 or cin + hid > 544:
+        return False
+    # the fused launch does 2-3x the 1x1 layer's products: it can only pay where the two launches are latency-bound, i.e. where a
+    # launch is well under one round of workgroups per CU (measured: profiles/r04/m_bottleneck_probe.txt — batch 1 wins 3-11 % at
+    # 64 / 128 channels, batch 16 loses 7-39 % everywhere)
+    if N * H * W > 40000 and FUSE_BOTTLENECKS != "force":
+        return False
+    if FUSE_BOTTLENECKS == "force":
+        return True
+    if not autotune_enabled(device) or torch.cuda.is_current_stream_capturing():
+        return False
+    _tune_store.load(device)
+    key = ("bnk", code, N, H, W, cin, hid, cout, bool(shortcut), int(tile1), int(tile3), str(device))
+    hit = _tile_cache.get(key)
+    if hit is not None:
+        return bool(hit)
+    from .model.packing import pack_conv_weight_frag
+    tdt = TORCH_DTYPE[code]
+    g = torch.Generator(device="cpu").manual_seed(cin + hid)          # random operands: zero-filled ones clock the chip up
+    x = View.alloc(N, H, W, cin, code, device)
+    x.buf.copy_(torch.randn(x.buf.shape, generator=g).to(tdt))
+    h = View.alloc(N, H, W, hid, code, device)
+    y = View.alloc(N, H, W, cout, code, device)
+    w1 = (torch.randn((hid, cin), generator=g) / cin ** 0.5).to(tdt).to(device)
+    w2 = (torch.randn((cout, 9 * hid), generator=g) / (9 * hid) ** 0.5).to(tdt).to(device)
+    w1f, w2f = pack_conv_weight_frag(w1, 1), pack_conv_weight_frag(w2, 3)
+    s1, b1 = torch.ones(hid, device=device), torch.zeros(hid, device=device)
+    s2, b2 = torch.ones(cout, device=device), torch.zeros(cout, device=device)
+    res = x if (shortcut and cin == cout) else None
+
+    def two():
+        conv2d(x, w1, h, 1, 1, s1, b1, epilogue=EPI_SILU, tile=tile1, wfrag=w1f if tile1 >= TILE_WR else None)
+        conv2d(h, w2, y, 3, 1, s2, b2, res=res, epilogue=EPI_SILU, tile=tile3, wfrag=w2f if tile3 >= TILE_WR else None)
+
+    def one():
+        conv2d(x, w2, y, 3, 1, s2, b2, res=res, epilogue=EPI_SILU, tile=119, wfrag=w2f, pre=(w1f, s1, b1))
+    times = []
+    try:
+        for fn in (two, one):
+            fn()
+            torch.cuda.synchronize(device)
+            side = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(side):                           # (capture on a side stream: the caller's stream may be the legacy one)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(8):
+                        fn()
+                g.replay()
+                torch.cuda.synchronize(device)
+                best = float("inf")
+                for _ in range(3):
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    g.replay()
+                    e.record()
+                    torch.cuda.synchronize(device)
+                    best = min(best, s.elapsed_time(e))
+            times.append(best)
+        win = times[1] < 0.96 * times[0]                            # fused must win by a margin
+    except (_lib.HipLibraryError, RuntimeError):
+        win = False
+    _tile_cache[key] = 1 if win else 0
+    _tune_store.dirty = True
+    return win
 
 
 # tile codes 1-6: scatter-transposed staging; +16 / +32: LDS-DMA ring (3 / 4 slabs) + ds_read_b64_tr_b16 fragments

@@ -419,3 +419,45 @@ def test_conv3x3_stride2_data_gradient_kernel(backend, dt, N, cin, cout, H, W):
     assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
     with pytest.raises(ops._lib.HipLibraryError):                    # forward launches are not this kernel's
         ops.conv2d(dxv, wt, dyp, 3, 2, tile=108, wfrag=wf)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("N,cin,hid,cout,H,W,shortcut", [(2, 64, 64, 64, 7, 37, True), (1, 128, 64, 160, 5, 70, False), (1, 256, 256, 256, 4, 33, True)])
+def test_bottleneck_fused_equals_the_two_launches(backend, dt, N, cin, hid, cout, H, W, shortcut):
+    """csrc/bottleneck_fused.h (tile code 119): yolox Bottleneck forward in eval mode — conv1 1x1 + BN + SiLU -> conv2 3x3 + BN +
+    SiLU (+ x) — as ONE launch with the hidden activation kept in LDS, against the two launches it replaces (1x1 tile kernel, then
+    the halo kernel with the residual epilogue) and against torch: image width / height ragged against the 2 x 32 tile, hidden
+    tiles shared unevenly by the four waves, output channels ragged against the 128-channel tile, channel-slice views."""
+    g = torch.Generator().manual_seed(cin + hid + W)
+    code = ops.dtype_code(dt)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
+    w1 = _q(torch.randn(hid, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    w2 = _q(torch.randn(cout, hid, 3, 3, generator=g) / (hid * 9) ** 0.5, dt)
+    s1, b1 = torch.rand(hid, generator=g) + 0.5, torch.randn(hid, generator=g) * 0.3
+    s2, b2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    if shortcut:
+        assert cin == cout
+    xv = View.alloc(N, H, W, cin + 32, dt, backend, zero=True).slice(32, cin); xv.set_nchw(x.to(backend))
+    w1p = pack_conv_weight(w1, code).to(backend); w1f = pack_conv_weight_frag(w1p, 1)
+    w2p = pack_conv_weight(w2, code).to(backend); w2f = pack_conv_weight_frag(w2p, 3)
+    dev = lambda t: t.to(backend)                                                     # noqa: E731
+    # the two launches
+    hv = View.alloc(N, H, W, hid, dt, backend)
+    ops.conv2d(xv, w1p, hv, 1, 1, dev(s1), dev(b1), epilogue=ops.EPI_SILU, tile=121, wfrag=w1f)
+    y2 = View.alloc(N, H, W, cout + 8, dt, backend, zero=True).slice(8, cout)
+    ops.conv2d(hv, w2p, y2, 3, 1, dev(s2), dev(b2), res=xv if shortcut else None, epilogue=ops.EPI_SILU, tile=117, wfrag=w2f)
+    # one launch
+    y1 = View.alloc(N, H, W, cout + 8, dt, backend, zero=True).slice(8, cout)
+    ops.conv2d(xv, w2p, y1, 3, 1, dev(s2), dev(b2), res=xv if shortcut else None, epilogue=ops.EPI_SILU, tile=119, wfrag=w2f,
+               pre=(w1f, dev(s1), dev(b1)))
+    a, b = y1.nchw().cpu(), y2.nchw().cpu()
+    assert float(y1.buf[..., :8].float().abs().max()) == 0.0
+    # same products, same fp32 accumulation order over K in both stages, the hidden activation rounded to the storage type in both:
+    # the two paths agree to the last bit or to one rounding of the output type
+    assert float((a - b).abs().max()) <= 2.0 ** (-7 if dt == "bf16" else -10) * float(b.abs().max()) * 1.01
+    hid_ref = F.silu(F.conv2d(x, w1) * s1[None, :, None, None] + b1[None, :, None, None])
+    ref = F.silu(F.conv2d(_q(hid_ref, dt), w2, None, 1, 1) * s2[None, :, None, None] + b2[None, :, None, None]) + (x if shortcut else 0)
+    assert _rel(a, ref) < TOL[dt]
+    # a launch without the pre_* operands on tile 119 (or with them on another tile) is an argument error
+    with pytest.raises(Exception):
+        ops.conv2d(hv, w2p, y1, 3, 1, dev(s2), dev(b2), epilogue=ops.EPI_SILU, tile=119, wfrag=w2f)

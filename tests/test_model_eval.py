@@ -275,3 +275,23 @@ def test_eval_m_vs_reference_golden_and_full_size_oracle(golden_dir):
 
 
 M_TOL = {"fp16": 3e-2, "bf16": 2e-1}      # measured on MI355X (profiles/r02 pytest log), bound <= 3x
+
+
+def test_fused_bottlenecks_reproduce_the_unfused_plan(backend, monkeypatch):
+    """Inference plans may run a Bottleneck's 1x1 -> 3x3 pair as one launch (csrc/bottleneck_fused.h; the tuner decides per layer on
+    the GPU).  Forced on for every Bottleneck the kernel applies to, the eval forward and the streaming step must reproduce the plan
+    that keeps two launches per Bottleneck (fp16: same products and accumulation order, one extra rounding at most per layer)."""
+    from streamyolo_amd import engine
+    outs = {}
+    for mode in ("0", "force"):
+        monkeypatch.setattr(engine, "FUSE_BOTTLENECKS", False if mode == "0" else mode)
+        m, sd, cfg = _model("nano", backend)
+        m.set_compute_dtype("fp16")
+        x = synth_frames(2, 64, 96, seed=2).to(backend)
+        with torch.no_grad():
+            outs[mode] = m(x).clone().float().cpu()
+        plan = next(iter(m._plans.plans.values()))
+        fused = [op for op in plan.ops if op.kind == "conv" and op._tiles.get("fuse")]
+        assert bool(fused) == (mode == "force")
+    # nano's widths (16 .. 64 hidden channels) are mostly below the kernel's 32-channel slab granularity: at least the 64-wide ones fuse
+    assert _rel(outs["force"], outs["0"]) < 2e-2

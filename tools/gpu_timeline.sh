@@ -1,6 +1,4 @@
-cd $GRAFT_REPO_ROOT; export STREAMYOLO_HIP_LIB=$PWD/tools/probes/_build/libstreamyolo_probe.so; mkdir -p gpurun_out/r4i
-( for args in "--kind conv --shape 9 --tile 121 --mode stats" "--kind conv --shape 9 --tile 121 --mode dgrad" "--kind conv --shape 9 --tile 121 --mode stats --half 0" "--kind conv --shape 5 --tile 123 --mode stats" \
-   "--kind conv --shape 10 --tile 117 --mode stats" "--kind conv --shape 10 --tile 117 --mode dgrad" "--kind conv --shape 6 --tile 117 --mode stats" "--kind conv --shape 6 --tile 118 --mode stats" \
-   "--kind wgrad --shape 10 --tile 65 --half 0" "--kind wgrad --shape 6 --tile 49 --half 0" "--kind bnred --shape 10" "--kind bnred --shape 6" ; do
-  python tools/kernel_timeline.py $args 2>&1 | grep -v amdgpu.ids; echo; done ) > gpurun_out/r4i/timelines.txt 2>&1
-cat gpurun_out/r4i/timelines.txt
+cd $GRAFT_REPO_ROOT; export STREAMYOLO_HIP_LIB=$PWD/tools/probes/_build/libstreamyolo_probe.so; mkdir -p gpurun_out/$1
+( for args in "--kind bnred --shape 10" "--kind bnred --shape 6" "--kind conv --shape 9 --tile 121 --mode stats" "--kind conv --shape 10 --tile 117 --mode stats" "--kind wgrad --shape 10 --tile 65 --half 0"; do
+  python tools/kernel_timeline.py $args 2>&1 | grep -v amdgpu.ids; echo; done ) > gpurun_out/$1/timelines.txt 2>&1
+cat gpurun_out/$1/timelines.txt
