@@ -706,17 +706,14 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                         }
                     }
                     if (STATS) {
+                        // Per-channel totals over the tile's 32 pixel columns: value-halving butterfly (sy_reduce16_over32) — lane l
+                        // ends up with the totals of accumulator register l & 15, lanes 0-15 of each half write them.
                         float* red = reinterpret_cast<float*>(smem);          // [WP][CT][2]
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float a = ssum[r], b = ssq[r];
-                            if (!(p.ablate & 16)) { a = sy_sum32_upper(a); b = sy_sum32_upper(b); }
-                            const int cl = (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
-                            if (l31 == 16) {
-                                red[(wp * CT + cl) * 2 + 0] = a;
-                                red[(wp * CT + cl) * 2 + 1] = b;
-                            }
-                        }
+                        float a = 0.0f, b = 0.0f;
+                        if (!(p.ablate & 16)) { a = sy_reduce16_over32(ssum); b = sy_reduce16_over32(ssq); }
+                        const int r = l31 & 15;
+                        const int cl = (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3);
+                        if (l31 < 16) { red[(wp * CT + cl) * 2 + 0] = a; red[(wp * CT + cl) * 2 + 1] = b; }
                     }
                 });
             };
