@@ -65,6 +65,7 @@ template <typename T> __device__ void pack_tile(const sy_pack_entry& e, int tile
 }
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const sy_pack_entry* entries, int n_entries) {
+    SY_TL_BEGIN(15);
     __shared__ float lds[kPackTaps][kPackTile][kPackTile + 1];
     int lo = 0, hi = n_entries - 1;                           // last entry with tile0 <= blockIdx.x
     while (lo < hi) {
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const sy_pack_entry* 
         case SY_DT_F16: pack_tile<F16>(e, tile, lds); break;
         default: pack_tile<F32>(e, tile, lds); break;
     }
+    SY_TL_END();
 }
 
 }  // namespace
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void rows_add_kernel(float* dst, long long ldd
 // columns of group cg -> partial[g][cg * 16 + c]  (fixed order: the result does not depend on scheduling)
 __global__ __launch_bounds__(256) void pred_colsum_kernel(const float* d_raw, int B, long long bs, int rows, int nch, float* partial,
                                                          int nch_pad) {
+    SY_TL_BEGIN(15);
     __shared__ float red[16][17];
     const int c = threadIdx.x & 15, rl = threadIdx.x >> 4, col = blockIdx.y * 16 + c;
     const long long total = (long long)B * rows;
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(256) void pred_colsum_kernel(const float* d_raw, in
         for (int k = 0; k < 16; ++k) s += red[k][c];
         partial[(long long)blockIdx.x * nch_pad + col] = s;
     }
+    SY_TL_END();
 }
 
 // one workgroup: bias gradients += column sums (partials folded in index order), weight gradients += the wgrad scratch
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(256) void pred_colsum_kernel(const float* d_raw, in
 __global__ __launch_bounds__(256) void pred_fold_kernel(const float* partial, int G, int nch_pad, int nc, float* scratch, int srows, int ld, int cin,
                                                        float* g_reg, float* g_obj, float* g_cls, float* gb_reg, float* gb_obj,
                                                        float* gb_cls) {
+    SY_TL_BEGIN(15);
     const int t = threadIdx.x;
     for (int col = t; col < 5 + nc; col += 256) {
         float s = 0.0f;
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(256) void pred_fold_kernel(const float* partial, in
         g_cls[i] += s1[r * ld + k];
         s1[r * ld + k] = 0.0f;
     }
+    SY_TL_END();
 }
 
 }  // namespace
@@ -182,3 +188,4 @@ extern "C" int sy_pred_grad_fold(const float* d_raw, int B, int64_t batch_stride
               g_obj, g_cls, gb_reg, gb_obj, gb_cls);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
+SY_PROBE_READER(sy_probe_read_api_misc)

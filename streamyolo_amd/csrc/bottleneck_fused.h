@@ -32,6 +32,7 @@ constexpr int kBnkHR = 4 * kHaloW;               // window pixels (TH + 2 = 4 ro
 
 template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void bottleneck_fused_kernel(ConvArgs p) {
+    SY_TL_BEGIN(16);
     constexpr int TC = 1, TP = 2, TH = 2, CT = NW * 32;
     constexpr int NPW = (9 + NW - 1) / NW;        // DMA pieces per wave per slab
     constexpr int PF = 8;                         // stage 1: W1 fragments in flight per wave (L2 latency >> the 5 MFMAs of a step)
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void bottleneck_fused_k
         }
     }
     conv_epilogue<T, NW, 1, 1, 2>(p_late, mp, e_bx, acc, smem, tid);
+    SY_TL_END();
 }
 
 template <typename T, int NW>

@@ -26,6 +26,7 @@ namespace sy_conv {
 // registers (accumulators persist; a barrier after a chunk's MFMAs frees the image for the next burst).
 template <typename T, int WC, int WP, int TC, int TP, int NS, int NCH = 1>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) void conv1x1_tile_kernel(ConvArgs p) {
+    SY_TL_BEGIN(4 + (p.mode == SY_CONV_DGRAD ? 32 : 0));
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
     constexpr int ESZ = 16 / EPC;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 && NS <= 8 ? 3 : 2)) vo
     const LinearPixels mp(p_late, e_by, e_bz, PT);
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
     sy_probe(6);
+    SY_TL_END();
 }
 
 // (A persistent variant — weights loaded once per workgroup, pixel tiles walked through two tile buffers, BatchNorm sums carried

@@ -32,6 +32,7 @@ constexpr int kHaloW = 34;            // 32 pixels + 1 halo pixel on each side
 
 template <typename T, int WC, int WP, int TC, int TP>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_halo_kernel(ConvArgs p) {
+    SY_TL_BEGIN(3 + (p.mode == SY_CONV_DGRAD ? 32 : 0));
     constexpr int kThreads = WC * WP * 64;
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
         }
     }
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+    SY_TL_END();
 }
 
 // ---- second generation: the same tile, software-pipelined inside the wave ---------------------------------------------
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
 //     conflict free), and the parity split costs nothing: every DMA lane picks its own global pixel anyway.
 template <typename T, int WC, int WP, int TC, int TP, int S2 = 0>
 __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1 : 2))) void conv3x3_halo2_kernel(ConvArgs p) {
+    SY_TL_BEGIN(2 + (p.mode == SY_CONV_DGRAD ? 32 : 0));
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
     constexpr int ESZ = 16 / EPC;
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     }
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
     sy_probe(6);
+    SY_TL_END();
 }
 
 template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int S2 = 0>
@@ -397,7 +401,7 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-// tile codes 110, 114..118 of sy_conv_desc::tile
+// tile codes 110, 112..118 of sy_conv_desc::tile
 template <typename T>
 int launch_halo_typed(const ConvArgs& a, void* stream) {
     switch (a.tile) {
@@ -407,6 +411,10 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         // second generation (in-wave software pipeline) of 115 / 113
         case 117: return launch_halo<T, 4, 1, 1, 2, 2>(a, stream);
         case 118: return launch_halo<T, 4, 1, 1, 4, 2>(a, stream);
+        // small launches (the streaming frame, the 19x30 maps): one 32 ch x 32 px MFMA tile per wave — half the serial MFMA chain
+        // of 117 per wave, and (112) twice the workgroups over which the layer's weights are fetched
+        case 112: return launch_halo<T, 2, 2, 1, 1, 2>(a, stream);  //  64 ch x ( 2 rows x 32 px), 4 waves
+        case 113: return launch_halo<T, 4, 2, 1, 1, 2>(a, stream);  // 128 ch x ( 2 rows x 32 px), 8 waves
         // STRIDE 2, forward (tile 117's configuration over a parity-split input window): +7 % / +26 % over the implicit-GEMM
         // variants on dark2.0 / dark4.0 (profiles/r04/a_probe_s2_stats.txt)
         case 110: return launch_halo<T, 4, 1, 1, 2, 2, 1>(a, stream);

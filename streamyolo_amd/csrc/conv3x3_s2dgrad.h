@@ -32,6 +32,7 @@ struct ClassPixels {              // TH rows x 32 class pixels (i, j) of parity 
 
 template <typename T, int WC, int WP, int TC, int TP>
 __global__ __launch_bounds__(WC * WP * 64, 3) void conv3x3_s2dgrad_kernel(ConvArgs p) {
+    SY_TL_BEGIN(5 + 32);
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
     constexpr int ESZ = 16 / EPC;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(WC * WP * 64, 3) void conv3x3_s2dgrad_kernel(ConvAr
         }
     }
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+    SY_TL_END();
 }
 
 // tile code 108: 4 waves x (32 channels x 2 class rows x 32 class pixels), the configuration of halo tile 117

@@ -124,6 +124,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
 // loads in flight while one feeds the MFMAs; a shallow ring costs less LDS, so more workgroups share a CU).
 template <typename T, int WC, int WP, int TC, int TP, int STG, int FAST>
 __global__ __launch_bounds__(WC * WP * 64, ((TC * TP <= 4 && !(STG == 6 && TC * TP == 4)) ? 4 : 2)) void conv_igemm_kernel(ConvArgs p) {
+    SY_TL_BEGIN(1 + (p.mode == SY_CONV_DGRAD ? 32 : 0));
     typedef typename T::elem elem;
     constexpr int RS = (STG == 1 || STG == 5 || STG == 6) ? 1 : 0;
     constexpr int WR = (STG == 5 || STG == 6) ? 1 : 0;   // weights: fragment-packed, global -> VGPR, never in LDS
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(WC * WP * 64, ((TC * TP <= 4 && !(STG == 6 && TC * 
     SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_by); SY_LAUNDER_INT(e_bz);
     const LinearPixels mp(p_late, e_by, e_bz, PT);
     conv_epilogue<T, WC, WP, TC, TP>(p_late, mp, e_bx, acc, smem, tid);
+    SY_TL_END();
 }
 
 // The epilogue as a separate (inlined) function: its only inputs are the late argument view, the logical tile and
@@ -940,14 +942,14 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
     }
 }
 
-template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 110, 114..118)
+template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 110, 112..118)
 template <typename T> int launch_s2dgrad(const ConvArgs& a, void* stream);         // conv3x3_s2dgrad.h (tile code 108)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..123)
 template <typename T> int launch_bottleneck_fused(const ConvArgs& a, void* stream); // bottleneck_fused.h (tile code 119)
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
-    if (a.tile == 110 || (a.tile >= 114 && a.tile <= 118)) return launch_halo_typed<T>(a, stream);
+    if (a.tile == 110 || (a.tile >= 112 && a.tile <= 118)) return launch_halo_typed<T>(a, stream);
     if (a.tile == 119) return launch_bottleneck_fused<T>(a, stream);
     if (a.tile == 108) return launch_s2dgrad<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 123) return launch_1x1_tile<T>(a, stream);

@@ -122,6 +122,7 @@ __device__ __forceinline__ void wgrad_epilogue(const WgradArgs& p, f32x16 (&acc)
 
 template <typename T, int WR, int WC, int TR, int TC>
 __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
+    SY_TL_BEGIN(8);
     typedef typename T::elem elem;
     constexpr int EPC = T::kEPC;
     constexpr int ESZ = 16 / EPC;
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
     }
 
     wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
+    SY_TL_END();
 }
 
 // ---- transpose-read variant (16-bit types) ------------------------------------------------------------------
@@ -328,6 +330,7 @@ constexpr int kSubPitch = 1024 + 128;
 // operands, a slab's addresses are per-lane constants + one wave-uniform offset, validity is m < M.
 template <typename T, int WR, int WC, int TR, int TC, int STG, int LIN>
 __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
+    SY_TL_BEGIN(7);
     constexpr int RT = WR * TR * 32, CT = WC * TC * 32;
     constexpr int SA = RT / 16, SB = CT / 16, NS = SA + SB;
     constexpr int STAGE = NS * kSubPitch;
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
     }
     sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
     wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
+    SY_TL_END();
 }
 
 // ---- 3x3 stride-1 "all taps" variant (16-bit types) ------------------------------------------------------------
@@ -484,6 +488,7 @@ constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (
 // (profiles/r04/a_probe_wgrad.txt) — removed; so was the eight-wave variant of this tile (ties, round 2).
 template <typename T, int STG, int PD = 2>
 __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
+    SY_TL_BEGIN(6);
     constexpr int CT = 128, CIT = 32;
     constexpr int SB = CT / 16;                   // dy subtiles per slab
     constexpr int STAGE = 2 * kXSub + SB * kSubPitch;
@@ -639,6 +644,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
             }
         }
     sy_probe(6);
+    SY_TL_END();
 }
 
 // dW (+)= sum over splits of the partial slabs; also applies the slab -> packed / OIHW layout change.
@@ -649,6 +655,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
 template <int ZL, bool BF>
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, float* dw, int Cout, int K, int Cin, int taps,
                                                          int splits, int oihw) {
+    SY_TL_BEGIN(9);
     constexpr int E = 256 / ZL;
     __shared__ float red[256];
     const long long total = (long long)Cout * K;
@@ -681,6 +688,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
             dw[o] += v;
         }
     }
+    SY_TL_END();
 }
 
 

@@ -12,6 +12,7 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(kBlock) void focus_pack_kernel(const float* in, int N, int Ctot, int c0, int H, int W,
                                                             typename T::elem* out) {
+    SY_TL_BEGIN(15);
     typedef typename T::elem elem;
     const int H2 = H >> 1, W2 = W >> 1;
     const long long total = (long long)N * H2 * W2;
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(kBlock) void focus_pack_kernel(const float* in, int
 #pragma unroll
         for (int k = 0; k < NV; ++k) dst[k] = v[k];
     }
+    SY_TL_END();
 }
 
 // ---- nearest resize to a target size (PyTorch 'nearest': src = min(floor(dst * in/out), in-1)) ----
@@ -50,6 +52,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void resize_nearest_kernel(const typename T::elem* in, int N, int Hi, int Wi, int C,
                                                                 int ldi, long long ibs, typename T::elem* out, int Ho,
                                                                 int Wo, int ldo, long long obs) {
+    SY_TL_BEGIN(15);
     const int cpp = C / T::kEPC;                       // chunks per pixel
     const long long total = (long long)N * Ho * Wo * cpp;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(kBlock) void resize_nearest_kernel(const typename T
         Chunk<T> c = Chunk<T>::load(in + n * ibs + ((long long)hs * Wi + ws) * ldi + cc * T::kEPC);
         c.store(out + n * obs + ((long long)ho * Wo + wo) * ldo + cc * T::kEPC);
     }
+    SY_TL_END();
 }
 
 // backward: every source pixel sums the destination pixels that read it (gather form, no atomics)
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(kBlock) void resize_nearest_bwd_kernel(const typena
                                                                     int C, int lddo, long long dobs,
                                                                     typename T::elem* din, int Hi, int Wi, int lddi,
                                                                     long long dibs, int accumulate) {
+    SY_TL_BEGIN(15);
     const int cpp = C / T::kEPC;
     const long long total = (long long)N * Hi * Wi * cpp;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(kBlock) void resize_nearest_bwd_kernel(const typena
         for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(acc[j]);
         o.store(dst);
     }
+    SY_TL_END();
 }
 
 // ---- view copy / accumulate -----------------------------------------------------------------------
@@ -223,3 +229,4 @@ extern "C" int sy_splitk_epilogue(const float* part, int splits, int64_t pixels,
                                        (long long)pixels, C, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)y, ldy, epilogue == SY_EPI_SILU ? 1 : 0));
 }
+SY_PROBE_READER(sy_probe_read_pointwise)

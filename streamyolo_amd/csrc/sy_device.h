@@ -418,15 +418,62 @@ __device__ __forceinline__ void sy_probe(int slot) {
         if (w < (unsigned)kProbeWG) sy_probe_buf[w * kProbeSlots + slot] = __builtin_amdgcn_s_memrealtime();
     }
 }
+// Launch timeline (tools/step_timeline.py): every workgroup's thread 0 folds its entry / exit stamps into ONE record per launch,
+// found by hashing the launch's kernel-argument segment address (unique among the ~1600 launches of a step: the runtime hands the
+// segments out of a ring far larger than that) — min entry, max exit, workgroup count, a family tag.  Unlike rocprofv3's kernel
+// trace (which serialises the streams on this stack) the records show the launches of a taped multi-stream step as they really
+// overlap.
+struct sy_tl_entry { unsigned long long key, t0, t1; unsigned tag, count; };
+constexpr int kTlSlots = 65536;
+static __device__ sy_tl_entry sy_tl[kTlSlots];
+__device__ __forceinline__ int sy_tl_begin(unsigned tag) {
+    // Workgroup 0 (dispatched first) opens the launch's record and stamps its start; exits are folded in by a SAMPLE of the
+    // workgroups (every 16th and the last four in dispatch order): thousands of same-address atomics per launch would serialise in
+    // L2 and stretch the step severalfold (the first version of this probe did: 101 ms instead of 23).
+    // (the block arithmetic stays in uniform control flow: the kernels reuse these values as scalar operands)
+    const unsigned w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const bool first = w == 0;
+    const bool sample = first || (w & 15u) == 15u || w + 4u >= nwg;
+    if (!sample || threadIdx.x != 0) return -1;
+    const unsigned long long key = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned h = (unsigned)((key >> 6) * 2654435761ull) & (unsigned)(kTlSlots - 1);      // direct-mapped: a collision loses the record
+    if (first) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long old = atomicCAS(&sy_tl[h].key, 0ull, key);
+        if (old != 0ull && old != key) return -1;
+        sy_tl[h].t0 = t;
+        sy_tl[h].tag = tag;
+        sy_tl[h].count = nwg;
+        return (int)h;
+    }
+    return __hip_atomic_load(&sy_tl[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key ? (int)h : -1;
+}
+__device__ __forceinline__ void sy_tl_end(int slot) {
+    if (slot >= 0) atomicMax(&sy_tl[slot].t1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+#define SY_TL_BEGIN(tag) const int sy_tl_slot_ = sy_tl_begin(tag)
+#define SY_TL_END() sy_tl_end(sy_tl_slot_)
 #define SY_PROBE_READER(name)                                                                                          \
     extern "C" __attribute__((visibility("default"))) int name(unsigned long long* dst, int clear) {                 \
         if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(sy_probe_buf), sizeof(sy_probe_buf)) != hipSuccess) return 2;          \
         if (clear) { static unsigned long long z[kProbeWG * kProbeSlots]; (void)hipMemcpyToSymbol(HIP_SYMBOL(sy_probe_buf), z, sizeof(z)); } \
         return 0;                                                                                                    \
+    }                                                                                                                \
+    extern "C" __attribute__((visibility("default"))) int name##_tl(void* dst, int clear) {                          \
+        if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(sy_tl), sizeof(sy_tl)) != hipSuccess) return 2;                       \
+        if (clear) {                                                                                                 \
+            static sy_tl_entry z[kTlSlots];                                                                          \
+            for (int i = 0; i < kTlSlots; ++i) { z[i].key = 0; z[i].t0 = ~0ull; z[i].t1 = 0; z[i].tag = 0; z[i].count = 0; } \
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sy_tl), z, sizeof(z));                                                \
+        }                                                                                                            \
+        return 0;                                                                                                    \
     }
 #else
 #define sy_probe(slot) ((void)0)
 #define SY_PROBE_READER(name)
+#define SY_TL_BEGIN(tag) ((void)0)
+#define SY_TL_END() ((void)0)
 #endif
 
 // ---- late kernel arguments -----------------------------------------------------------------------------------

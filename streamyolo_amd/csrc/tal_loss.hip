@@ -149,6 +149,7 @@ __device__ __forceinline__ void tal_pair(const TalGeom& geom, int a, const float
 __global__ __launch_bounds__(256) void tal_prep_kernel(const float* raw, int A, int nc, const float* labels, const float* support,
                                                        int max_labels, TalGeom geom, float gamma, float ignore_thr,
                                                        float ignore_value, unsigned char* ws, TalLayout L) {
+    SY_TL_BEGIN(14);
     __shared__ float s_gt[kMaxGT][4];
     __shared__ int s_cnt;
     const int img = blockIdx.y, tid = threadIdx.x;
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256) void tal_prep_kernel(const float* raw, int A, 
         }
         W.csum[a] = acc;
     }
+    SY_TL_END();
 }
 
 // ---- kernel 1b: dynamic k + matching, one 256-thread workgroup per (GT row, image); rows >= nlabel exit at once.
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void tal_prep_kernel(const float* raw, int A, 
 // registers), each wave merges its lanes' heads entry by entry (wave_argmin) into its own top ten, wave 0 merges the four lists.
 __global__ __launch_bounds__(256) void tal_match_kernel(const float* raw, int A, int nc, const float* labels, int max_labels,
                                                         TalGeom geom, unsigned char* ws, TalLayout L) {
+    SY_TL_BEGIN(14);
     __shared__ int s_cnt;
     __shared__ int s_wcnt[4];
     __shared__ float s_v[2][4][10];
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(256) void tal_match_kernel(const float* raw, int A,
         if (v == bv && i == bi) { v = INFINITY; i = 0x7fffffff; }
         if (lane == 0) { atomicAdd(&W.mcnt[bi], 1); W.mgt[bi] = g; }
     }
+    SY_TL_END();
 }
 
 // ---- kernel 1c: conflicts (an anchor claimed by several GTs keeps the arg-min cost over ALL GTs, :696-700), foreground list and the
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(256) void tal_match_kernel(const float* raw, int A,
 __global__ __launch_bounds__(kAssignThreads) void tal_resolve_kernel(const float* raw, int A, int nc, const float* labels,
                                                                      int max_labels, TalGeom geom, int use_l1, unsigned char* ws,
                                                                      TalLayout L) {
+    SY_TL_BEGIN(14);
     __shared__ float s_gt[kMaxGT][4];
     __shared__ int s_gcls[kMaxGT];
     __shared__ float s_w[kMaxGT];
@@ -394,12 +399,14 @@ __global__ __launch_bounds__(kAssignThreads) void tal_resolve_kernel(const float
         for (int w = 0; w < NW; ++w) v += s_red[w][tid];
         W.part[tid] = v;
     }
+    SY_TL_END();
 }
 
 __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, int A, int nc, const float* labels,
                                                        int max_labels, TalGeom geom, float gamma, int use_l1,
                                                        const unsigned char* ws, TalLayout L,
                                                        float* d_raw, float* losses, int* fg_mask, void* d_pad, int pad_dtype) {
+    SY_TL_BEGIN(14);
     __shared__ float s_tot[8];
     __shared__ float s_acc[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -522,6 +529,7 @@ __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, 
         losses[6] = num_fg;
         losses[7] = num_gt;
     }
+    SY_TL_END();
 }
 
 __global__ void tal_zero_losses_kernel(float* losses) {
@@ -572,3 +580,4 @@ extern "C" int sy_tal_loss(const float* raw, int B, int A, int num_classes, cons
               use_l1, (const unsigned char*)workspace, L, d_raw, losses, fg_mask, d_pad, pad_dtype);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
+SY_PROBE_READER(sy_probe_read_tal_loss)

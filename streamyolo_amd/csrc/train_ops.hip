@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kBlock) void spp_pool_kernel(typename T::elem* buf,
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem* buf, int H, int W, int C, int ld,
                                                                long long bs, unsigned char* argmax) {
+    SY_TL_BEGIN(15);
     typedef typename T::elem elem;
     constexpr int E = T::kEPC;
     SY_DYN_SMEM(smem);
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem*
                 __builtin_memcpy(argmax + (((long long)n * HW + p) * 3 + l) * C + cc * E, a, E);
         }
     }
+    SY_TL_END();
 }
 
 // backward (gather form, deterministic, no atomics): source pixel (h,w) collects the pooled gradient of
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_kernel(typename T::elem* 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::elem* dbuf, const unsigned char* argmax,
                                                                    int H, int W, int C, int ld, long long bs) {
+    SY_TL_BEGIN(15);
     typedef typename T::elem elem;
     constexpr int E = T::kEPC;
     SY_DYN_SMEM(smem);
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::e
         for (int j = 0; j < E; ++j) o.e[j] = T::from_f32(acc[j]);
         o.store(gslot0);
     }
+    SY_TL_END();
 }
 
 // ---- training-mode BatchNorm -------------------------------------------------------------------------
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, c
                                                              float eps, float momentum, float* running_mean,
                                                              float* running_var, float* scale, float* shift,
                                                              float* mean_out, float* invstd_out) {
+    SY_TL_BEGIN(11);
     __shared__ float s_s[8][32], s_q[8][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -334,11 +339,13 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, c
         running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
         running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+    SY_TL_END();
 }
 
 // Running statistics of every BatchNorm of the step in one launch (sy_bn_running_update): workgroup = (entry,
 // 32-channel block); the replica fold repeats bn_finalize_kernel's order so both see the same batch statistics.
 __global__ __launch_bounds__(kBlock) void bn_running_update_kernel(const sy_bn_running_entry* entries) {
+    SY_TL_BEGIN(15);
     __shared__ float s_s[8][32], s_q[8][32];
     const sy_bn_running_entry e = entries[blockIdx.x];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -368,12 +375,14 @@ __global__ __launch_bounds__(kBlock) void bn_running_update_kernel(const sy_bn_r
         __syncthreads();
     }
     if (rg == 0 && c < e.C) { e.running_mean[c] = rm; e.running_var[c] = rv; }
+    SY_TL_END();
 }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T::elem* y, int ldy, const float* scale,
                                                                const float* shift, const typename T::elem* res, int ldr,
                                                                typename T::elem* out, int ldo, long long pixels, int C) {
+    SY_TL_BEGIN(10);
     const int cpp = C / T::kEPC;
     const int cc = threadIdx.x % cpp;
     const int c0 = cc * T::kEPC;
@@ -419,6 +428,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
         for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
         o.store(out + pix * ldo + c0);
     }
+    SY_TL_END();
 }
 
 // bn_finalize + bn_silu_apply in ONE launch.  A dependent launch on the step's critical path costs ~13 us whatever it does
@@ -436,6 +446,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_apply_kernel(const float* 
                                                                    const typename T::elem* res, int ldr,
                                                                    typename T::elem* out, int ldo, long long pixels, int C,
                                                                    int CS) {
+    SY_TL_BEGIN(10);
     __shared__ float s_part[2][8][64];
     __shared__ float s_aff[2][64];
     const int cpp = CS / T::kEPC;
@@ -504,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_apply_kernel(const float* 
         o.store(out + pix * ldo + c0);
         v = vn; rv = rn;
     }
+    SY_TL_END();
 }
 
 // reduce: sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat.  Thread = (pixel row, channel chunk); register
@@ -518,6 +530,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
                                                                     const float* scale, const float* shift,
                                                                     const float* mean, const float* invstd, float* sums,
                                                                     long long pixels, int C, int CS, int copies) {
+    SY_TL_BEGIN(12);
     __shared__ float red[kBlock * 2 * 8];
     const int cpp = CS / T::kEPC;
     const int rows = kBlock / cpp;
@@ -577,6 +590,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_reduce_kernel(const typena
         atomicAdd(sums + (long long)(blockIdx.x % copies) * 2 * C + kind * C + cb + ch * T::kEPC + j, v);
     }
     sy_probe(6);
+    SY_TL_END();
 }
 
 template <typename T>
@@ -589,6 +603,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
                                                                    int C, int copies, float* dgamma, float* dbeta,
                                                                    long long seg_sum_stride, typename T::elem* dres,
                                                                    int lddres, int dres_acc) {
+    SY_TL_BEGIN(13);
     // fold the replicas of the two reduction sums once per workgroup, cooperatively, through LDS
     __shared__ float s_fold[2 * 1024];
     {   // segment blockIdx.y
@@ -662,6 +677,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
             gv.store(dst);
         }
     }
+    SY_TL_END();
 }
 
 // sums[0][i] = sum over replicas k of sums[k][i]  (i in [0, 2C)): run once before the apply pass

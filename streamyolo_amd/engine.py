@@ -98,6 +98,9 @@ class FocusOp:
 # csrc/bottleneck_fused.h).  "0": never; "force": wherever the kernel applies (tests, the emulator has no tuner).
 FUSE_BOTTLENECKS = os.environ.get("STREAMYOLO_FUSE_BOTTLENECKS", "1")
 FUSE_BOTTLENECKS = False if FUSE_BOTTLENECKS == "0" else FUSE_BOTTLENECKS
+# Streaming step (launch tape, batch 1): the three detection levels — their DFP fusion convs and head towers — leave the main
+# chain as soon as their PAN output exists and run on chains 1 / 2 beside the rest of the bottom-up path ("0": one chain).
+STREAM_CHAINS = os.environ.get("STREAMYOLO_STREAM_CHAINS", "1") != "0"
 # test hook: "S,tile" forces a split-K decision for every eligible layer (the emulator has no tuner)
 FORCE_SPLIT_K = tuple(int(v) for v in os.environ["STREAMYOLO_FORCE_SPLIT_K"].split(",")) if os.environ.get("STREAMYOLO_FORCE_SPLIT_K") else None
 
@@ -389,6 +392,50 @@ class InferencePlan:
         for op in self.ops[self.n_backbone_ops:]:                 # head ops: per-level towers end with their PredOp
             op.level = lvl
             lvl += 1 if op.kind == "pred" else 0
+        for op in self.ops:
+            op.chain = 0
+        self._chain_streams = None
+        self._stream_order = self._chained_order() if (STREAM_CHAINS and not self.pair and pafpn is not None and head is not None) else None
+
+    def _chained_order(self):
+        """Issue order of the streaming step over three chains: a list of ("op", op, chain, part) and ("dep", from, to).  Level k's
+        fusion convs and head ops (chain 1 for the stride-8 level, 2 for stride 16, the main chain for stride 32) follow the
+        op that produces PAN output k instead of the end of the neck: the stride-8 head (the largest) runs beside C3_n3 /
+        C3_n4, the stride-16 head beside C3_n4.  The stride-32 level is the tail of the frame: its cls tower (second conv +
+        prediction launch) forks to chain 1, idle by then.  Every op keeps its own output buffer, so any topological order
+        computes the same frame."""
+        n_fuse = 6
+        neck = self.ops[:self.n_backbone_ops - n_fuse]
+        fuse = self.ops[self.n_backbone_ops - n_fuse:self.n_backbone_ops]
+        head = self.ops[self.n_backbone_ops:]
+        last = {}                                                   # level -> index of the neck op that writes its PAN output
+        for k, pan in enumerate(self.cur_pans):
+            idx = [i for i, op in enumerate(neck) if op.kind == "conv" and op.y.buf is pan.buf and op.y.c_off == pan.c_off]
+            last[k] = idx[-1]
+        order, at = [], 0
+        for k in range(3):
+            order += [("op", op, 0, None) for op in neck[at:last[k] + 1]]
+            at = last[k] + 1
+            chain = (1, 2, 0)[k]
+            level = fuse[2 * k:2 * k + 2] + [op for op in head if op.level == k]
+            if chain:
+                order.append(("dep", 0, chain))
+                order += [("op", op, chain, None) for op in level]
+                continue
+            cls1 = [op for op in level if op.kind == "conv" and op.tag == "head.cls%d.1" % k]
+            pred = level[-1]
+            assert len(cls1) == 1 and pred.kind == "pred" and pred.cls_x.buf is cls1[0].y.buf
+            shared = [op for op in level[:-1] if op is not cls1[0] and not op.tag.startswith("head.reg%d.1" % k)]
+            reg1 = [op for op in level[:-1] if op.tag.startswith("head.reg%d.1" % k)]
+            order += [("op", op, 0, None) for op in shared]
+            order += [("dep", 0, 1), ("op", cls1[0], 1, None), ("op", pred, 1, "cls")]
+            order += [("op", op, 0, None) for op in reg1] + [("op", pred, 0, "reg")]
+        assert at == len(neck)
+        order += [("dep", 1, 0), ("dep", 2, 0)]
+        for e in order:
+            if e[0] == "op" and e[3] is None:
+                e[1].chain = e[2]
+        return order
 
     def _mark(self, kind, arg=None):
         if self._rec is not None:
@@ -419,9 +466,17 @@ class InferencePlan:
                     need = max(need, dec[0] * op.y.pixels * op.y.C)
         # the fp32 partial-sum scratch is sized HERE, once, for the largest split decision of the plan: a tape that is being
         # recorded holds its raw pointer, so it must not be re-allocated in the middle of a recording
-        if need and (self._splitk_ws is None or self._splitk_ws.numel() < need):
-            self._splitk_ws = torch.empty(max(need, 4 << 20), dtype=torch.float32, device=self.device)
-            self._stream_tape = None
+        if need:
+            self._splitk_grow(need)
+
+    def _splitk_grow(self, need):
+        """fp32 partial-sum scratch, one row per chain (chains run concurrently).  True if it was (re-)allocated."""
+        if self._splitk_ws is not None and self._splitk_ws.shape[1] >= need:
+            return False
+        self._splitk_ws = torch.empty((3 if self._stream_order is not None else 1, max(need, 4 << 20)), dtype=torch.float32,
+                                      device=self.device)
+        self._stream_tape = None                                     # recorded pointers are stale
+        return True
 
     # -- execution --------------------------------------------------------------------------------
     def _fuse_decision(self, op):
@@ -436,7 +491,8 @@ class InferencePlan:
                                                                 op.res is not None, self.device, pre.tile("fwd"), op.tile("fwd")))
         return dec
 
-    def _run_op(self, op):
+    def _run_op(self, op, part=None):
+        """part: "reg" / "cls" = only that launch of a PredOp (the towers of a level on two chains)."""
         if op.kind == "conv":
             if op.fused_into is not None and self._fuse_decision(op.fused_into):
                 return                                                  # computed inside the 3x3 launch that reads it
@@ -451,12 +507,9 @@ class InferencePlan:
             t = op.tile("fwd")
             dec = self._split_decision(op, t) if self._in_stream else (1, t)
             if dec[0] > 1:
-                need = dec[0] * op.y.pixels * op.y.C
-                if self._splitk_ws is None or self._splitk_ws.numel() < need:      # (a decision made after _ensure_tuned ran)
-                    self._splitk_ws = torch.empty(max(need, 4 << 20), dtype=torch.float32, device=self.device)
-                    self._stream_tape = None                            # recorded pointers are stale ...
-                    self._ws_grew = True                                # ... and so are those of a recording that is open NOW
-                ops.conv2d_splitk(op.x, w, op.y, op.k, op.stride, scale, shift, self._splitk_ws, dec[0], res=op.res,
+                if self._splitk_grow(dec[0] * op.y.pixels * op.y.C):   # (a decision made after _ensure_tuned ran)
+                    self._ws_grew = True                                # the pointers of a recording that is open NOW are stale too
+                ops.conv2d_splitk(op.x, w, op.y, op.k, op.stride, scale, shift, self._splitk_ws[op.chain], dec[0], res=op.res,
                                   epilogue=EPI_SILU, tile=dec[1], wfrag=self.cache.conv_weight_frag(op.mod))
                 return
             ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU, tile=t,
@@ -471,10 +524,12 @@ class InferencePlan:
             base = self.out.data_ptr() + op.a0 * nch * 4
             ybs = self.A * nch
             dec = self.decode
-            ops.conv2d(op.reg_x, w_ro, None, 1, 1, None, b_ro, epilogue=EPI_DECODE if dec else EPI_LINEAR,
-                       dec_stride=op.stride, y_f32=True, y_ptr=base, y_ld=nch, y_bs=ybs, cout=5)
-            ops.conv2d(op.cls_x, w_c, None, 1, 1, None, b_c, epilogue=EPI_SIGMOID, y_f32=True,
-                       y_ptr=base + 5 * 4, y_ld=nch, y_bs=ybs, cout=self.nc)
+            if part != "cls":
+                ops.conv2d(op.reg_x, w_ro, None, 1, 1, None, b_ro, epilogue=EPI_DECODE if dec else EPI_LINEAR,
+                           dec_stride=op.stride, y_f32=True, y_ptr=base, y_ld=nch, y_bs=ybs, cout=5)
+            if part != "reg":
+                ops.conv2d(op.cls_x, w_c, None, 1, 1, None, b_c, epilogue=EPI_SIGMOID, y_f32=True,
+                           y_ptr=base + 5 * 4, y_ld=nch, y_bs=ybs, cout=self.nc)
         else:
             raise AssertionError(op.kind)
 
@@ -523,6 +578,26 @@ class InferencePlan:
             ops.focus_pack(x.float().contiguous(), 0, self.f0)
         n_fuse = 6
         self._in_stream = True
+        if self._rec is not None and self._stream_order is not None and not first:
+            # launch tape: the chained issue order (one stream while recording; sy_tape_replay_n spreads it over the chains)
+            try:
+                chain = 0
+                for e in self._stream_order:
+                    if e[0] == "dep":
+                        self._mark("dep", (e[1], e[2]))
+                        continue
+                    if e[2] != chain:
+                        chain = e[2]
+                        self._mark("cur", chain)
+                    self._run_op(e[1], e[3])
+                self._mark("cur", 0)
+                if not self.decode:
+                    ops.head_decode(self.out, boxes=False, obj_sigmoid=True)
+            finally:
+                self._in_stream = False
+            for dst, s in zip(self.sup_in, self.cur_pans):
+                ops.view_copy(s, dst)
+            return self.out
         try:
             for op in self.ops[:self.n_backbone_ops - n_fuse]:
                 self._run_op(op)
@@ -595,7 +670,12 @@ class InferencePlan:
             # results are correct (the wrappers ran with the pointers of their moment), the tape is not kept
             self._stream_tape = None if self._ws_grew else (sig, post, tape, res)
             return res
-        prog[2].replay(ops.stream_of(self.out), None)
+        if self._stream_order is None or not self.out.is_cuda:
+            prog[2].replay(ops.stream_of(self.out), None)
+        else:
+            if self._chain_streams is None:
+                self._chain_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            prog[2].replay(ops.stream_of(self.out), self._chain_streams[0].cuda_stream, more=(self._chain_streams[1].cuda_stream,))
         return prog[3]
 
     def export_buffer(self):

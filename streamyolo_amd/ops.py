@@ -488,7 +488,7 @@ class _TuneStore:
         h = hashlib.sha256()
         h.update(_lib.kernel_source_key().encode())
         h.update(_lib.lib().sy_version())
-        h.update(repr((HALO_TILES, HALO_S2_TILES, TILE_1X1K, WGRAD_EXTRA)).encode())          # candidate-set switches (A/B runs)
+        h.update(repr((HALO_TILES, HALO_SMALL_TILES, HALO_S2_TILES, TILE_1X1K, WGRAD_EXTRA)).encode())          # candidate-set switches (A/B runs)
         # (no device name in the key: this library is gfx950-only, and torch reports an empty name under rocprofv3 — a profiled
         #  run then overwrote the cache of the normal runs with its own)
         return h.hexdigest()[:16]
@@ -545,6 +545,9 @@ HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,
 # stride-2 3x3 layers on the window-in-LDS kernels (tile codes 110 = forward, 108 = data gradient).  Measured in round 4
 # (profiles/r04/a_probe_s2_*.txt): forward 421 vs 395 (dark2.0) / 739 vs 585 TF/s (dark4.0) against the best implicit-GEMM
 # variant, data gradient 245 vs 250 / 504 vs 484; l step 22.61 vs 22.70 ms (b_bench_s2 / b_bench_base) — candidates by default
+# launches of few pixels (one streamed frame; the 19x30 maps of a training batch): one MFMA tile per wave, more workgroups
+HALO_SMALL_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_SMALL_TILES", "112,113").replace("+", ",").split(",") if t]
+HALO_SMALL_PIXELS = 12000
 HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "110,108").replace("+", ",").split(",") if t]
 TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123").split(",") if t]
 
@@ -601,6 +604,8 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     if k == 3 and stride == 1 and wf is not None and HALO_TILES:
         # 3x3 stride-1 layers: the halo-resident kernel (csrc/conv3x3_halo.h), tiles of 64 / 128 / 256 channels
         cands += [t for t in HALO_TILES if not (t == 116 and Cout > 64)]
+        if N * Ho * Wo <= HALO_SMALL_PIXELS:
+            cands += HALO_SMALL_TILES
     if k == 3 and stride == 2 and wf is not None and Cin % (16 if code == DT_F32 else 32) == 0:
         cands += [t for t in HALO_S2_TILES if (t == 108) == (mode == CONV_DGRAD)]     # 110: forward, 108: data gradient
     if k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256, 512, 1024, 2048) and code != DT_F32:
@@ -657,7 +662,7 @@ def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile):
     for S in (2, 4):
         if S > Cin // (4 * epc):
             continue
-        for t in (117, 118):
+        for t in (117, 118, 113, 112):
             try:
                 run = lambda: conv2d_splitk(x, w, y, 3, 1, scale, shift, part, S, epilogue=EPI_SILU, tile=t, wfrag=wf)   # noqa: E731
                 run()

@@ -945,6 +945,14 @@ class TrainPlan:
             cap = int(os.environ.get("STREAMYOLO_WGRAD_BLOCKS_CAP", "512"))
             if cap > 0 and wt[1] > cap:
                 wt = (wt[0], cap)
+            # the all-nine-taps kernel holds 464 registers per lane: one workgroup owns a CU's register file, so a 256-
+            # workgroup launch shuts every other chain out of the chip for its ~75 us (the launch timeline shows 1.7 ms per
+            # step with nothing but this kernel resident).  128 workgroups leave half the CUs to the main chains: the kernel
+            # itself takes ~1.8x as long on its side stream, the step is 0.6 ms shorter (22.4-22.8 -> 21.8-22.1 ms; 96 the
+            # same, 64 / 192 / 384 worse — profiles/r04 stage s)
+            cap9 = int(os.environ.get("STREAMYOLO_WGRAD9_BLOCKS", "128"))
+            if cap9 > 0 and wt[0] in (49, 65) and wt[1] > cap9:
+                wt = (wt[0], cap9)
             op._tiles[key] = wt
         if w.shape[1] == x.C:
             ops.conv2d_wgrad(x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self._ws(),

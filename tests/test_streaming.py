@@ -152,6 +152,60 @@ def test_stream_tape_follows_changed_weights_and_inputs(backend):
         assert plan._stream_tape[2] is not tape1
 
 
+def test_stream_tape_issue_order_over_three_chains(backend):
+    """The taped streaming step issues level k's fusion convs + head towers right behind the op that writes PAN output k, on
+    chains 1 / 2 / 0 (the last level's cls tower forks to chain 1): every launch exactly once, every reader after its writers, both
+    side chains joined before the step ends."""
+    import streamyolo_amd as sy
+    from oracle import streamyolo_oracle as O
+    from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, load_bn_stats
+    cfg = O.OracleConfig.named("nano")
+    model = sy.build_model("nano")
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=load_bn_stats("nano")), strict=True)
+    model = model.to(backend).eval().set_compute_dtype("fp32")
+    x = synth_frames(1, 32, 64, seed=2)[:, 0:3].contiguous().to(backend)
+    plan = model._plans.inference(model.backbone, model.head, "on_pipe", x, owner=model)
+    order = plan._stream_order
+    issued = [e for e in order if e[0] == "op"]
+    whole = [e[1] for e in issued if e[3] is None]
+    halves = [e for e in issued if e[3] is not None]
+    assert [(e[1].level, e[3], e[2]) for e in halves] == [(2, "cls", 1), (2, "reg", 0)] and halves[0][1] is halves[1][1]
+    assert len(whole) + 1 == len(plan.ops) and {id(op) for op in whole} | {id(halves[0][1])} == {id(op) for op in plan.ops}
+    assert [e for e in order if e[0] == "dep"] == [("dep", 0, 1), ("dep", 0, 2), ("dep", 0, 1), ("dep", 1, 0), ("dep", 2, 0)]
+    written = set()                                              # (buffer, channel) written so far
+
+    def chans(v):
+        return {(v.buf.data_ptr(), c) for c in range(v.c_off, v.c_off + v.C)}
+    for _, op, chain, part in issued:
+        if op.kind == "conv":
+            reads = [op.x] + ([op.res] if op.res is not None else [])
+        elif op.kind == "pred":
+            reads = [op.cls_x] if part == "cls" else [op.reg_x]
+        else:
+            reads = [op.src] if op.kind == "resize" else []
+        for v in reads:
+            if v.buf is plan.f0.buf or any(v.buf is s.buf for s in plan.sup_in):
+                continue                                         # the packed frame / last frame's PAN outputs: written before the step
+            assert chans(v) <= written, getattr(op, "tag", op.kind)
+        if op.kind == "conv":
+            written |= chans(op.y)
+        elif op.kind == "resize":
+            written |= chans(op.dst)
+        elif op.kind == "spp":
+            written |= chans(op.v)
+    assert {e[2] for e in issued if getattr(e[1], "level", None) == 0} == {1}
+    assert {e[2] for e in issued if getattr(e[1], "level", None) == 1} == {2}
+    with torch.no_grad():
+        plan.run_stream(x, first=True)
+        want = plan.run_stream(x).clone()
+        plan.run_stream_taped(x)
+        plan.out.zero_()
+        assert torch.equal(plan.run_stream_taped(x), want)
+        if backend.type == "cuda":
+            ev, waits = plan._stream_tape[2].counters()
+            assert ev == 5 and waits == 5, (ev, waits)
+
+
 def test_streaming_step_with_split_k_layers(backend, monkeypatch):
     """allow_split_k (StreamingDetector's 16-bit modes, bench.py --workload stream): the deep 3x3 layers run as channel-slab
     ranges + sy_splitk_epilogue.  Only the fp32 summation order differs from the single-pass kernels, so the decoded outputs

@@ -29,12 +29,15 @@ ap.add_argument("--shape", type=int, default=10)
 ap.add_argument("--tile", type=int, default=117)
 ap.add_argument("--mode", default="stats", choices=["fwd", "stats", "dgrad"])
 ap.add_argument("--half", type=int, default=1, help="1: one frame's launch (N / 2 images), as the chain schedule issues it")
+ap.add_argument("--batch", type=int, default=0, help="images in the launch (overrides the table's batch and --half): 1 = the streaming step")
 ap.add_argument("--blocks", type=int, default=256, help="wgrad: split-K target workgroups")
 a = ap.parse_args()
 lib = _lib.lib()
 dev = torch.device("cuda:0")
 name, N, Ho, Wo, cin, cout, k, st = SHAPES[a.shape]
-if a.half:
+if a.batch:
+    N = a.batch
+elif a.half:
     N //= 2
 H, W = Ho * st, Wo * st
 g = torch.Generator().manual_seed(1)
