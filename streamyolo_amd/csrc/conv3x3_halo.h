@@ -200,8 +200,15 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : 2)) void conv3x3_
 //     are parked with the columns split by parity — LDS row of input pixel (hy, hx) = hy * 66 + (hx & 1) * 33 + (hx >> 1) — so
 //     that the 32 lanes of a tap (input column 2 * lane + kw) read 32 CONSECUTIVE rows exactly as at stride 1 (same XOR swizzle,
 //     conflict free), and the parity split costs nothing: every DMA lane picks its own global pixel anyway.
-template <typename T, int WC, int WP, int TC, int TP, int S2 = 0>
-__global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1 : 2))) void conv3x3_halo2_kernel(ConvArgs p) {
+//   * KS > 1 (small launches, forward): the workgroup's waves are KS groups of WC x WP, group g contracting channel slabs g, g + KS,
+//     ... of the workgroup's range into its own accumulators from its own pair of LDS buffers — every wave still fetches only the
+//     weights of ITS channels x ITS slabs, so the bytes a wave must pull through its 72-register fragment window halve (KS = 2)
+//     or quarter: at batch 1 the main loop is bound by exactly that (one wave per SIMD, ~18 KB in flight per wave; 113's eight
+//     waves that DUPLICATE the weights are slower than 117's four — profiles/r04 stage ad).  The groups' partial tiles are
+//     summed through LDS in group order (deterministic), groups > 0 exit, group 0 runs the ordinary epilogue.
+template <typename T, int WC, int WP, int TC, int TP, int S2 = 0, int KS = 1>
+__global__ __launch_bounds__(WC * WP * KS * 64, (KS > 1 ? (WC * WP * KS <= 4 ? 3 : 1) : (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1 : 2))))
+void conv3x3_halo2_kernel(ConvArgs p) {
     SY_TL_BEGIN(2 + (p.mode == SY_CONV_DGRAD ? 32 : 0));
     constexpr int NW = WC * WP;
     constexpr int EPC = T::kEPC;
@@ -214,13 +221,15 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;
     constexpr int BUF = NW * NI * 16 * 64;
     constexpr int BD = (TC * TP <= 2) ? SY_HALO2_BD : 3;   // pixel-fragment ring: BD - 1 (tap, k-half) steps of reads in flight
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NW == 4 || NW == 8 || (KS > 1 && NW <= 2), "4 or 8 waves (1 or 2 per K group)");
     static_assert(NI <= 9, "one DMA piece per tap");
 
     SY_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = sy_uniform(tid >> 6);
+    const int wave_all = sy_uniform(tid >> 6);
+    const int kg = KS > 1 ? wave_all / NW : 0;             // K group of this wave
+    const int wave = KS > 1 ? wave_all % NW : wave_all;    // wave inside its group
     const int wc = wave / WP;
     const int wp = wave % WP;
     const int l31 = lane & 31;
@@ -252,11 +261,14 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     const int kz = ksplit > 1 ? bid.z : 0;
     const int cs_begin = sy_uniform((kz * ncs_all) / ksplit);
     const int ncs = sy_uniform(((kz + 1) * ncs_all) / ksplit);
-    auto issue_piece = [&](auto i_, int cslab) {           // piece I of slab `cslab` (out of range past the last slab)
+    // trip j of the slab loop: group kg contracts slab cs_begin + j * KS + kg (KS == 1: slab cs_begin + j) from LDS buffer j & 1 of its pair
+    const unsigned gbo = (unsigned)(kg * 2 * BUF);
+    auto issue_piece = [&](auto i_, int j) {               // piece I of trip j's slab (out of range past the last slab)
         constexpr int I = decltype(i_)::value;
+        const int cslab = cs_begin + j * KS + kg;
         const unsigned s_x = (unsigned)(cslab * BK * ESZ);
         const bool dead = voff[I] == 0xFFFFFFFFu || cslab >= ncs;
-        sy_glds16_buf_at(bufx, dead ? 0xFFFFFFFFu : voff[I] + s_x, lds0, (unsigned)((cslab & 1) * BUF + (wave + I * NW) * 1024));
+        sy_glds16_buf_at(bufx, dead ? 0xFFFFFFFFu : voff[I] + s_x, lds0, gbo + (unsigned)((j & 1) * BUF + (wave + I * NW) * 1024));
     };
 
     const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
@@ -268,8 +280,9 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
         foff[t] = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs_all * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
     }
     uint4 fr[9][TC][2];
-    auto fetch = [&](auto tap_, int cslab) {               // fragments of tap TAP of slab `cslab` into their slot
+    auto fetch = [&](auto tap_, int j) {                   // fragments of tap TAP of trip j's slab into their slot
         constexpr int TAP = decltype(tap_)::value;
+        const int cslab = cs_begin + j * KS + kg;
         const unsigned s_f = (unsigned)((cslab * 9 + TAP) * 2048);
         const bool live = cslab < ncs;
 #pragma unroll
@@ -302,14 +315,15 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     }
 
     sy_probe(0);
-    sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, cs_begin); });
-    sy_static_for<0, 9>([&](auto t_) { fetch(t_, cs_begin); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
+    sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, 0); });
+    sy_static_for<0, 9>([&](auto t_) { fetch(t_, 0); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
     sy_probe(1);
-    for (int cs = cs_begin; cs < ncs; ++cs) {
+    const int trips = (ncs - cs_begin + KS - 1) / KS;      // the same for every group (slabs past the range contribute zeros)
+    for (int j = 0; j < trips; ++j) {
         sy_wait_vmcnt<(9 - NI) * 2 * TC>();      // the slab's DMA pieces (older than the last (9 - NI) taps of fragment loads)
         sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
-        if (cs == cs_begin) sy_probe(2);
-        const unsigned hbo = (unsigned)((cs & 1) * BUF);
+        if (j == 0) sy_probe(2);
+        const unsigned hbo = gbo + (unsigned)((j & 1) * BUF);
         uint4 b[BD][TP];
         auto read_step = [&](auto s_) {
             constexpr int S = decltype(s_)::value;
@@ -328,14 +342,42 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
 #pragma unroll
                 for (int u = 0; u < TP; ++u) acc[t][u] = sy_mfma_group(T(), fr[TAP][t][G], b[S % BD][u], acc[t][u]);
             if constexpr (G == 1) {
-                fetch(sy_int<TAP>(), cs + 1);
-                if constexpr (TAP < NI) issue_piece(sy_int<TAP>(), cs + 1);
+                fetch(sy_int<TAP>(), j + 1);
+                if constexpr (TAP < NI) issue_piece(sy_int<TAP>(), j + 1);
             }
             sy_sched_fence();
         });
     }
     sy_wait_vmcnt<0>();                           // the out-of-range pieces of the slab after the last one
     sy_barrier();
+    if constexpr (KS > 1) {
+        // partial tiles of groups 1 .. KS-1 through LDS ([group - 1][wave][register][lane]: conflict-free), summed by group 0 in
+        // group order; the other groups' waves END here (an ended wave no longer counts at s_barrier)
+        float* const red = reinterpret_cast<float*>(smem);
+        constexpr int RW_ = TC * TP * 16;
+        if (kg > 0) {
+            float* const dst = red + ((size_t)((kg - 1) * NW + wave) * RW_) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int u = 0; u < TP; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((t * TP + u) * 16 + r) * 64] = acc[t][u][r];
+        }
+        sy_barrier();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            const float* const src = red + ((size_t)((g - 1) * NW + wave) * RW_) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int u = 0; u < TP; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][u][r] += src[((t * TP + u) * 16 + r) * 64];
+        }
+        sy_barrier();                             // (group 0 only from here on) the epilogue reuses the LDS
+    }
 
     SY_LATE_ARGS(ConvArgs, p);
     sy_probe(3);
@@ -359,9 +401,10 @@ __global__ __launch_bounds__(WC * WP * 64, (TC * TP <= 2 ? 3 : (TC * TP >= 8 ? 1
     SY_TL_END();
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int S2 = 0>
+template <typename T, int WC, int WP, int TC, int TP, int GEN = 1, int S2 = 0, int KS = 1>
 int launch_halo(const ConvArgs& a_in, void* stream) {
     constexpr int NW = WC * WP, CT = WC * TC * 32, TH = WP * TP, PT = TH * 32;
+    static_assert(KS == 1 || GEN == 2, "K groups: second-generation kernel");
     constexpr int HR = S2 ? (2 * TH + 1) * 66 : (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
     static_assert(!S2 || GEN == 2, "stride 2: second-generation kernel, forward");
     ConvArgs a = a_in;
@@ -375,33 +418,34 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
         if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return SY_ERR_UNSUPPORTED;
     }
     if (a.Cin % (4 * T::kEPC) != 0 || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
-    constexpr size_t smem_k = 2 * (size_t)BUF;
+    constexpr size_t smem_r = (size_t)(KS - 1) * NW * 64 * TC * TP * 16 * 4;      // K groups: partial tiles of groups 1 .. KS-1
+    constexpr size_t smem_k = (size_t)KS * 2 * BUF > smem_r ? (size_t)KS * 2 * BUF : smem_r;
     constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
     constexpr bool can_stage = (T::kEPC == 8 && smem_e <= StageLimit<WC, WP, TC, TP>::kBytes);
     constexpr size_t smem_s = (size_t)WP * CT * 8;            // statistics scratch of the un-staged epilogue
     constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
     const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
-    if (a.ksplit > 1 && (GEN != 2 || a.ksplit > a.Cin / (4 * T::kEPC))) return SY_ERR_UNSUPPORTED;
+    if (a.ksplit > 1 && (GEN != 2 || KS > 1 || a.ksplit > a.Cin / (4 * T::kEPC))) return SY_ERR_UNSUPPORTED;
     dim3 grid((a.Cout + CT - 1) / CT, tiles, a.ksplit > 1 ? a.ksplit : 1);
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {
         const void* fn;                                        // (if constexpr: only the generation this tile code launches is instantiated)
-        if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, S2>;
+        if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, S2, KS>;
         else fn = (const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
     if constexpr (GEN == 2) {
-        SY_LAUNCH((conv3x3_halo2_kernel<T, WC, WP, TC, TP, S2>), grid, dim3(NW * 64), smem, stream, a);
+        SY_LAUNCH((conv3x3_halo2_kernel<T, WC, WP, TC, TP, S2, KS>), grid, dim3(NW * KS * 64), smem, stream, a);
     } else {
         SY_LAUNCH((conv3x3_halo_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);
     }
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-// tile codes 110, 112..118 of sy_conv_desc::tile
+// tile codes 105, 106, 110..118 of sy_conv_desc::tile
 template <typename T>
 int launch_halo_typed(const ConvArgs& a, void* stream) {
     switch (a.tile) {
@@ -415,6 +459,11 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         // of 117 per wave, and (112) twice the workgroups over which the layer's weights are fetched
         case 112: return launch_halo<T, 2, 2, 1, 1, 2>(a, stream);  //  64 ch x ( 2 rows x 32 px), 4 waves
         case 113: return launch_halo<T, 4, 2, 1, 1, 2>(a, stream);  // 128 ch x ( 2 rows x 32 px), 8 waves
+        // K groups inside the workgroup (the fp32 summation order differs from the other tiles': plans opt in)
+        case 111: return launch_halo<T, 2, 1, 1, 2, 2, 0, 2>(a, stream);  //  64 ch x (2 rows x 32 px), 2 groups of 2 waves
+        // (64 ch x 4 groups and 128 ch x 2 groups measured no better than 111 / 117: the main loop follows the weight bytes per CU)
+        case 106: return launch_halo<T, 1, 1, 1, 2, 2, 0, 4>(a, stream);  //  32 ch x (2 rows x 32 px), 4 groups of 1 wave
+        case 105: return launch_halo<T, 4, 1, 1, 2, 2, 1, 2>(a, stream);  // STRIDE 2 forward (110's tile), 2 groups of 4 waves
         // STRIDE 2, forward (tile 117's configuration over a parity-split input window): +7 % / +26 % over the implicit-GEMM
         // variants on dark2.0 / dark4.0 (profiles/r04/a_probe_s2_stats.txt)
         case 110: return launch_halo<T, 4, 1, 1, 2, 2, 1>(a, stream);

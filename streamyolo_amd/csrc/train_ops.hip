@@ -76,13 +76,14 @@ __global__ __launch_bounds__(kBlock) void spp_pool_kernel(typename T::elem* buf,
 // maximum of the row-major scan above, so pooled values AND arg-max bytes are bit-identical to
 // spp_pool_kernel with 13 + 27 LDS reads per pixel instead of 169 global loads.
 // LDS layout: in[HW] chunks | rv[3][HW] chunks (row maxima) | ra[3][HW][kEPC] bytes (dw + 6 of the row maximum).
-template <typename T>
-__global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem* buf, int H, int W, int C, int ld,
-                                                               long long bs, unsigned char* argmax) {
-    SY_TL_BEGIN(15);
+// LSEL >= 0: only pooling level LSEL (5 + 4 LSEL wide) — the eval launch of a small batch runs the three levels as three
+// workgroups per channel chunk (gridDim.y = 3: 64 workgroups of 39 us -> 192 of ~15 at one streamed frame); same arithmetic.
+template <typename T, int LSEL>
+__device__ __forceinline__ void spp_pool_tile_body(typename T::elem* buf, int H, int W, int C, int ld, long long bs,
+                                                   unsigned char* argmax, unsigned char* smem) {
     typedef typename T::elem elem;
     constexpr int E = T::kEPC;
-    SY_DYN_SMEM(smem);
+    constexpr int L0 = LSEL < 0 ? 0 : LSEL, L1 = LSEL < 0 ? 3 : LSEL + 1, RH = 2 * L1;
     const int HW = H * W;
     const int cpp = C / E;
     const int cc = blockIdx.x % cpp, n = blockIdx.x / cpp;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem*
         for (int l = 0; l < 3; ++l)
 #pragma unroll
             for (int j = 0; j < E; ++j) { m[l][j] = -INFINITY; a[l][j] = 6; }
-        for (int dw = -6; dw <= 6; ++dw) {
+        for (int dw = -RH; dw <= RH; ++dw) {
             const int ww = w + dw;
             if (ww < 0 || ww >= W) continue;
             const int aw = dw < 0 ? -dw : dw;
@@ -108,13 +109,13 @@ __global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem*
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 const float v = T::to_f32(c.e[j]);
-                if (v > m[2][j]) { m[2][j] = v; a[2][j] = (unsigned char)(dw + 6); }
-                if (aw <= 4 && v > m[1][j]) { m[1][j] = v; a[1][j] = (unsigned char)(dw + 6); }
-                if (aw <= 2 && v > m[0][j]) { m[0][j] = v; a[0][j] = (unsigned char)(dw + 6); }
+                if (L1 == 3 && v > m[2][j]) { m[2][j] = v; a[2][j] = (unsigned char)(dw + 6); }
+                if (L0 <= 1 && L1 >= 2 && aw <= 4 && v > m[1][j]) { m[1][j] = v; a[1][j] = (unsigned char)(dw + 6); }
+                if (L0 == 0 && aw <= 2 && v > m[0][j]) { m[0][j] = v; a[0][j] = (unsigned char)(dw + 6); }
             }
         }
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
+        for (int l = L0; l < L1; ++l) {
             Chunk<T> o;
 #pragma unroll
             for (int j = 0; j < E; ++j) o.e[j] = T::from_f32(m[l][j]);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem*
         const int w = p % W, h = p / W;
         elem* dst = base + (long long)p * ld;
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
+        for (int l = L0; l < L1; ++l) {
             const int r = 2 * (l + 1);
             float m[E];
             unsigned char a[E];
@@ -154,6 +155,17 @@ __global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem*
                 __builtin_memcpy(argmax + (((long long)n * HW + p) * 3 + l) * C + cc * E, a, E);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem* buf, int H, int W, int C, int ld,
+                                                               long long bs, unsigned char* argmax) {
+    SY_TL_BEGIN(15);
+    SY_DYN_SMEM(smem);
+    if (gridDim.y == 1) spp_pool_tile_body<T, -1>(buf, H, W, C, ld, bs, argmax, smem);
+    else if (blockIdx.y == 0) spp_pool_tile_body<T, 0>(buf, H, W, C, ld, bs, argmax, smem);
+    else if (blockIdx.y == 1) spp_pool_tile_body<T, 1>(buf, H, W, C, ld, bs, argmax, smem);
+    else spp_pool_tile_body<T, 2>(buf, H, W, C, ld, bs, argmax, smem);
     SY_TL_END();
 }
 
@@ -732,7 +744,7 @@ extern "C" int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_
     const size_t tile_lds = (size_t)H * W * (16 + 3 * 16 + 3 * e);      // in | row maxima | row arg-max bytes
     if (tile_lds <= kSppTileLds && !spp_force_scan()) {
         SY_DISPATCH_DTYPE(dtype, if (!spp_lds_ok((const void*)spp_pool_tile_kernel<T>, T::kCode)) return SY_ERR_LAUNCH;
-                          SY_LAUNCH((spp_pool_tile_kernel<T>), dim3(N * (C / e)), dim3(kBlock), tile_lds, stream,
+                          SY_LAUNCH((spp_pool_tile_kernel<T>), dim3(N * (C / e), N * (C / e) < 256 ? 3 : 1), dim3(kBlock), tile_lds, stream,
                                     (typename T::elem*)buf, H, W, C, ld, (long long)bs, (unsigned char*)argmax));
     }
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((spp_pool_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream,

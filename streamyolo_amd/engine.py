@@ -443,11 +443,12 @@ class InferencePlan:
 
     def _split_decision(self, op, t):
         """(splits, tile) of a streaming-step conv: (1, t) = the ordinary single-pass launch."""
-        if not (self.allow_split_k and op.k == 3 and op.stride == 1 and op.y.bs_ is None and (op.res is None or op.res.bs_ is None)):
+        if not (self.allow_split_k and op.k == 3 and op.stride in (1, 2) and op.y.bs_ is None and (op.res is None or op.res.bs_ is None)):
             return (1, t)
         dec = op._tiles.get("splitk")
         if dec is None:
-            dec = FORCE_SPLIT_K or ops.tuned_splitk(op.x.dtype, op.x.N, op.x.H, op.x.W, op.x.C, op.y.C, self.device, t)
+            dec = (FORCE_SPLIT_K if op.stride == 1 else None) or \
+                ops.tuned_splitk(op.x.dtype, op.x.N, op.x.H, op.x.W, op.x.C, op.y.C, self.device, t, op.stride)
             if dec[0] > 1 and op.x.C // (16 if op.x.dtype == ops.DT_F32 else 32) < dec[0]:
                 dec = (1, t)
             op._tiles["splitk"] = dec
@@ -459,9 +460,9 @@ class InferencePlan:
         need = 0
         for op in self.ops:
             if op.kind == "conv":
+                dec = self._split_decision(op, op.tile("fwd"))
                 if op.pre_op is not None:
                     self._fuse_decision(op)
-                dec = self._split_decision(op, op.tile("fwd"))
                 if dec[0] > 1:
                     need = max(need, dec[0] * op.y.pixels * op.y.C)
         # the fp32 partial-sum scratch is sized HERE, once, for the largest split decision of the plan: a tape that is being
@@ -487,8 +488,11 @@ class InferencePlan:
             return False
         dec = op._tiles.get("fuse")
         if dec is None:
+            t3 = op.tile("fwd")
+            sk = self._split_decision(op, t3)                        # the two-launch alternative runs the 3x3 on its streaming tile
+            t3 = sk[1] if sk[0] == 1 else t3
             dec = op._tiles["fuse"] = bool(ops.tuned_bottleneck(op.x.dtype, op.x.N, op.x.H, op.x.W, pre.x.C, op.x.C, op.y.C,
-                                                                op.res is not None, self.device, pre.tile("fwd"), op.tile("fwd")))
+                                                                op.res is not None, self.device, pre.tile("fwd"), t3))
         return dec
 
     def _run_op(self, op, part=None):
@@ -512,6 +516,7 @@ class InferencePlan:
                 ops.conv2d_splitk(op.x, w, op.y, op.k, op.stride, scale, shift, self._splitk_ws[op.chain], dec[0], res=op.res,
                                   epilogue=EPI_SILU, tile=dec[1], wfrag=self.cache.conv_weight_frag(op.mod))
                 return
+            t = dec[1]                                                  # (a K-group tile where the streaming tuner found one faster)
             ops.conv2d(op.x, w, op.y, op.k, op.stride, scale, shift, res=op.res, epilogue=EPI_SILU, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
         elif op.kind == "resize":

@@ -488,7 +488,7 @@ class _TuneStore:
         h = hashlib.sha256()
         h.update(_lib.kernel_source_key().encode())
         h.update(_lib.lib().sy_version())
-        h.update(repr((HALO_TILES, HALO_SMALL_TILES, HALO_S2_TILES, TILE_1X1K, WGRAD_EXTRA)).encode())          # candidate-set switches (A/B runs)
+        h.update(repr((HALO_TILES, HALO_SMALL_TILES, HALO_KGROUP_TILES, HALO_S2_KGROUP_TILES, HALO_S2_TILES, TILE_1X1K, WGRAD_EXTRA)).encode())          # candidate-set switches (A/B runs)
         # (no device name in the key: this library is gfx950-only, and torch reports an empty name under rocprofv3 — a profiled
         #  run then overwrote the cache of the normal runs with its own)
         return h.hexdigest()[:16]
@@ -548,6 +548,9 @@ HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,
 # launches of few pixels (one streamed frame; the 19x30 maps of a training batch): one MFMA tile per wave, more workgroups
 HALO_SMALL_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_SMALL_TILES", "112,113").replace("+", ",").split(",") if t]
 HALO_SMALL_PIXELS = 12000
+# K groups inside the workgroup (csrc/conv3x3_halo.h, KS): eval / streaming plans that allow another fp32 summation order
+HALO_KGROUP_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_KGROUP_TILES", "111,106").replace("+", ",").split(",") if t]
+HALO_S2_KGROUP_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_KGROUP_TILES", "105").replace("+", ",").split(",") if t]
 HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "110,108").replace("+", ",").split(",") if t]
 TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123").split(",") if t]
 
@@ -637,30 +640,42 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     return best
 
 
-def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile):
-    """(splits, tile) for a 3x3 stride-1 EVAL convolution of a small map: the plain kernel (`base_tile`, splits = 1) against 2 / 4
-    channel-slab ranges + sy_splitk_epilogue on tiles 117 / 118, timed on dummy tensors (cached, persisted as mode 2 entries)."""
+def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile, stride=1):
+    """(splits, tile) for a 3x3 stride-1 EVAL convolution of a small map: the plain kernel (`base_tile`, splits = 1) against (a) the
+    K-group tiles (HALO_KGROUP_TILES: the contraction split over wave groups INSIDE the workgroup, one launch, splits = 1) and (b)
+    2 / 4 channel-slab ranges + sy_splitk_epilogue (maps of <= 6000 pixels), timed on dummy tensors (cached, persisted as mode 2
+    entries).  Every alternative sums the fp32 products in another order than the plain kernels — plans opt in (allow_split_k)."""
     code = dtype_code(dtype)
     epc = 4 if code == DT_F32 else 8
-    if not autotune_enabled(device) or Cin % (4 * epc) or N * H * W > 6000:
+    Ho, Wo = conv_out_size(H, 3, stride), conv_out_size(W, 3, stride)
+    if not autotune_enabled(device) or Cin % (4 * epc) or N * Ho * Wo > HALO_SMALL_PIXELS:
         return (1, base_tile)
     _tune_store.load(device)
-    key = ("splitk", code, N, H, W, Cin, Cout, base_tile, str(device))
+    key = ("splitk", code, N, H, W, Cin, Cout, base_tile, str(device)) + (() if stride == 1 else (stride,))
     hit = _tile_cache.get(key)
     if hit is not None:
         return (hit // 1000, hit % 1000) if hit >= 1000 else (1, base_tile)
     from .model.packing import pack_conv_weight_frag
     x = View.alloc(N, H, W, Cin, code, device, zero=True)
-    y = View.alloc(N, H, W, Cout, code, device)
+    y = View.alloc(N, Ho, Wo, Cout, code, device)
     w = torch.zeros((Cout, 9 * Cin), dtype=TORCH_DTYPE[code], device=device)
     wf = pack_conv_weight_frag(w, 3)
     scale, shift = torch.ones(Cout, device=device), torch.zeros(Cout, device=device)
-    part = torch.empty(4 * N * H * W * Cout, dtype=torch.float32, device=device)
+    part = torch.empty(4 * N * H * W * Cout, dtype=torch.float32, device=device) if stride == 1 else None
     best, best_t = (1, base_tile), _time_launches(
-        lambda: conv2d(x, w, y, 3, 1, scale, shift, epilogue=EPI_SILU, tile=base_tile, wfrag=wf if base_tile >= TILE_WR else None),
+        lambda: conv2d(x, w, y, 3, stride, scale, shift, epilogue=EPI_SILU, tile=base_tile, wfrag=wf if base_tile >= TILE_WR else None),
         device, launches=8)
+    for t in (HALO_KGROUP_TILES if stride == 1 else HALO_S2_KGROUP_TILES):
+        try:
+            run = lambda: conv2d(x, w, y, 3, stride, scale, shift, epilogue=EPI_SILU, tile=t, wfrag=wf)   # noqa: E731
+            run()
+            dt_ = _time_launches(run, device, launches=8)
+        except _lib.HipLibraryError:
+            continue
+        if dt_ < best_t:
+            best, best_t = (1, t), dt_
     for S in (2, 4):
-        if S > Cin // (4 * epc):
+        if S > Cin // (4 * epc) or N * H * W > 6000 or stride != 1:
             continue
         for t in (117, 118, 113, 112):
             try:
@@ -671,7 +686,7 @@ def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile):
                 continue
             if dt_ < best_t:
                 best, best_t = (S, t), dt_
-    _tile_cache[key] = best[0] * 1000 + best[1] if best[0] > 1 else 1
+    _tile_cache[key] = best[0] * 1000 + best[1] if best != (1, base_tile) else 1
     _tune_store.dirty = True
     return best
 

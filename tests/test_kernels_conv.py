@@ -176,10 +176,10 @@ def test_wgrad_many_splits_fold(backend):
     assert _rel(dw.cpu(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [112, 113, 114, 115, 116, 117, 118])
+@pytest.mark.parametrize("tile", [106, 111, 112, 113, 114, 115, 116, 117, 118])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "fwd"), ("bf16", "dgrad"), ("fp32", "dgrad")])
 def test_conv3x3_halo_kernel(backend, tile, dt, mode):
-    """csrc/conv3x3_halo.h (tile codes 112..118; 112 / 113 / 117 / 118 = the in-wave software-pipelined generation): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
+    """csrc/conv3x3_halo.h (tile codes 106, 111..118; 112 / 113 / 117 / 118 = the in-wave software-pipelined generation, 106 / 111 = the same with K groups inside the workgroup): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
     gradient (first write, accumulate, channel-slice output), on an image whose width and height are ragged against the
     32-pixel / TH-row tiles, with Cout ragged against the channel tile; against torch and against the implicit-GEMM kernel."""
     g = torch.Generator().manual_seed(tile + len(mode))
@@ -350,10 +350,11 @@ def test_conv3x3_split_k_equals_the_single_pass_kernel(backend, tile, dt, splits
     assert _rel(y1.nchw().cpu(), y0.nchw().cpu()) < {"fp32": 1e-5, "fp16": 2e-3, "bf16": 1.6e-2}[dt]
 
 
+@pytest.mark.parametrize("tile", [110, 105])
 @pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 72, 11, 37), (1, 32, 160, 8, 66), (2, 64, 128, 5, 130)])
-def test_conv3x3_stride2_halo_kernel(backend, dt, N, cin, cout, H, W):
-    """conv3x3_halo2_kernel<..., S2> (tile code 110): the 3x3 STRIDE-2 forward with the (2 TH + 1) x 65 input window resident in
+def test_conv3x3_stride2_halo_kernel(backend, tile, dt, N, cin, cout, H, W):
+    """conv3x3_halo2_kernel<..., S2> (tile code 110; 105 = the same with two K groups of waves): the 3x3 STRIDE-2 forward with the (2 TH + 1) x 65 input window resident in
     LDS, columns split by parity — odd and even input sizes, ragged output tiles and channel tiles, training epilogue (raw output
     + per-frame statistics) and eval epilogue (affine + SiLU), against torch and against the implicit-GEMM kernel."""
     code = ops.dtype_code(dt)
@@ -368,7 +369,7 @@ def test_conv3x3_stride2_halo_kernel(backend, dt, N, cin, cout, H, W):
     yv = View.alloc(N, Ho, Wo, cout + 8, dt, backend, zero=True).slice(8, cout)
     segs = 2 if N % 2 == 0 else 1
     ssum = torch.zeros(segs * 4 * cout, device=backend); ssq = torch.zeros(segs * 4 * cout, device=backend)
-    ops.conv2d(xv, wp, yv, 3, 2, stats=(ssum, ssq), tile=110, wfrag=wf, segments=segs)
+    ops.conv2d(xv, wp, yv, 3, 2, stats=(ssum, ssq), tile=tile, wfrag=wf, segments=segs)
     assert _rel(yv.nchw().cpu(), y) < TOL[dt]
     assert float(yv.buf[..., :8].float().abs().max()) == 0.0
     for s_ in range(segs):
@@ -376,7 +377,7 @@ def test_conv3x3_stride2_halo_kernel(backend, dt, N, cin, cout, H, W):
         assert _rel(ssq.view(segs, 4, cout)[s_].sum(0).cpu(), (ys ** 2).sum((0, 2, 3))) < 1e-3
         assert float((ssum.view(segs, 4, cout)[s_].sum(0).cpu() - ys.sum((0, 2, 3))).abs().max()) < 1e-2 * float(ys.abs().sum((0, 2, 3)).max())
     scale, shift = (torch.rand(cout, generator=g) + 0.5), torch.randn(cout, generator=g) * 0.3
-    ops.conv2d(xv, wp, yv, 3, 2, scale.to(backend), shift.to(backend), epilogue=ops.EPI_SILU, tile=110, wfrag=wf)
+    ops.conv2d(xv, wp, yv, 3, 2, scale.to(backend), shift.to(backend), epilogue=ops.EPI_SILU, tile=tile, wfrag=wf)
     ref = F.silu(y * scale[None, :, None, None] + shift[None, :, None, None])
     assert _rel(yv.nchw().cpu(), ref) < TOL[dt]
     ref_v = View.alloc(N, Ho, Wo, cout, dt, backend)
@@ -384,7 +385,7 @@ def test_conv3x3_stride2_halo_kernel(backend, dt, N, cin, cout, H, W):
     assert _rel(yv.nchw().cpu(), ref_v.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
     # the data gradient of a stride-2 layer stays on the implicit-GEMM kernel
     with pytest.raises(ops._lib.HipLibraryError):
-        ops.conv2d(ref_v, wp, xv, 3, 2, mode=ops.CONV_DGRAD, tile=110, wfrag=wf)
+        ops.conv2d(ref_v, wp, xv, 3, 2, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])

@@ -66,12 +66,13 @@ def test_spp_pool_fwd_bwd(backend, dt):
         assert _rel(dv.slice(0, C).nchw().cpu(), x.grad) < 1e-6
 
 
-@pytest.mark.parametrize("dt,H,W", [("bf16", 19, 30), ("fp32", 7, 5), ("bf16", 3, 5)])
-def test_spp_tile_kernels_match_scan_kernels(backend, dt, H, W, monkeypatch):
+@pytest.mark.parametrize("dt,H,W,C", [("bf16", 19, 30, 16), ("fp32", 7, 5, 16), ("bf16", 3, 5, 16), ("bf16", 6, 7, 1024)])
+def test_spp_tile_kernels_match_scan_kernels(backend, dt, H, W, C, monkeypatch):
     """The LDS-tiled (separable) SPP kernels must reproduce the scan kernels bit for bit — pooled values, the
-    arg-max bytes (ties included: inputs quantised to a few levels); routed gradients to rounding."""
+    arg-max bytes (ties included: inputs quantised to a few levels); routed gradients to rounding.  Launches of < 256 channel
+    chunks run the three pooling levels as three workgroups per chunk (C = 16), larger ones one workgroup per chunk (C = 1024)."""
     g = torch.Generator().manual_seed(5)
-    N, C = 2, 16
+    N = 2
     x = (torch.randn(N, C, H, W, generator=g) * 2).round() / 2          # many exact ties
     dy = torch.randn(N, 4 * C, H, W, generator=g)
     res = {}
