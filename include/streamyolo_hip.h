@@ -48,13 +48,13 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
                              needs wfrag): 128 ch x 2 rows x 32 px (8 waves) | 128 x 2 | 64 x 8 | 128 x 2 and 128 x 4 software-pipelined;
                              112, 113: software-pipelined, one 32 x 32 MFMA tile per wave (small launches): 64 ch x 2 rows | 128 ch x 2 rows;
                              105, 106, 111: K GROUPS inside the workgroup (small launches; partial tiles summed through LDS in group order — another
-                             fp32 summation order than the tiles above): 105 stride 2 forward 128 ch, 2 groups | 106 32 ch, 4 groups |
+                             fp32 summation order than the tiles above): 105 stride 2 forward 64 ch x 1 row, 2 groups | 106 32 ch, 4 groups |
                              111 64 ch, 2 groups (all 2 rows x 32 px);
                              119: FUSED Bottleneck forward (1x1 -> 3x3, the hidden activation kept in LDS; sy_conv_desc::pre_*);
                              110: STRIDE 2 forward, 128 ch x 2 output rows x 32 px, input window split by column parity;
                              108: STRIDE 2 data gradient (csrc/conv3x3_s2dgrad.h), four output-parity classes */
-       SY_TILE_1X1K = 121 /* 121..123: 1x1 stride-1 kernel with the tile's whole K extent requested in one burst (csrc/conv1x1_tile.h; needs
-                             wfrag, 16-bit types, Cin 64 / 128 / 256 / 512): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px */ };
+       SY_TILE_1X1K = 121 /* 121..124: 1x1 stride-1 kernel with the tile's whole K extent requested in one burst (csrc/conv1x1_tile.h; needs
+                             wfrag, 16-bit types, Cin 64 / 128 / 256 / 512): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px | 64 ch x 64 px */ };
 
 /* gather modes of sy_conv2d */
 enum {

@@ -196,16 +196,16 @@ int launch_1x1_tile_cfg(const ConvArgs& a, void* stream) {
             if constexpr (TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16>(a, stream);
             return SY_ERR_UNSUPPORTED;
         case 32:                                  // Cin 1024 / 2048: two / four chunks of 512 channels
-            if constexpr (WC == 4 && TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16, 2>(a, stream);
+            if constexpr ((WC == 4 || TC * TP == 1) && TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16, 2>(a, stream);
             return SY_ERR_UNSUPPORTED;
         case 64:
-            if constexpr (WC == 4 && TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16, 4>(a, stream);
+            if constexpr ((WC == 4 || TC * TP == 1) && TC * TP <= 2) return launch_1x1_tile_ns<T, WC, WP, TC, TP, 16, 4>(a, stream);
             return SY_ERR_UNSUPPORTED;
         default: return SY_ERR_UNSUPPORTED;
     }
 }
 
-// tile codes 121..123 (SY_TILE_1X1K + k)
+// tile codes 121..124 (SY_TILE_1X1K + k)
 template <typename T>
 int launch_1x1_tile(const ConvArgs& a, void* stream) {
     if constexpr (T::kEPC != 8) {
@@ -219,6 +219,9 @@ int launch_1x1_tile(const ConvArgs& a, void* stream) {
             case 121: return launch_1x1_tile_cfg<T, 4, 1, 1, 2>(a, stream);     // 128 ch x  64 px
             case 122: return launch_1x1_tile_cfg<T, 2, 2, 1, 2>(a, stream);     //  64 ch x 128 px
             case 123: return launch_1x1_tile_cfg<T, 4, 1, 1, 4>(a, stream);     // 128 ch x 128 px
+            // small launches with a long K (the 19x30 maps' 1024 / 2048-channel layers of a streamed frame): half the weight bytes
+            // per workgroup, twice the workgroups (at Cin <= 512 it measured the same as 121: not a candidate there)
+            case 124: return launch_1x1_tile_cfg<T, 2, 2, 1, 1>(a, stream);     //  64 ch x  64 px
             default: return SY_ERR_ARG;
         }
     }

@@ -463,7 +463,7 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         case 111: return launch_halo<T, 2, 1, 1, 2, 2, 0, 2>(a, stream);  //  64 ch x (2 rows x 32 px), 2 groups of 2 waves
         // (64 ch x 4 groups and 128 ch x 2 groups measured no better than 111 / 117: the main loop follows the weight bytes per CU)
         case 106: return launch_halo<T, 1, 1, 1, 2, 2, 0, 4>(a, stream);  //  32 ch x (2 rows x 32 px), 4 groups of 1 wave
-        case 105: return launch_halo<T, 4, 1, 1, 2, 2, 1, 2>(a, stream);  // STRIDE 2 forward (110's tile), 2 groups of 4 waves
+        case 105: return launch_halo<T, 2, 1, 1, 1, 2, 1, 2>(a, stream);  // STRIDE 2 forward, 64 ch x (1 row x 32 px), 2 groups of 2 waves
         // STRIDE 2, forward (tile 117's configuration over a parity-split input window): +7 % / +26 % over the implicit-GEMM
         // variants on dark2.0 / dark4.0 (profiles/r04/a_probe_s2_stats.txt)
         case 110: return launch_halo<T, 4, 1, 1, 2, 2, 1>(a, stream);

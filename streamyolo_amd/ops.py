@@ -552,7 +552,7 @@ HALO_SMALL_PIXELS = 12000
 HALO_KGROUP_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_KGROUP_TILES", "111,106").replace("+", ",").split(",") if t]
 HALO_S2_KGROUP_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_KGROUP_TILES", "105").replace("+", ",").split(",") if t]
 HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "110,108").replace("+", ",").split(",") if t]
-TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123").split(",") if t]
+TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123,124").replace("+", ",").split(",") if t]
 
 
 def autotune_enabled(device):
@@ -561,7 +561,10 @@ def autotune_enabled(device):
 
 
 def _time_launches(run, device, launches=4, rounds=2):
-    """Best of `rounds` timings of `launches` back-to-back launches (HIP events on the current stream), in ms."""
+    """Best of `rounds` timings of `launches` back-to-back launches (HIP events on the current stream), in ms.  (Timing a hipGraph of
+    the launches instead — no host time between them — picks WORSE tiles for the few-microsecond launches of a streamed frame:
+    1.55-1.56 vs 1.41-1.47 ms per frame over three tunings each on one box, profiles/r04 stage ao.  Through the wrappers every launch
+    starts on an idle chip, as it does behind the ~3 us dependent-launch gap of the plan's tape.)"""
     best = float("inf")
     for _ in range(rounds):
         torch.cuda.synchronize(device)
@@ -613,7 +616,8 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
         cands += [t for t in HALO_S2_TILES if (t == 108) == (mode == CONV_DGRAD)]     # 110: forward, 108: data gradient
     if k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256, 512, 1024, 2048) and code != DT_F32:
         # whole-K burst kernel (csrc/conv1x1_tile.h): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px (Cin <= 256)
-        cands += [t for t in TILE_1X1K if not (t == 122 and Cout > 64) and not (t == 123 and Cin > 256) and not (t != 121 and Cin > 512)]
+        cands += [t for t in TILE_1X1K if not (t == 122 and Cout > 64) and not (t == 123 and Cin > 256) and not (t not in (121, 124) and Cin > 512)
+                  and not (t == 124 and (Cin < 1024 or N * Ho * Wo > HALO_SMALL_PIXELS))]
     if only is not None:
         cands = list(only)
     best, best_t = (0 if only is None else only[-1]), float("inf")
@@ -630,7 +634,9 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
                 conv2d(x, w, y, k, stride, epilogue=EPI_LINEAR, mode=mode, tile=t, wfrag=wf)
         try:
             run()
-            dt = _time_launches(run, device)
+            # (the few-microsecond eval launches of a streamed frame: more repetitions, the choice among near-equal tiles is noisy)
+            small = mode == CONV_FWD and not with_stats and N * Ho * Wo <= HALO_SMALL_PIXELS
+            dt = _time_launches(run, device, launches=8, rounds=4) if small else _time_launches(run, device)
         except _lib.HipLibraryError:
             continue
         if dt < best_t:
@@ -664,12 +670,12 @@ def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile, stride=1):
     part = torch.empty(4 * N * H * W * Cout, dtype=torch.float32, device=device) if stride == 1 else None
     best, best_t = (1, base_tile), _time_launches(
         lambda: conv2d(x, w, y, 3, stride, scale, shift, epilogue=EPI_SILU, tile=base_tile, wfrag=wf if base_tile >= TILE_WR else None),
-        device, launches=8)
+        device, launches=8, rounds=4)
     for t in (HALO_KGROUP_TILES if stride == 1 else HALO_S2_KGROUP_TILES):
         try:
             run = lambda: conv2d(x, w, y, 3, stride, scale, shift, epilogue=EPI_SILU, tile=t, wfrag=wf)   # noqa: E731
             run()
-            dt_ = _time_launches(run, device, launches=8)
+            dt_ = _time_launches(run, device, launches=8, rounds=4)
         except _lib.HipLibraryError:
             continue
         if dt_ < best_t:
@@ -681,7 +687,7 @@ def tuned_splitk(dtype, N, H, W, Cin, Cout, device, base_tile, stride=1):
             try:
                 run = lambda: conv2d_splitk(x, w, y, 3, 1, scale, shift, part, S, epilogue=EPI_SILU, tile=t, wfrag=wf)   # noqa: E731
                 run()
-                dt_ = _time_launches(run, device, launches=8)
+                dt_ = _time_launches(run, device, launches=8, rounds=4)
             except _lib.HipLibraryError:
                 continue
             if dt_ < best_t:

@@ -263,15 +263,15 @@ def test_wgrad_all_taps_kernel(backend, tile, N, cin, cout, H, W):
     assert _rel(dw4.cpu(), dw3.cpu()) < 1e-2
 
 
-@pytest.mark.parametrize("tile", [121, 122, 123])
+@pytest.mark.parametrize("tile", [121, 122, 123, 124])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("cin,cout,N,H,W", [(64, 72, 2, 7, 9), (128, 160, 4, 5, 13), (256, 128, 2, 9, 11), (512, 64, 2, 6, 13),
                                            (1024, 128, 2, 5, 9), (2048, 64, 2, 4, 9)])
 def test_conv1x1_tile_kernel(backend, tile, dt, cin, cout, N, H, W):
-    """csrc/conv1x1_tile.h (tile codes 121..123): 1x1 stride-1 training forward (raw output + per-frame BatchNorm
+    """csrc/conv1x1_tile.h (tile codes 121..124): 1x1 stride-1 training forward (raw output + per-frame BatchNorm
     statistics), the eval epilogue (affine + SiLU + residual), and the data gradient (first write and accumulate), with pixel
     and channel tiles ragged against the image; against torch and against the implicit-GEMM kernel."""
-    if (tile == 122 and cout > 64) or (tile == 123 and cin > 256) or (tile != 121 and cin > 512):
+    if (tile == 122 and cout > 64) or (tile == 123 and cin > 256) or (tile not in (121, 124) and cin > 512):
         pytest.skip("not a tuner candidate for this shape")
     code = ops.dtype_code(dt)
     g = torch.Generator().manual_seed(cin + cout + tile)
