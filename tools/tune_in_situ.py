@@ -2,6 +2,7 @@
 """Tune kernel variants IN the training step instead of alone.
 
     python tools/tune_in_situ.py [--model l] [--batch 8] [--kinds wgrad,fwd,dgrad] [--save 1]
+    python tools/tune_in_situ.py --workload stream [--dtype fp16]        # the streamed frame's launch tape
 
 ops.tuned_tile / tuned_wgrad time every kernel variant alone on an idle chip.  In the step the launches of four chains share the
 CUs, and what is best alone is not what is best beside the neighbours (profiles/r04 stages r-v, aj, as: `wgrad9` on half the chip is
@@ -9,7 +10,9 @@ CUs, and what is best alone is not what is best beside the neighbours (profiles/
 it swaps the group's variant for each alternative, re-records the launch tapes (one step) and times the step (median of --steps
 replays); a swap is kept when it beats the current best by --gain ms in two measurements.  Kept choices are written into the
 tuner's persisted cache (streamyolo_amd/lib/tune_cache.json, ops.save_tuned) under the same keys the per-kernel tuner uses, so
-every later plan of this shape starts from them.  One pass over the weight-gradient groups of the l step takes ~1 GPU-minute."""
+every later plan of this shape starts from them.  One pass over the weight-gradient groups of the l step takes ~1 GPU-minute.
+--workload stream does the same for the streaming plan's per-layer decisions (tile, K-group tile / split-K, fused Bottleneck): the
+per-kernel tuner times a layer with its weights hot in L2, in the frame every layer's weights are touched once."""
 import argparse
 import os
 import sys
@@ -28,6 +31,8 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--gain", type=float, default=0.06, help="ms a swap must win by, twice")
 ap.add_argument("--min-ms", type=float, default=0.0, help="skip groups whose launches sum to less than this per step (profile estimate)")
 ap.add_argument("--save", type=int, default=1)
+ap.add_argument("--workload", default="train", choices=["train", "stream"])
+ap.add_argument("--frames", type=int, default=60, help="stream: frames per timing")
 a = ap.parse_args()
 import streamyolo_amd as sy                                             # noqa: E402
 from oracle import streamyolo_oracle as O                                # noqa: E402
@@ -40,6 +45,10 @@ cfg = O.OracleConfig.named(a.model)
 model = sy.build_model(a.model)
 model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0, bn_stats=load_bn_stats(a.model)), strict=True)
 model = model.to(dev).set_compute_dtype(a.dtype)
+if a.workload == "stream":
+    from tools._tune_stream import tune_stream                            # noqa: E402
+    tune_stream(a, model, cfg, dev)
+    sys.exit(0)
 x = synth_frames(a.batch, 600, 960, seed=2).to(dev)
 lab, sup = synth_labels(a.batch, 600, 960, cfg.num_classes, seed=3)
 lab, sup = lab.to(dev), sup.to(dev)
