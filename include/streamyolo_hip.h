@@ -47,6 +47,7 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
        SY_TILE_HALO = 112, /* 114..118 (HALO + 2..6): 3x3 stride-1 kernel with the input tile + halo resident in LDS (csrc/conv3x3_halo.h;
                              needs wfrag): 128 ch x 2 rows x 32 px (8 waves) | 128 x 2 | 64 x 8 | 128 x 2 and 128 x 4 software-pipelined;
                              112, 113: software-pipelined, one 32 x 32 MFMA tile per wave (small launches): 64 ch x 2 rows | 128 ch x 2 rows;
+                             107, 104: software-pipelined, 128 ch x 3 rows | 128 ch x 5 rows (three / five MFMAs per weight fragment);
                              105, 106, 111: K GROUPS inside the workgroup (small launches; partial tiles summed through LDS in group order — another
                              fp32 summation order than the tiles above): 105 stride 2 forward 64 ch x 1 row, 2 groups | 106 32 ch, 4 groups |
                              111 64 ch, 2 groups (all 2 rows x 32 px);

@@ -445,7 +445,7 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-// tile codes 105, 106, 110..118 of sy_conv_desc::tile
+// tile codes 104..107, 110..118 of sy_conv_desc::tile
 template <typename T>
 int launch_halo_typed(const ConvArgs& a, void* stream) {
     switch (a.tile) {
@@ -455,6 +455,8 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         // second generation (in-wave software pipeline) of 115 / 113
         case 117: return launch_halo<T, 4, 1, 1, 2, 2>(a, stream);
         case 118: return launch_halo<T, 4, 1, 1, 4, 2>(a, stream);
+        case 107: return launch_halo<T, 4, 1, 1, 3, 2>(a, stream);     // 128 ch x (3 rows x 32 px): between 117 and 118
+        case 104: return launch_halo<T, 4, 1, 1, 5, 2>(a, stream);     // 128 ch x (5 rows x 32 px)
         // small launches (the streaming frame, the 19x30 maps): one 32 ch x 32 px MFMA tile per wave — half the serial MFMA chain
         // of 117 per wave, and (112) twice the workgroups over which the layer's weights are fetched
         case 112: return launch_halo<T, 2, 2, 1, 1, 2>(a, stream);  //  64 ch x ( 2 rows x 32 px), 4 waves

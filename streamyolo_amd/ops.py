@@ -541,7 +541,10 @@ def save_tuned():
 
 
 # (112 / 113 — the first-generation 2x2-wave and 128-pixel tiles — were never chosen by the tuner on any StreamYOLO shape: removed)
-HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,116,117,118").replace("+", ",").split(",") if t]
+# 107 / 104 = the software-pipelined tile on 3 / 5 output rows: a frame's 38 x 60 map is 13 x 3 or 8 x 5 rows, 416 / 256 workgroups
+# instead of 117's 608 (one ragged round of 2.4 per CU) with 0.67 / 0.4 of its weight-fragment loads per MFMA: +15 % on the
+# 256->256 @38x60 layers, +17 % on 512->512 @19x30 (profiles/r04 stage bd)
+HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,116,117,118,107,104").replace("+", ",").split(",") if t]
 # stride-2 3x3 layers on the window-in-LDS kernels (tile codes 110 = forward, 108 = data gradient).  Measured in round 4
 # (profiles/r04/a_probe_s2_*.txt): forward 421 vs 395 (dark2.0) / 739 vs 585 TF/s (dark4.0) against the best implicit-GEMM
 # variant, data gradient 245 vs 250 / 504 vs 484; l step 22.61 vs 22.70 ms (b_bench_s2 / b_bench_base) — candidates by default
