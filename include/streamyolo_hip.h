@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 5
+#define SY_ABI_VERSION 6
 #define SY_API __attribute__((visibility("default")))
 
 enum { SY_DT_BF16 = 0, SY_DT_F16 = 1, SY_DT_F32 = 2 };
@@ -317,6 +317,12 @@ SY_API int sy_tal_loss(const float* raw, int B, int A, int num_classes, const fl
                        const int32_t* level_w, const float* level_stride, int nlevels, float gamma,
                        float ignore_thr, float ignore_value, int use_l1, float* d_raw, float* losses,
                        int32_t* fg_mask, void* workspace, void* d_pad, int pad_dtype, void* stream);
+
+/* Assignment of the LAST sy_tal_loss call on `workspace` (same B, A, max_labels): matched_gt [B, A] int32 = index of the matched
+ * ground truth of every anchor, -1 for background; matched_iou [B, A] fp32 = its IoU (either may be NULL).  The reference's
+ * get_assignments returns the same pair for the foreground anchors (exps/model/tal_head.py:559-600); diagnostics and parity tests. */
+SY_API int sy_tal_loss_assignment(const void* workspace, int B, int A, int max_labels, int32_t* matched_gt,
+                                  float* matched_iou, void* stream);
 
 /* elementwise helpers on views: out (+)= in */
 SY_API int sy_view_copy(const void* in, int ldi, void* out, int ldo, int64_t pixels, int C, int dtype,

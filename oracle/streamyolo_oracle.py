@@ -391,6 +391,7 @@ def tal_loss(raw_levels, labels, support_labels, cfg: OracleConfig):
     nsup = (support_labels.sum(2) > 0).sum(1)
 
     fg_all = torch.zeros(B, A, dtype=torch.bool)
+    mg_all = torch.full((B, A), -1, dtype=torch.int32)                   # matched GT index per anchor (test read-out)
     cls_t, reg_t, l1_t, trend = [], [], [], []
     num_fg, num_gt_total = 0.0, 0.0
     for i in range(B):
@@ -404,6 +405,7 @@ def tal_loss(raw_levels, labels, support_labels, cfg: OracleConfig):
         fg, mg, miou = simota_assign(gtb, gtc, boxes[i].detach(), obj[i].detach(), cls[i].detach(),
                                      gx, gy, gs, nc)
         fg_all[i] = fg
+        mg_all[i, fg] = mg.to(torch.int32)
         num_fg += int(fg.sum())
         cls_t.append(F.one_hot(gtc[mg].to(torch.int64), nc) * miou[:, None])
         reg_t.append(gtb[mg])
@@ -440,7 +442,7 @@ def tal_loss(raw_levels, labels, support_labels, cfg: OracleConfig):
     total = 5.0 * loss_iou + loss_obj + loss_cls + loss_l1
     return {"total_loss": total, "iou_loss": 5.0 * loss_iou, "l1_loss": loss_l1,
             "conf_loss": loss_obj, "cls_loss": loss_cls, "num_fg": num_fg / max(num_gt_total, 1),
-            "_fg_mask": fg_all}
+            "_fg_mask": fg_all, "_matched_gt": mg_all}
 
 
 def forward_train(sd, x, labels, support_labels, cfg: OracleConfig):

@@ -18,7 +18,7 @@ DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 EPI_LINEAR, EPI_SILU, EPI_SIGMOID, EPI_DECODE = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD = 0, 1
 
-ABI_VERSION = 5          # SY_ABI_VERSION of include/streamyolo_hip.h this binding was written against
+ABI_VERSION = 6          # SY_ABI_VERSION of include/streamyolo_hip.h this binding was written against
 _ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape"}
 SY_ERR_UNSUPPORTED = 3
 
@@ -111,6 +111,7 @@ SIGNATURES = {
     "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "sy_tal_loss_assignment": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_splitk_epilogue": (_I, [_P, _I, _L, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sy_rows_add_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),

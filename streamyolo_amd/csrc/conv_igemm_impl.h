@@ -949,7 +949,7 @@ template <typename T> int launch_bottleneck_fused(const ConvArgs& a, void* strea
 
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
-    if ((a.tile >= 104 && a.tile <= 107) || (a.tile >= 110 && a.tile <= 118)) return launch_halo_typed<T>(a, stream);
+    if ((a.tile >= 104 && a.tile <= 107) || (a.tile >= 110 && a.tile <= 118) || a.tile == 120 || (a.tile >= 125 && a.tile <= 127)) return launch_halo_typed<T>(a, stream);
     if (a.tile == 119) return launch_bottleneck_fused<T>(a, stream);
     if (a.tile == 108) return launch_s2dgrad<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 124) return launch_1x1_tile<T>(a, stream);

@@ -146,6 +146,7 @@ static inline void sy_glds16(const void* gsrc, unsigned char* lds_wave_base) {
 }
 template <int N> static inline void sy_wait_vmcnt() {}
 static inline void sy_barrier() { __syncthreads(); }
+static inline void sy_barrier_lds() { __syncthreads(); }
 
 #else
 // Issued through inline asm on purpose: when hipcc sees an LDS-DMA it cannot prove disjoint from a later
@@ -163,6 +164,13 @@ __device__ __forceinline__ void sy_glds16(const void* gsrc, unsigned char* lds_w
 }
 template <int N> __device__ __forceinline__ void sy_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void sy_barrier() { __builtin_amdgcn_s_barrier(); }
+// Barrier behind ordinary LDS stores (ds_write): the raw s_barrier above does not drain the LGKM counter, and gfx950's back-off
+// barrier means hipcc adds no wait of its own in front of it — a wave could pass the barrier while its stores are still in
+// flight and another wave read stale LDS.  sy_barrier() is for DMA-filled LDS (paired with sy_wait_vmcnt) only.
+__device__ __forceinline__ void sy_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 #endif
 
 // ---- LDS transpose read (ds_read_b64_tr_b16) ---------------------------------------------------------

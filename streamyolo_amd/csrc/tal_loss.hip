@@ -33,6 +33,7 @@ namespace {
 constexpr int kAssignThreads = 1024;
 constexpr int kMaxLevels = 8;
 constexpr int kMaxGT = 128;
+constexpr int kGradBlocksMax = 2048;      // workgroups of tal_grad_kernel = rows of its partial-sum buffer (workspace tail)
 
 struct TalGeom {
     int nlevels;
@@ -405,7 +406,8 @@ __global__ __launch_bounds__(kAssignThreads) void tal_resolve_kernel(const float
 __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, int A, int nc, const float* labels,
                                                        int max_labels, TalGeom geom, float gamma, int use_l1,
                                                        const unsigned char* ws, TalLayout L,
-                                                       float* d_raw, float* losses, int* fg_mask, void* d_pad, int pad_dtype) {
+                                                       float* d_raw, float* losses, int* fg_mask, void* d_pad, int pad_dtype,
+                                                       float* block_part) {
     SY_TL_BEGIN(14);
     __shared__ float s_tot[8];
     __shared__ float s_acc[4][4];
@@ -516,14 +518,10 @@ __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, 
         if (lane == 0) s_acc[wave][j] = v;
     }
     __syncthreads();
-    if (tid < 4) {
-        const float v = (s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid]) * inv_nf;
-        // losses: [0] total, [1] 5*iou, [2] l1, [3] conf, [4] cls, [5] num_fg/num_gt, [6] num_fg, [7] num_gt
-        if (tid == 0) { atomicAdd(losses + 1, 5.0f * v); atomicAdd(losses + 0, 5.0f * v); }
-        if (tid == 1) { atomicAdd(losses + 3, v); atomicAdd(losses + 0, v); }
-        if (tid == 2) { atomicAdd(losses + 4, v); atomicAdd(losses + 0, v); }
-        if (tid == 3) { atomicAdd(losses + 2, v); atomicAdd(losses + 0, v); }
-    }
+    // This workgroup's four partial sums (iou, obj, cls, l1) go to ITS row of `block_part`; tal_finish_kernel adds the rows in a
+    // fixed order.  (Until round 5 every workgroup added into losses[] with fp32 atomics: the loss scalars of two identical steps
+    // differed in their last bits with the arrival order of up to 2048 workgroups.)
+    if (tid < 4) block_part[blockIdx.x * 4 + tid] = (s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid]) * inv_nf;
     if (blockIdx.x == 0 && tid == 0) {
         losses[5] = num_fg / (num_gt > 1.0f ? num_gt : 1.0f);
         losses[6] = num_fg;
@@ -532,8 +530,22 @@ __global__ __launch_bounds__(256) void tal_grad_kernel(const float* raw, int B, 
     SY_TL_END();
 }
 
-__global__ void tal_zero_losses_kernel(float* losses) {
-    if (threadIdx.x < 8) losses[threadIdx.x] = 0.0f;
+// One workgroup of four waves: wave j totals component j of the per-workgroup rows — lane i the rows i, i + 64, ... in index
+// order, then a butterfly over the lanes — so the result does not depend on which workgroup of tal_grad_kernel finished first.
+__global__ __launch_bounds__(256) void tal_finish_kernel(const float* block_part, int blocks, float* losses) {
+    __shared__ float s_tot[4];
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    float v = 0.0f;
+    for (int b = lane; b < blocks; b += 64) v += block_part[b * 4 + j];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) s_tot[j] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // losses: [0] total, [1] 5*iou, [2] l1, [3] conf, [4] cls, [5] num_fg/num_gt, [6] num_fg, [7] num_gt
+        const float iou5 = 5.0f * s_tot[0], conf = s_tot[1], cls = s_tot[2], l1 = s_tot[3];
+        losses[1] = iou5; losses[3] = conf; losses[4] = cls; losses[2] = l1;
+        losses[0] = ((iou5 + conf) + cls) + l1;               // the reference's order (tal_head.py:461)
+    }
 }
 
 }  // namespace
@@ -541,7 +553,7 @@ __global__ void tal_zero_losses_kernel(float* losses) {
 extern "C" int64_t sy_tal_loss_workspace_bytes(int B, int A, int max_gt) {
     if (B <= 0 || A <= 0 || max_gt <= 0) return 0;
     if (max_gt > kMaxGT) max_gt = kMaxGT;
-    return tal_layout(A, max_gt).image_bytes * (int64_t)B;
+    return tal_layout(A, max_gt).image_bytes * (int64_t)B + kGradBlocksMax * 4 * (int64_t)sizeof(float);   // + tal_grad_kernel's partial rows
 }
 
 extern "C" int sy_tal_loss(const float* raw, int B, int A, int num_classes, const float* labels, const float* support,
@@ -565,7 +577,6 @@ extern "C" int sy_tal_loss(const float* raw, int B, int A, int num_classes, cons
     g.a0[nlevels] = a0;
     if (a0 != A) return SY_ERR_ARG;
     TalLayout L = tal_layout(A, max_labels);
-    SY_LAUNCH(tal_zero_losses_kernel, dim3(1), dim3(64), 0, stream, losses);
     SY_LAUNCH(tal_prep_kernel, dim3((A + 255) / 256, B), dim3(256), 0, stream, raw, A, num_classes, labels, support, max_labels, g,
               gamma, ignore_thr, ignore_value, (unsigned char*)workspace, L);
     SY_LAUNCH(tal_match_kernel, dim3(max_labels, B), dim3(256), 0, stream, raw, A, num_classes, labels, max_labels, g,
@@ -575,9 +586,33 @@ extern "C" int sy_tal_loss(const float* raw, int B, int A, int num_classes, cons
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
     long long work = (long long)B * A;
     int blocks = (int)((work + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kGradBlocksMax) blocks = kGradBlocksMax;
+    float* const block_part = reinterpret_cast<float*>((unsigned char*)workspace + L.image_bytes * (long long)B);
     SY_LAUNCH(tal_grad_kernel, dim3(blocks), dim3(256), 0, stream, raw, B, A, num_classes, labels, max_labels, g, gamma,
-              use_l1, (const unsigned char*)workspace, L, d_raw, losses, fg_mask, d_pad, pad_dtype);
+              use_l1, (const unsigned char*)workspace, L, d_raw, losses, fg_mask, d_pad, pad_dtype, block_part);
+    SY_LAUNCH(tal_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)block_part, blocks, losses);
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+// Read-out of the last sy_tal_loss call's assignment (tests / diagnostics): per anchor the matched ground-truth index (-1 =
+// background) and its IoU, as the reference's get_assignments returns them (tal_head.py:559-600: matched_gt_inds,
+// pred_ious_this_matching) — the foreground MASK alone cannot show an anchor re-matched to another box.
+namespace {
+__global__ void tal_assignment_kernel(const unsigned char* ws, TalLayout L, int A, int32_t* matched_gt, float* matched_iou) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (a >= A) return;
+    const unsigned char* wsi = ws + (long long)b * L.image_bytes;
+    const int g = reinterpret_cast<const int*>(wsi + L.agt)[a];
+    if (matched_gt != nullptr) matched_gt[(long long)b * A + a] = g;
+    if (matched_iou != nullptr) matched_iou[(long long)b * A + a] = g >= 0 ? reinterpret_cast<const float*>(wsi + L.aiou)[a] : 0.0f;
+}
+}  // namespace
+
+extern "C" int sy_tal_loss_assignment(const void* workspace, int B, int A, int max_labels, int32_t* matched_gt,
+                                      float* matched_iou, void* stream) {
+    if (workspace == nullptr || B <= 0 || A <= 0 || max_labels <= 0 || max_labels > kMaxGT || (matched_gt == nullptr && matched_iou == nullptr))
+        return SY_ERR_ARG;
+    SY_LAUNCH(tal_assignment_kernel, dim3((A + 255) / 256, B), dim3(256), 0, stream, (const unsigned char*)workspace,
+              tal_layout(A, max_labels), A, matched_gt, matched_iou);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 SY_PROBE_READER(sy_probe_read_tal_loss)

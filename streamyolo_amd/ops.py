@@ -455,6 +455,15 @@ def tal_loss(raw, labels, support, num_classes, gamma, ignore_thr, ignore_value,
     return ws.losses, ws.d_raw, ws.fg
 
 
+def tal_assignment(ws):
+    """(matched_gt [B, A] int32, -1 = background; matched_iou [B, A] fp32) of the last tal_loss call on `ws` (sy_tal_loss_assignment)."""
+    mg = torch.empty((ws.B, ws.A), dtype=torch.int32, device=ws.ws.device)
+    mi = torch.empty((ws.B, ws.A), dtype=torch.float32, device=ws.ws.device)
+    check(_lib.lib().sy_tal_loss_assignment(ws.ws.data_ptr(), ws.B, ws.A, ws.max_labels, mg.data_ptr(), mi.data_ptr(),
+                                            stream_of(ws.ws)), "sy_tal_loss_assignment")
+    return mg, mi
+
+
 # ---------------------------------------------------------------------------------------------------
 # per-shape kernel-variant selection for sy_conv2d (measured once per shape on the device, cached)
 # ---------------------------------------------------------------------------------------------------

@@ -37,6 +37,10 @@ from .ops import View, EPI_LINEAR, CONV_DGRAD
 # replicas that make it 0.1-0.26 ms faster break the 1e-5 run-to-run reproducibility of the fp16 step — profiles/r02/t_*, u_*,
 # profiles/r04/d_bench_ff8.json)
 _FUSED_FINALIZE = __import__("os").environ.get("STREAMYOLO_FUSED_FINALIZE", "0") != "0"
+# exact (fp32) mode: one statistics replica row per workgroup -> run-to-run bit-equal steps (TrainPlan.__init__); "0" = the
+# replica counts of the speed modes (A/B switch)
+EXACT_STATS = __import__("os").environ.get("STREAMYOLO_EXACT_STATS", "1") != "0"
+_BN_REDUCE_BLOCKS = int(__import__("os").environ.get("SY_BN_REDUCE_BLOCKS", "768"))   # csrc/train_ops.hip: cap_reduce
 # Measured and REMOVED in round 4 (profiles/r04/README.md): BatchNorm finalisation by the producing convolution's last workgroup
 # (every statistics launch got 8-13 us slower — each workgroup waits for its own atomics and a ticket round trip — the l step
 # 22.6-23.9 vs 22.3-23.0 ms at 2 ... 32 replicas) and BatchNorm backward as one resident launch whose workgroups wait for each
@@ -314,11 +318,23 @@ class TrainPlan:
         # ---- per-op training state carved out of flat arenas (zeroed with one memset each) ---------
         convs = [op for op in self.ops if op.kind == "conv"]
         tot_c = sum(op.y.C for op in convs)
-        SC = self.STAT_COPIES
-        self.stat_arena = torch.zeros(2 * SC * tot_c, dtype=torch.float32, device=device)  # [sum | sumsq] x copies
-        BC = self.BWD_COPIES
-        self.bwd_arena = torch.zeros(2 * BC * tot_c, dtype=torch.float32, device=device)  # [copies][sum dz | sum dz*xhat]
+        # Replicas of the statistics arrays, per conv.  Speed modes: STAT_COPIES / BWD_COPIES everywhere (fp32 atomics of many
+        # workgroups per replica: the sums depend on their arrival order in the last bits).  EXACT mode (fp32 compute, round 5):
+        # every workgroup gets a replica row of its own — one `0 + x` atomic per row and channel — and the finalize / fold
+        # launches add the rows in index order, so two identical steps are bit-equal and SimOTA's discrete decisions
+        # (tal_head.py:679-712) no longer flip between runs.  Rows: forward = pixel tiles of a frame's launch (<= N * H *
+        # ceil(W / 32), whatever tile the tuner picks); backward reduce = its workgroup cap (SY_BN_REDUCE_BLOCKS, 768).
+        self.exact_stats = EXACT_STATS and self.dtype == ops.DT_F32
+        def copies_of(op):
+            if not self.exact_stats:
+                return self.STAT_COPIES, self.BWD_COPIES
+            return max(self.STAT_COPIES, op.y.N * op.y.H * ((op.y.W + 31) // 32)), max(self.BWD_COPIES, _BN_REDUCE_BLOCKS)
+        for op in convs:
+            op.stat_copies, op.bwd_copies = copies_of(op)
+        self.stat_arena = torch.zeros(2 * sum(op.stat_copies * op.y.C for op in convs), dtype=torch.float32, device=device)  # [sum | sumsq] x copies
+        self.bwd_arena = torch.zeros(2 * sum(op.bwd_copies * op.y.C for op in convs), dtype=torch.float32, device=device)   # [copies][sum dz | sum dz*xhat]
         self.aff_arena = torch.empty(4 * tot_c, dtype=torch.float32, device=device)       # scale|shift|mean|invstd
+        sq0 = self.stat_arena.numel() // 2                     # the sumsq half of the statistics arena
         off = 0
         max_raw = 0
         nf = self.n_frame_ops
@@ -334,11 +350,15 @@ class TrainPlan:
         # frame keeps its own batch statistics, like the reference's two backbone passes (dfp_pafpn.py:120-165).
         units = [(self.ops[i], self.ops[nf + i]) for i in range(nf) if self.ops[i].kind == "conv"]
         units += [(op,) for op in self.ops[2 * nf:] if op.kind == "conv"]
+        s_off = b_off = 0
         for unit in units:
             C, S = unit[0].y.C, len(unit)
-            u_sum = self.stat_arena[SC * off:SC * (off + S * C)]
-            u_sq = self.stat_arena[SC * (tot_c + off):SC * (tot_c + off + S * C)]
-            u_bsum = self.bwd_arena[2 * BC * off:2 * BC * (off + S * C)]
+            SC, BC = unit[0].stat_copies, unit[0].bwd_copies
+            u_sum = self.stat_arena[s_off:s_off + SC * S * C]
+            u_sq = self.stat_arena[sq0 + s_off:sq0 + s_off + SC * S * C]
+            u_bsum = self.bwd_arena[b_off:b_off + 2 * BC * S * C]
+            s_off += SC * S * C
+            b_off += 2 * BC * S * C
             u_aff = tuple(self.aff_arena[k * tot_c + off:k * tot_c + off + S * C] for k in range(4))
             for s_, op in enumerate(unit):
                 op.stat = (u_sum[s_ * SC * C:(s_ + 1) * SC * C], u_sq[s_ * SC * C:(s_ + 1) * SC * C])
@@ -476,7 +496,7 @@ class TrainPlan:
             mods = {}
             for op in self.ops:                                      # plan order == the reference's call order
                 if op.kind == "conv":
-                    c0, ctot, SC = 0, op.y.C, self.STAT_COPIES
+                    c0, ctot, SC = 0, op.y.C, op.stat_copies
                     for m in base_convs(op.mod):                     # a stacked launch: each module's channel slice of the arrays
                         mods.setdefault(id(m.bn), (m.bn, []))[1].append((op.stat[0][c0:], op.stat[1][c0:], op.y.pixels, SC, ctot))
                         c0 += m.bn.num_features

@@ -46,7 +46,7 @@ y = View.alloc(N, Ho, Wo, cout, "bf16", dev); y.buf.copy_(torch.randn(y.buf.shap
 w = (torch.randn(cout, k * k * cin, generator=g) / (cin * k * k) ** 0.5).to(x.buf.dtype).to(dev)
 from streamyolo_amd.model.packing import pack_conv_weight_frag      # noqa: E402
 wf = pack_conv_weight_frag(w, k)
-reader = {"conv": "sy_probe_read_conv_extra" if a.tile >= 105 else "sy_probe_read_conv_igemm", "wgrad": "sy_probe_read_wgrad",
+reader = {"conv": "sy_probe_read_conv_extra" if (a.tile >= 104 and a.tile != 119 and a.tile not in (102, 103)) else "sy_probe_read_conv_igemm", "wgrad": "sy_probe_read_wgrad",
           "bnred": "sy_probe_read_train_ops"}[a.kind]
 read = getattr(C.CDLL(_lib.library_path()), reader)
 read.argtypes, read.restype = [C.c_void_p, C.c_int], C.c_int
@@ -105,5 +105,8 @@ for i, nm in enumerate(names, start=1):
     d = (t[:, i] - t[:, prev]) / 100.0
     print("  %-52s p50 %6.2f  p90 %6.2f us" % (nm, pc(d, 50), pc(d, 90)))
     prev = i
+if (t[:, 7] > 0).all():
+    d = (t[:, 3] - t[:, 7]) / 100.0
+    print("  %-52s p50 %6.2f  p90 %6.2f us" % ("(of the main loop: K-group reduction / loop exit -> slot 3)", pc(d, 50), pc(d, 90)))
 life = (t[:, 6] - t[:, 0]) / 100.0
 print("  workgroup lifetime                                    p50 %6.2f  p90 %6.2f us" % (pc(life, 50), pc(life, 90)))
