@@ -221,8 +221,7 @@ void conv3x3_halo2_kernel(ConvArgs p) {
     constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;
     constexpr int BUF = NW * NI * 16 * 64;
     constexpr int BD = (TC * TP <= 2) ? SY_HALO2_BD : 3;   // pixel-fragment ring: BD - 1 (tap, k-half) steps of reads in flight
-    static_assert(NW == 4 || NW == 8 || (KS > 1 && NW <= 2), "4 or 8 waves (1, 2 or 4 per K group)");
-    static_assert(NW * KS <= 8, "at most 8 waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || (KS > 1 && NW <= 2), "4 or 8 waves (1 or 2 per K group)");
     static_assert(NI <= 9, "one DMA piece per tap");
 
     SY_DYN_SMEM(smem);
@@ -468,13 +467,9 @@ int launch_halo_typed(const ConvArgs& a, void* stream) {
         // (64 ch x 4 groups and 128 ch x 2 groups measured no better than 111 / 117: the main loop follows the weight bytes per CU)
         case 106: return launch_halo<T, 1, 1, 1, 2, 2, 0, 4>(a, stream);  //  32 ch x (2 rows x 32 px), 4 groups of 1 wave
         case 105: return launch_halo<T, 2, 1, 1, 1, 2, 1, 2>(a, stream);  // STRIDE 2 forward, 64 ch x (1 row x 32 px), 2 groups of 2 waves
-        // round 5: the training tiles 104 / 107 / 117 / 118 as TWO K groups of four waves = two waves per SIMD that contract alternate
-        // channel slabs (SQ counters, profiles/r05: a 104 wave is parked in s_waitcnt / s_barrier for 30 % of its life and MFMA-busy for
-        // 48 %, LDS 26 % busy, 3.7 % bank-conflict cycles: with one wave per SIMD nothing covers the parked time)
-        case 125: return launch_halo<T, 4, 1, 1, 5, 2, 0, 2>(a, stream);  // 128 ch x (5 rows x 32 px), 2 groups of 4 waves
-        case 126: return launch_halo<T, 4, 1, 1, 3, 2, 0, 2>(a, stream);  // 128 ch x (3 rows x 32 px)
-        case 127: return launch_halo<T, 4, 1, 1, 2, 2, 0, 2>(a, stream);  // 128 ch x (2 rows x 32 px)
-        case 120: return launch_halo<T, 4, 1, 1, 4, 2, 0, 2>(a, stream);  // 128 ch x (4 rows x 32 px)
+        // (round 5: 104 / 107 / 117 / 118 as TWO K groups of four waves = two waves per SIMD contracting alternate channel slabs were
+        //  measured and removed — the two waves run in lockstep, the SIMD's MFMA rate does not change (main loop 17.9 vs 18.8 us at
+        //  256->256 @38x60 x 8) and the partial-tile exchange costs 0.8 us: 5-20 % slower on every training shape, profiles/r05 stage c)
         // STRIDE 2, forward (tile 117's configuration over a parity-split input window): +7 % / +26 % over the implicit-GEMM
         // variants on dark2.0 / dark4.0 (profiles/r04/a_probe_s2_stats.txt)
         case 110: return launch_halo<T, 4, 1, 1, 2, 2, 1>(a, stream);

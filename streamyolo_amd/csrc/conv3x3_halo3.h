@@ -1,0 +1,268 @@
+// conv3x3_halo3.h — third generation of the 3x3 stride-1 window-in-LDS kernel (forward and data gradient), round 5.
+//
+// Replaces the same reference code as conv3x3_halo.h (yolox BaseConv's Conv2d of the Bottleneck / head-tower 3x3 layers —
+// exps/model/darknet.py:118-165 via CSPLayer, dfp_pafpn.py:33-81, tal_head.py:55-104 — and cuDNN backward-data).
+//
+// What the counters of the second generation said (profiles/r05, stages a-d; tile 104 = 128 ch x 5 rows, 256->256 @38x60 x 8):
+//   * LDS is NOT the wall: SQ_LDS_IDX_ACTIVE = 26 % of the kernel, SQ_LDS_BANK_CONFLICT = 3.7 % of that (the XOR swizzle holds);
+//   * a wave is MFMA-busy for 48 % of its life, parked in s_waitcnt / s_barrier for 30 %, and issues 4.3 other instructions per
+//     MFMA in the main loop — 1.6 of them VALU address arithmetic for the ds_read_b128 in front of every MFMA; with the LDS
+//     fragment reads (and their address / wait instructions) ablated the main loop loses 35 % of its time, with the operand loads
+//     ablated another 20 %; a second wave per SIMD (K groups, tiles 120 / 125-127 of stage c) runs in lockstep and buys nothing;
+//   * +2 scalar instructions per MFMA (the ablation branches of stage d) cost the loop +40 %: with one wave per SIMD the loop
+//     is bound by its in-order instruction stream, not by a memory level.
+// So this generation removes instructions from the stream instead of adding waves:
+//   * LDS addresses as IMMEDIATES.  The window keeps its 34-row pitch, but the XOR swizzle of a row's 16-byte chunks is keyed on
+//     the row's COLUMN index hx = row % 34 instead of the linear row — then address(y, hx, chunk) = y * 34 * 64 + g(hx, chunk), and
+//     the 18 x TP fragment reads of a slab are six per-lane base registers (kw x k-half) + compile-time offsets ((tile row + kh) *
+//     2176 B): no VALU per read, 6 address registers instead of 9 x TP.  Conflict freedom is unchanged (a b128 lane group reads 16
+//     columns of ONE window row: four 4-column runs 0 / 12 / 20 / 24 apart = row quads 0 / 3 / 1 / 2 mod 4).
+//   * forward / data gradient as a TEMPLATE parameter (the tap -> window offset map is compile time, as the immediates need);
+//   * the last slab PEELED: no `live` selects on the fragment loads / DMA pieces of the slab after the last one (they are not
+//     issued at all — no dead loads for the final wait to drain);
+//   * DMA pieces take the slab's channel offset through the SGPR offset operand of buffer_load ... lds (no VALU add per piece);
+//     the halo-buffer parity is two v_add per (kw, k-half) base and slab instead of one per read.
+// Tile = 4 waves x (32 ch x TP rows x 32 px) as tiles 117 / 107 / 118 / 104 (the grids that fit the layer sizes).
+// Epilogue: conv_epilogue of conv_igemm_impl.h through the TilePixels mapper.
+#pragma once
+#include "conv3x3_halo.h"
+
+namespace sy_conv {
+
+// LDS-DMA with a wave-uniform byte offset in the instruction's SGPR-offset operand (range check on the VGPR offset alone:
+// 0xFFFFFFFF stays out of range whatever the scalar adds)
+#ifdef SY_EMU
+static inline void sy_glds16_buf_at_s(const sy_buffer& b, unsigned voff, unsigned soff, sy_lds_base_t base, unsigned off) {
+    sy_glds16_buf(b, voff == 0xFFFFFFFFu ? 0xFFFFFFFFu : voff + soff, base + off);
+}
+#else
+__device__ __forceinline__ void sy_glds16_buf_at_s(const sy_buffer& b, unsigned voff, unsigned soff, sy_lds_base_t base, unsigned off) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(base + off);
+    asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(b), "s"(soff), "{m0}"(dst) : "memory");
+}
+#endif
+
+template <typename T, int TP, int DGRAD, int BD, int ILV = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
+    SY_TL_BEGIN(2 + (DGRAD ? 32 : 0));
+    constexpr int NW = 4;
+    constexpr int EPC = T::kEPC;
+    constexpr int ESZ = 16 / EPC;
+    constexpr int BK = 4 * EPC;
+    constexpr int TH = TP;
+    constexpr int RW = kHaloW;                             // 34 window columns per tile row
+    constexpr int HR = (TH + 2) * RW;
+    constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;     // DMA pieces (16 window rows each) per wave and slab
+    constexpr int BUF = NW * NI * 16 * 64;
+    constexpr int RB = RW * 64;                            // bytes between the windows of consecutive tile rows
+    static_assert(NI <= 9, "one DMA piece per tap");
+    static_assert(BUF + (TH + 1) * RB + 34 * 64 < 65536, "fragment offsets are 16-bit immediates");
+
+    SY_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = sy_uniform(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const sy_block_id bid = sy_xcd_block_id();
+    const int tiles_w = (p.Wo + 31) >> 5, tiles_h = (p.Ho + TH - 1) / TH;
+    const int tw = bid.y % tiles_w, th_ = (bid.y / tiles_w) % tiles_h, n = bid.y / (tiles_w * tiles_h);
+    const int h0 = th_ * TH, w0 = tw * 32;
+
+    // ---- DMA assignment: piece i of this wave fills window rows [16 (wave + 4 i), + 16); lane -> (row, physical 16-byte slot);
+    //      the slot of logical chunk c of a row in window column hx is c ^ ((hx >> 2) & 3)
+    const sy_buffer bufx = sy_make_buffer(p.x, p.x_extent);
+    unsigned voff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = (wave + i * NW) * 16 + (lane >> 2);
+        const int hy = r / RW, hx = r - hy * RW;
+        const int h = h0 - 1 + hy, w = w0 - 1 + hx;
+        const int chunk = (lane & 3) ^ ((hx >> 2) & 3);
+        const bool ok = r < HR && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W && !(p.ablate & 1);
+        voff[i] = ok ? (unsigned)((((long long)n * p.xbs + ((long long)h * p.W + w) * p.ldx) + chunk * EPC) * ESZ) : 0xFFFFFFFFu;
+    }
+    const sy_lds_base_t lds0 = sy_lds_base(smem);
+    const int ncs = sy_uniform(p.Cin / BK);
+    auto issue_piece = [&](auto i_, int j) {               // piece I of slab j into buffer j & 1
+        constexpr int I = decltype(i_)::value;
+        sy_glds16_buf_at_s(bufx, voff[I], (unsigned)(j * BK * ESZ), lds0, (unsigned)((j & 1) * BUF + (wave + I * NW) * 1024));
+    };
+
+    // ---- weight fragments [ct][slab][tap][g][64 lanes][16 B]: the wave's 32 channels, one per-lane offset register
+    const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
+    const int ntile32 = (p.Cout + 31) / 32;
+    const int ct = bid.x * NW + wave;
+    const unsigned foff = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
+    const unsigned foff1 = foff == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff + 1024u;      // k-half 1
+    uint4 fr[9][2];
+    auto fetch = [&](auto tap_, int j) {                   // fragments of tap TAP of slab j into their slot
+        constexpr int TAP = decltype(tap_)::value;
+        const unsigned s_f = (unsigned)((j * 9 + TAP) * 2048);
+        fr[TAP][0] = sy_buffer_load16_s(buff, foff, s_f);
+        fr[TAP][1] = sy_buffer_load16_s(buff, foff1, s_f);
+    };
+
+    f32x16 acc[1][TP];
+#pragma unroll
+    for (int u = 0; u < TP; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][u][r] = 0.0f;
+
+    // ---- fragment read bases: window column hx = l31 + ox (ox = the tap's column offset), k-half G; everything else is an immediate
+    unsigned ba[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int hx = l31 + (DGRAD ? 2 - kw : kw);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) ba[kw][g] = (unsigned)(hx * 64 + (((g * 2 + half) ^ ((hx >> 2) & 3)) << 4));
+    }
+
+    sy_probe(0);
+    sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, 0); });
+    sy_static_for<0, 9>([&](auto t_) { fetch(t_, 0); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
+    sy_probe(1);
+
+    // one slab: 18 (tap, k-half) steps of TP MFMAs; the pixel fragments are read BD - 1 steps ahead; behind tap t the slot of tap t is
+    // refilled with the next slab's fragments and (t < NI) piece t of the next slab is issued — unless this is the LAST slab
+    auto slab = [&](auto last_, int j) {
+        constexpr bool LAST = decltype(last_)::value != 0;
+        uint4 b[BD][TP];
+        auto read_step = [&](auto s_) {
+            constexpr int S = decltype(s_)::value;
+            constexpr int TAP = S >> 1, G = S & 1, KH = TAP / 3, KW = TAP % 3;
+            constexpr int OY = DGRAD ? 2 - KH : KH;
+#pragma unroll
+            for (int u = 0; u < TP; ++u)
+                b[S % BD][u] = *reinterpret_cast<const uint4*>(smem + ba[KW][G] + (unsigned)((u + OY) * RB));
+        };
+        sy_static_for<0, BD - 1>([&](auto s_) { read_step(s_); });
+        if constexpr (!ILV) {
+            sy_static_for<0, 18>([&](auto s_) {
+                constexpr int S = decltype(s_)::value;
+                constexpr int TAP = S >> 1, G = S & 1;
+                if constexpr (S + BD - 1 < 18) read_step(sy_int<S + BD - 1>());
+#pragma unroll
+                for (int u = 0; u < TP; ++u) acc[0][u] = sy_mfma_group(T(), fr[TAP][G], b[S % BD][u], acc[0][u]);
+                if constexpr (G == 1 && !LAST) {
+                    fetch(sy_int<TAP>(), j + 1);
+                    if constexpr (TAP < NI) issue_piece(sy_int<TAP>(), j + 1);
+                }
+                sy_sched_fence();
+            });
+        } else {
+            // ILV: the stream placed by hand — behind EVERY MFMA exactly one fragment read of the step BD - 1 ahead and at most one
+            // global load, a scheduling fence after each such group.  (Left to itself the compiler gathers a step's five reads, two
+            // fragment loads and the DMA piece between two MFMAs: ~11 instructions in the shadow of ONE 32-cycle MFMA, then four MFMAs
+            // back to back with nothing to hide behind them.)  An in-order wave can only use an MFMA's shadow for what stands in front
+            // of the next MFMA in program order.
+            sy_static_for<0, 18>([&](auto s_) {
+                constexpr int S = decltype(s_)::value;
+                constexpr int TAP = S >> 1, G = S & 1;
+                sy_static_for<0, TP>([&](auto u_) {
+                    constexpr int U = decltype(u_)::value;
+                    acc[0][U] = sy_mfma_group(T(), fr[TAP][G], b[S % BD][U], acc[0][U]);
+                    if constexpr (S + BD - 1 < 18) {
+                        constexpr int S2 = S + BD - 1, TAP2 = S2 >> 1, G2 = S2 & 1, KH = TAP2 / 3, KW = TAP2 % 3;
+                        constexpr int OY = DGRAD ? 2 - KH : KH;
+                        b[S2 % BD][U] = *reinterpret_cast<const uint4*>(smem + ba[KW][G2] + (unsigned)((U + OY) * RB));
+                    }
+                    if constexpr (G == 1 && !LAST) {
+                        const unsigned s_f = (unsigned)(((j + 1) * 9 + TAP) * 2048);
+                        if constexpr (U == 0) fr[TAP][0] = sy_buffer_load16_s(buff, foff, s_f);          // k-half 0: its MFMAs are a step behind
+                        if constexpr (U == (TP > 2 ? 1 : 0) && TAP < NI) issue_piece(sy_int<TAP>(), j + 1);
+                        if constexpr (U == TP - 1) fr[TAP][1] = sy_buffer_load16_s(buff, foff1, s_f);     // k-half 1: behind its last MFMA
+                    }
+                    sy_sched_fence();
+                });
+            });
+        }
+    };
+
+    for (int j = 0; j < ncs - 1; ++j) {
+        sy_wait_vmcnt<(9 - NI) * 2 + (ILV ? 1 : 0)>();   // the slab's DMA pieces (older than the last 9 - NI taps of fragment loads; ILV: + k-half 1 of the last piece's tap)
+        sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
+        if (j == 0) sy_probe(2);
+        slab(sy_int<0>(), j);
+        const unsigned flip = (j & 1) ? (unsigned)(-BUF) : (unsigned)BUF;      // the other halo buffer
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { ba[kw][0] += flip; ba[kw][1] += flip; }
+    }
+    sy_wait_vmcnt<(9 - NI) * 2 + (ILV ? 1 : 0)>();
+    sy_barrier();
+    if (ncs == 1) sy_probe(2);
+    slab(sy_int<1>(), ncs - 1);
+    sy_wait_vmcnt<0>();
+    sy_barrier();                                 // every wave is done with the window: the epilogue reuses the LDS
+    sy_probe(7);
+
+    SY_LATE_ARGS(ConvArgs, p);
+    sy_probe(3);
+    int e_bx = bid.x, e_n = n, e_h0 = h0, e_w0 = w0, e_by = bid.y;
+    SY_LAUNDER_INT(e_bx); SY_LAUNDER_INT(e_n); SY_LAUNDER_INT(e_h0); SY_LAUNDER_INT(e_w0); SY_LAUNDER_INT(e_by);
+    TilePixels mp;
+    mp.n = e_n; mp.h0 = e_h0; mp.w0 = e_w0; mp.Ho = p_late.Ho; mp.Wo = p_late.Wo; mp.rep = e_by;
+    mp.seg = p_late.seg_M > 0 ? (e_n * p_late.HoWo) / p_late.seg_M : 0;
+    // output pixels of the tile outside the image still see valid input through their window: clear them (the BatchNorm
+    // statistics of the epilogue sum every accumulator)
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        int n_, rem_;
+        if (!mp.map(u * 32 + l31, n_, rem_)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][u][r] = 0.0f;
+        }
+    }
+    conv_epilogue<T, NW, 1, 1, TP>(p_late, mp, e_bx, acc, smem, tid);
+    sy_probe(6);
+    SY_TL_END();
+}
+
+template <typename T, int TP, int BD, int ILV = 0>
+int launch_halo3(const ConvArgs& a_in, void* stream) {
+    constexpr int NW = 4, CT = 128, TH = TP, PT = TH * 32;
+    constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
+    ConvArgs a = a_in;
+    a.s2_classes = 0;
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W || a.ksplit > 1) return SY_ERR_UNSUPPORTED;
+    if (a.Cin % (4 * T::kEPC) != 0 || a.Cin < 4 * T::kEPC || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
+    constexpr size_t smem_k = (size_t)2 * BUF;
+    constexpr size_t smem_e = (size_t)EpiLds<1, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
+    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= StageLimit<NW, 1, 1, TP>::kBytes);
+    constexpr size_t smem_s = (size_t)CT * 8;
+    constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
+    const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
+    dim3 grid((a.Cout + CT - 1) / CT, tiles, 1);
+    const bool dgrad = a.mode == SY_CONV_DGRAD;
+#ifndef SY_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 0, BD, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 1, BD, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return SY_ERR_LAUNCH;
+        attr_done = true;
+    }
+#endif
+    if (dgrad) { SY_LAUNCH((conv3x3_halo3_kernel<T, TP, 1, BD, ILV>), grid, dim3(NW * 64), smem, stream, a); }
+    else { SY_LAUNCH((conv3x3_halo3_kernel<T, TP, 0, BD, ILV>), grid, dim3(NW * 64), smem, stream, a); }
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
+
+// tile codes 120, 125..127 of sy_conv_desc::tile
+template <typename T>
+int launch_halo3_typed(const ConvArgs& a, void* stream) {
+    switch (a.tile) {
+        case 127: return launch_halo3<T, 2, 3>(a, stream);     // 128 ch x (2 rows x 32 px)   (second generation: 117)
+        case 126: return launch_halo3<T, 3, 3>(a, stream);     // 128 ch x (3 rows x 32 px)   (107)
+        case 120: return launch_halo3<T, 4, 3>(a, stream);     // 128 ch x (4 rows x 32 px)   (118)
+        case 125: return launch_halo3<T, 5, 3>(a, stream);     // 128 ch x (5 rows x 32 px)   (104)
+        // the same with the hand-placed instruction stream (ILV)
+        case 109: return launch_halo3<T, 5, 3, 1>(a, stream);
+        case 100: return launch_halo3<T, 3, 3, 1>(a, stream);
+        case 101: return launch_halo3<T, 2, 3, 1>(a, stream);
+        case 98: return launch_halo3<T, 4, 3, 1>(a, stream);
+        default: return SY_ERR_ARG;
+    }
+}
+
+}  // namespace sy_conv

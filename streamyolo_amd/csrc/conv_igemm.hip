@@ -50,7 +50,7 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
         a.ksplit = d->k_splits;
     }
     a.tile = d->tile & 0xff;
-    a.ablate = (d->tile >> 8) & 31;      // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes
+    a.ablate = (d->tile >> 8) & 1023;    // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes, 8 / 16 statistics, 32.. see ConvArgs
     a.HoWo = d->Ho * d->Wo; a.M = d->N * a.HoWo; a.K = d->KH * d->KW * d->Cin;
     switch (d->dtype) {
         case SY_DT_BF16: return sy_conv_launch_bf16(a, stream);

@@ -714,7 +714,7 @@ class TrainPlan:
         self._zero_gradient_arenas()
         losses, d_raw, _ = ops.tal_loss(self.raw, labels, support, self.nc, head.gamma, head.ignore_thr,
                                         head.ignore_value, head.use_l1, self.loss_ws, d_pad=pad)
-        self._packed_for = d_raw if pad is not None else None
+        self._packed_for = (d_raw, d_raw._version) if pad is not None else None     # identity AND content: an in-place scaling repacks
         out = {"total_loss": losses[0], "iou_loss": losses[1], "l1_loss": losses[2], "conf_loss": losses[3],
                "cls_loss": losses[4], "num_fg": losses[5]}
         return out, d_raw
@@ -726,7 +726,8 @@ class TrainPlan:
         parts == "head": afterwards self.fused_grads() holds the gradients of the fused inputs."""
         self._zero_gradient_arenas(wait=True)
         nc = self.nc
-        if self.head is not None and getattr(self, "_packed_for", None) is not d_raw:
+        pf = getattr(self, "_packed_for", None)
+        if self.head is not None and not (pf is not None and pf[0] is d_raw and pf[1] == d_raw._version):
             # pack d_raw as [reg 4 | obj 1 | 0 0 0 | cls nc] in the compute dtype for the MFMA kernels (sy_tal_loss wrote it already
             # when d_raw is the loss's own, unscaled, tensor)
             self.dpad[..., 0:5] = d_raw[..., 0:5]
@@ -1137,6 +1138,21 @@ def get_train_plan(model, x):
     return model._plans.get(key, lambda: TrainPlan(model, B, H, W, dt, x.device, pool=model._plans))
 
 
+class _Pin:
+    """One count of a plan's `pending`, given back exactly once — by release() or when the holder (an autograd node's ctx) dies."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.pending = max(0, self.plan.pending - 1)
+            self.plan = None
+
+    def __del__(self):
+        self.release()
+
+
 class _PlanFunction(torch.autograd.Function):
     """total_loss = TAL(plan.forward(x)); the forward pass also produces d(total)/d(raw) (closed form in
     sy_tal_loss), so backward only scales it by the incoming gradient (GradScaler's loss scale) and
@@ -1149,6 +1165,7 @@ class _PlanFunction(torch.autograd.Function):
         ctx.counted = any(ctx.needs_input_grad)         # False under no_grad: no backward will come
         if ctx.counted:
             plan.pending += 1              # the plan cache must not evict (release) it before this node's backward ran
+            ctx.pin = _Pin(plan)           # ... and is released when backward runs OR the node is dropped without one
         plan.forward(x)
         out, d_raw = plan.loss(labels, support)
         ctx.d_raw = d_raw
@@ -1160,7 +1177,7 @@ class _PlanFunction(torch.autograd.Function):
     def backward(ctx, g_total, _g_stats):
         plan = ctx.plan
         if ctx.counted:
-            plan.pending = max(0, plan.pending - 1)
+            ctx.pin.release()
             ctx.counted = False
         arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
         return (None, None, None, None) + _arena_views(arena, plan.params)
@@ -1189,6 +1206,7 @@ class _BackboneFunction(torch.autograd.Function):
         ctx.counted = any(ctx.needs_input_grad)         # False under no_grad: no backward will come
         if ctx.counted:
             plan.pending += 1
+            ctx.pin = _Pin(plan)
         fused = plan.forward(x)
         return tuple(f.export() for f in fused)
 
@@ -1196,7 +1214,7 @@ class _BackboneFunction(torch.autograd.Function):
     def backward(ctx, *gouts):
         plan = ctx.plan
         if ctx.counted:
-            plan.pending = max(0, plan.pending - 1)
+            ctx.pin.release()
             ctx.counted = False
         arena = plan.backward(None, d_fused=[g.float() for g in gouts]).clone()
         return (None, None) + _arena_views(arena, plan.params)
@@ -1212,6 +1230,7 @@ class _HeadFunction(torch.autograd.Function):
         ctx.counted = any(ctx.needs_input_grad)
         if ctx.counted:
             plan.pending += 1
+            ctx.pin = _Pin(plan)
         plan.forward((f0, f1, f2))
         out, d_raw = plan.loss(labels, support)
         ctx.d_raw = d_raw
@@ -1223,7 +1242,7 @@ class _HeadFunction(torch.autograd.Function):
     def backward(ctx, g_total, _g_stats):
         plan = ctx.plan
         if ctx.counted:
-            plan.pending = max(0, plan.pending - 1)
+            ctx.pin.release()
             ctx.counted = False
         arena = plan.backward((ctx.d_raw * g_total.float()).contiguous()).clone()
         gf = tuple(g.to(plan.tdtype) for g in plan.fused_grads())
@@ -1310,6 +1329,18 @@ class TrainStep:
             model.head.use_l1 = True                # double_trainer.py:209-216 (no_aug_epochs == max_epoch); TALHead's L1
                                                     # branch is unguarded (tal_head.py:435), PIPEHead honours use_l1
 
+    def close(self):
+        """Release the step's pin on its plan (`pending`): the plan cache may evict it again.  Called by __del__; idempotent."""
+        if getattr(self, "plan", None) is not None:
+            self.plan.pending = max(0, self.plan.pending - 1)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                    # noqa: BLE001 (interpreter shutdown)
+            pass
+
     def _ensure(self, x):
         """The plan of this input size, through the model's plan cache on EVERY step (LRU order stays right, a size change gets
         its own plan); the step's current plan is pinned (`pending`) so that other users of the cache — the drop-in path at
@@ -1380,7 +1411,7 @@ class TrainStep:
                 w.wait()                                        # (cuda: the current stream waits for the collective)
             if self.comm_bf16:
                 for lo, hi, _ in plan.buckets:                  # widen the reduced bf16 buckets back into the fp32 arena, averaged
-                    torch.div(self._comm16[lo:hi], self.world, out=plan.arena[lo:hi])
+                    plan.arena[lo:hi].copy_(self._comm16[lo:hi]).div_(self.world)   # widen FIRST: no second bf16 rounding of the quotient
             else:
                 plan.arena.div_(self.world)
             if cuda:

@@ -92,6 +92,59 @@ def test_a_train_step_pins_its_plan_against_the_drop_in_paths_evictions(backend,
     assert st.plan is not pinned and pinned.pending == 0 and st.plan.pending == 1
 
 
+def test_plan_pins_are_released_when_their_holder_goes_away(backend):
+    """a TrainStep that is dropped, and a drop-in forward whose backward never runs (an exception, a validation
+    forward outside no_grad), give their pin on the plan back — otherwise the bounded plan cache could never evict those plans
+    under multi-scale training."""
+    import gc
+    from streamyolo_amd.train_engine import TrainStep
+    cfg = O.OracleConfig.named("nano")
+    model = sy.build_model("nano")
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0), strict=True)
+    model = model.to(backend).train().set_compute_dtype("fp32")
+    model.head.use_l1 = True
+    x = synth_frames(2, 32, 64, seed=40).to(backend)
+    lab, sup = synth_labels(2, 32, 64, cfg.num_classes, num_gt=4, seed=50)
+    t = (lab.to(backend), sup.to(backend))
+    st = TrainStep(model, graph=False)
+    st.step(x, t)
+    plan = st.plan
+    assert plan.pending == 1
+    del st
+    gc.collect()
+    assert plan.pending == 0
+    out = model(x, t)                                        # drop-in forward with grad ...
+    assert plan.pending == 1
+    del out                                                  # ... whose backward never comes
+    gc.collect()
+    assert plan.pending == 0
+    out = model(x, t)
+    out["total_loss"].backward()
+    assert plan.pending == 0
+
+
+def test_backward_repacks_a_raw_gradient_that_was_scaled_in_place(backend):
+    """loss() hands out the plan's persistent d_raw; a caller that scales it IN PLACE (loss scaling) and passes the
+    same tensor must not get the stale unscaled packed copy in the prediction convolutions' gradients."""
+    from streamyolo_amd.train_engine import get_train_plan
+    cfg = O.OracleConfig.named("nano")
+    model = sy.build_model("nano")
+    model.load_state_dict(synth_state_dict(O.param_shapes(cfg), seed=0), strict=True)
+    model = model.to(backend).train().set_compute_dtype("fp32")
+    model.head.use_l1 = True
+    x = synth_frames(2, 32, 64, seed=40).to(backend)
+    lab, sup = synth_labels(2, 32, 64, cfg.num_classes, num_gt=4, seed=50)
+    plan = get_train_plan(model, x)
+    grads = []
+    for scale in (1.0, 4.0):
+        plan.forward(x)
+        _, d_raw = plan.loss(lab.to(backend), sup.to(backend))
+        if scale != 1.0:
+            d_raw.mul_(scale)
+        grads.append(plan.backward(d_raw).clone())
+    assert float((grads[1] - 4.0 * grads[0]).abs().max() / (4.0 * grads[0]).abs().max()) < 1e-5
+
+
 @pytest.mark.gpu
 def test_multiscale_memory_stays_flat_and_later_plans_build_from_the_tuner_cache(tmp_path, monkeypatch):
     """GPU: cycle through five sizes twice with at most three training plans alive: allocated memory after the second cycle
