@@ -155,6 +155,34 @@ def pmc_traffic_full(workload, args, B):
         return None, None, None, "unreadable traffic file"
 
 
+def in_step_utilisation(workload, args, B, flops_step):
+    """What the chip does DURING the overlapped step: from the committed launch timeline of this configuration
+    (tools/step_timeline.py --json, probe build: every launch's first workgroup entry / last exit on the device clock) — the share
+    of the step during which at least one MFMA kernel is resident, the conv FLOPs over THAT time (not over the one-at-a-time sum
+    of kernel durations, which the co-scheduled tuning has made longer than the step), and the resident-launch histogram.  Counts
+    only when measured on this tree's kernel sources."""
+    import glob
+    from streamyolo_amd import _lib
+    if (args.height, args.width) != (600, 960) or args.dtype != "bf16" or B != 8:
+        return None
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "step_timeline_%s_%s.json" % (workload, args.model))))
+    if not hits:
+        return None
+    try:
+        with open(hits[-1]) as fh:
+            d = json.load(fh)
+        src = os.path.relpath(hits[-1], ROOT)
+        out = {"source": src, "commit": d.get("commit"), "key_matches_tree": d.get("kernel_source_key") == _lib.kernel_source_key()}
+        wall, res = float(d["step_ms_first_entry_to_last_exit"]), float(d["mfma_kernel_resident_ms"])
+        out.update({"step_ms_probe_build": round(wall, 3), "mfma_kernel_resident_ms": round(res, 3), "mfma_kernel_resident_frac": round(res / wall, 4),
+                    "achieved_tflops_over_mfma_resident_time": round(flops_step / (res * 1e-3) / 1e12, 1),
+                    "frac_of_peak_over_mfma_resident_time": round(flops_step / (res * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                    "resident_launches_ms": [round(v, 3) for v in d["resident_launches_ms"]]})
+        return out
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def other_configs(args):
     """The other BASELINE.json configurations and the exact-fp32 mode of the headline step, each a short run of THIS file in a child
     process (own plan, own tuner entries; the parent's GPU memory stays allocated — 288 GB), reduced to the figures that matter:
@@ -466,6 +494,11 @@ def main():
         dist.all_gather(every, t)
         rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
         elapsed = max(float(e.item()) for e in every)            # MAX over ranks
+        # every rank's core slice (first core, count; -1 = not pinned), for the line's comm record
+        ct = torch.tensor([pinned[0] if pinned else -1, len(pinned) if pinned else 0], device=dev, dtype=torch.int64)
+        cores_all = [torch.zeros_like(ct) for _ in range(world)]
+        dist.all_gather(cores_all, ct)
+        all_rank_cores = [None if int(c[0]) < 0 else [int(c[0]), int(c[0]) + int(c[1]) - 1] for c in cores_all]
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
@@ -506,7 +539,7 @@ def main():
             w_ms = sum(ms for kind, shp, _, ms, _ in rows if kind == "wgrad")
             w_fl = sum(fl for kind, shp, _, _, fl in rows if kind == "wgrad")
             if d_ms > 0:
-                dominant = {"kernel": "conv3x3_halo2_kernel (3x3 stride-1 forward + data gradient)", "ms_per_step": round(d_ms, 4),
+                dominant = {"kernel": "conv3x3_halo3_kernel / conv3x3_halo2_kernel (3x3 stride-1 forward + data gradient)", "ms_per_step": round(d_ms, 4),
                             "achieved": d_fl / (d_ms * 1e-3) / 1e12, "frac": d_fl / (d_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype],
                             "second": {"kernel": "conv_wgrad9_kernel / conv_wgrad_tr_kernel (+ wgrad_fold)", "ms_per_step": round(w_ms, 4),
                                        "achieved": w_fl / (w_ms * 1e-3) / 1e12 if w_ms > 0 else 0.0,
@@ -517,7 +550,7 @@ def main():
         mfma_ms = sum(v for k, v in prof.items() if k in ("conv", "pred", "dgrad", "wgrad", "conv(pred)", "dgrad(pred)", "wgrad(pred)"))
         ach = flops_pair * B / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         traffic, traffic_src, traffic_commit, traffic_note = pmc_traffic_full(workload, args, B)
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_halo(2)_kernel+conv1x1_tile_kernel" +
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel+conv3x3_halo(2,3)_kernel+conv1x1_tile_kernel" +
                     ("+conv_wgrad_tr_kernel+conv_wgrad9_kernel(+wgrad_fold)" if workload == "train" else ""),
                     "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_unit": "bytes/step (MFMA kernels)",
@@ -525,6 +558,9 @@ def main():
                     "flops_per_step": flops_pair * B, "kernel_ms_per_step": mfma_ms,
                     "per_kind_ms": {k: round(v, 4) for k, v in prof.items()},
                     "dominant": dominant,
+                    "kernel_ms_note": "kernel_ms_per_step / per_kind_ms / dominant: every launch timed ALONE (HIP events, one at a time); the "
+                                      "step overlaps three chains, see in_step",
+                    "in_step": in_step_utilisation(workload, args, B, flops_pair * B),
                     "whole_step_frac": flops_pair * B / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype]}
 
     # ---- beside the headline (1 GPU, default training path): the drop-in boundary and configs[3]'s per-GPU load ----------
@@ -589,6 +625,7 @@ def main():
                 "exposed_allreduce_ms": None if exposed is None else round(exposed, 4),
                 "exposed_note": "last timed step, rank 0: end of backward -> end of the gradient exchange incl. averaging (what backward did not hide)",
                 "rank_cores": pinned,
+                "all_rank_cores": all_rank_cores,           # [first, last] host core of every rank's slice (None: not pinned)
                 "rank_ms_per_step": [round(v, 4) for v in rank_ms]}
 
     cpu = None

@@ -34,7 +34,15 @@ enum {
     SY_EPI_LINEAR = 0,      /* y = acc*scale + shift                                   */
     SY_EPI_SILU = 1,        /* y = silu(acc*scale + shift) [+ residual]  (BaseConv)    */
     SY_EPI_SIGMOID = 2,     /* y = sigmoid(acc*scale + shift)            (cls preds)   */
-    SY_EPI_DECODE = 3       /* ch0,1: (v+grid)*stride; ch2,3: exp(v)*stride; ch4: sigmoid (reg+obj preds) */
+    SY_EPI_DECODE = 3,      /* ch0,1: (v+grid)*stride; ch2,3: exp(v)*stride; ch4: sigmoid (reg+obj preds) */
+    SY_EPI_BNR = 4          /* SY_CONV_DGRAD only (16-bit types, first write): y = acc, and the BatchNorm-backward REDUCE of the layer whose
+                               activation gradient this launch produces rides in the epilogue — with z = that layer's raw conv output
+                               (passed as `res`, same pixel / batch strides as y), its folded affine in `scale` / `shift`:
+                               g = acc * silu'(scale*z + shift);  stat_sum[r][0][c] += sum g,  stat_sum[r][1][c] += sum g*z  over the
+                               tile's pixels, replica r = tile % stat_copies ([copies][2][Cout] as sy_bn_silu_bwd_reduce's `sums`, but
+                               the second row is the RAW moment: sy_bn_silu_bwd_apply takes it with bit 2 of dres_accumulate).
+                               Replaces one sy_bn_silu_bwd_reduce launch and its read of dA (autograd of BatchNorm2d + SiLU,
+                               exps/model/darknet.py:115-165 BaseConv). */
 };
 
 /* workgroup tiles of sy_conv2d (output channels x output pixels) */
@@ -48,6 +56,8 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
                              needs wfrag): 128 ch x 2 rows x 32 px (8 waves) | 128 x 2 | 64 x 8 | 128 x 2 and 128 x 4 software-pipelined;
                              112, 113: software-pipelined, one 32 x 32 MFMA tile per wave (small launches): 64 ch x 2 rows | 128 ch x 2 rows;
                              107, 104: software-pipelined, 128 ch x 3 rows | 128 ch x 5 rows (three / five MFMAs per weight fragment);
+                             101, 100, 98, 109: THIRD generation (csrc/conv3x3_halo3.h) of 117 / 107 / 118 / 104: fragment reads with immediate
+                             offsets, hand-placed instruction stream, prefetch across the channel-slab boundary (same summation order);
                              105, 106, 111: K GROUPS inside the workgroup (small launches; partial tiles summed through LDS in group order — another
                              fp32 summation order than the tiles above): 105 stride 2 forward 64 ch x 1 row, 2 groups | 106 32 ch, 4 groups |
                              111 64 ch, 2 groups (all 2 rows x 32 px);
@@ -295,7 +305,9 @@ SY_API int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldd
  * ([copies][2][C]); optionally dgamma += S1, dbeta += S0.  dres (optional): the gradient view of the residual input of
  * y = silu(bn(conv)) + res (Bottleneck shortcut, DFP add): dres = da, or dres += da when (dres_accumulate & 1) — the same
  * pass that already reads da (replaces a separate sy_view_copy).  dres_accumulate & 2: dgamma / dbeta are accumulated with
- * atomics even for nseg == 1 (the two frames of a pair go through separate launches on different streams). */
+ * atomics even for nseg == 1 (the two frames of a pair go through separate launches on different streams).
+ * dres_accumulate & 4: row 1 of `sums` holds the raw moment sum dz*y as a data gradient's fused reduce leaves it (SY_EPI_BNR);
+ * converted here: sum dz*xhat = invstd * (sum dz*y - mean * sum dz). */
 SY_API int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int ldda, const float* scale,
                                 const float* shift, const float* mean, const float* invstd,
                                 const float* gamma, const float* sums, int copies, void* dy, int lddy,

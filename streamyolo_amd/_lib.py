@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "lib", "libstreamyolo_hip.so")
 
 DT_BF16, DT_F16, DT_F32 = 0, 1, 2
-EPI_LINEAR, EPI_SILU, EPI_SIGMOID, EPI_DECODE = 0, 1, 2, 3
+EPI_LINEAR, EPI_SILU, EPI_SIGMOID, EPI_DECODE, EPI_BNR = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 
 ABI_VERSION = 6          # SY_ABI_VERSION of include/streamyolo_hip.h this binding was written against

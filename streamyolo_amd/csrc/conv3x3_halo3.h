@@ -21,8 +21,13 @@
 //   * the last slab PEELED: no `live` selects on the fragment loads / DMA pieces of the slab after the last one (they are not
 //     issued at all — no dead loads for the final wait to drain);
 //   * DMA pieces take the slab's channel offset through the SGPR offset operand of buffer_load ... lds (no VALU add per piece);
-//     the halo-buffer parity is two v_add per (kw, k-half) base and slab instead of one per read.
-// Tile = 4 waves x (32 ch x TP rows x 32 px) as tiles 117 / 107 / 118 / 104 (the grids that fit the layer sizes).
+//     the halo-buffer parity is two v_add per (kw, k-half) base and slab instead of one per read;
+//   * the stream is PLACED BY HAND (one fragment read and at most one global load behind every MFMA, scheduling fences), one explicit
+//     LGKM wait per step instead of one per MFMA, and the fragment ring runs on ACROSS the slab boundary: the last steps of a slab
+//     prefetch the first steps of the next window, the slab rendezvous stands in front of them (see the kernel).
+// Main loop at 256->256 @38x60 x 8 (720 MFMAs per wave): 18.8 us (tile 104) -> 17.2 (immediates) -> 16.4 us (placed stream, cross-slab
+// prefetch), instructions per MFMA besides the MFMA 4.3 -> 2.2; kernels +7-17 % in tools/conv_probe.py (profiles/r05 stages e-h).
+// Tile = 4 waves x (32 ch x TP rows x 32 px) as tiles 117 / 107 / 118 / 104 -> 101 / 100 / 98 / 109 (the grids that fit the layer sizes).
 // Epilogue: conv_epilogue of conv_igemm_impl.h through the TilePixels mapper.
 #pragma once
 #include "conv3x3_halo.h"
@@ -42,7 +47,28 @@ __device__ __forceinline__ void sy_glds16_buf_at_s(const sy_buffer& b, unsigned 
 }
 #endif
 
-template <typename T, int TP, int DGRAD, int BD, int ILV = 0>
+// explicit LGKM wait (LDS reads): at most N outstanding.  A real S_WAITCNT (not inline asm), so the compiler's own wait insertion
+// sees it and drops the per-MFMA waits it covers.
+#ifdef SY_EMU
+template <int N> static inline void sy_wait_lgkm() {}
+#else
+template <int N> __device__ __forceinline__ void sy_wait_lgkm() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));      // vmcnt = 63, expcnt = 7: untouched
+}
+#endif
+
+// Loads issued behind the last DMA piece (G = 1 step of tap NI - 1, behind its second MFMA) up to the start of step SB of the same
+// slab: k-half 1 of that tap + two fragment loads per later G = 1 step
+constexpr int halo3_loads_behind_pieces(int NI, int SB) {
+    int n = 1;
+    for (int s = 2 * NI; s < SB; ++s) n += (s & 1) ? 2 : 0;
+    return n;
+}
+
+// BD: pixel-fragment ring — the fragments of step S + BD - 1 are requested while step S multiplies.
+// ILV = 1: this generation's stream; ILV = 0 keeps the compiler-ordered step of the first halo3 measurement (profiles/r05 stage e).
+template <typename T, int TP, int DGRAD, int BD, int ILV = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
     SY_TL_BEGIN(2 + (DGRAD ? 32 : 0));
     constexpr int NW = 4;
@@ -55,7 +81,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
     constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;     // DMA pieces (16 window rows each) per wave and slab
     constexpr int BUF = NW * NI * 16 * 64;
     constexpr int RB = RW * 64;                            // bytes between the windows of consecutive tile rows
-    static_assert(NI <= 9, "one DMA piece per tap");
+    constexpr int PF = BD - 1;                             // prefetch distance in (tap, k-half) steps
+    constexpr int SB = 18 - PF;                            // the step whose prefetch is the NEXT slab's step 0: the slab rendezvous sits in front of it
+    static_assert(2 * NI - 1 < SB, "the slab's DMA pieces are issued before the rendezvous");
+    static_assert(TP * PF <= 15, "outstanding fragment reads fit the 4-bit LGKM counter");
+    static_assert(18 % BD == 0, "the fragment ring runs on across slabs: a slab's 18 steps are a whole number of turns");
     static_assert(BUF + (TH + 1) * RB + 34 * 64 < 65536, "fragment offsets are 16-bit immediates");
 
     SY_DYN_SMEM(smem);
@@ -89,19 +119,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
         sy_glds16_buf_at_s(bufx, voff[I], (unsigned)(j * BK * ESZ), lds0, (unsigned)((j & 1) * BUF + (wave + I * NW) * 1024));
     };
 
-    // ---- weight fragments [ct][slab][tap][g][64 lanes][16 B]: the wave's 32 channels, one per-lane offset register
+    // ---- weight fragments [ct][slab][tap][g][64 lanes][16 B]: the wave's 32 channels, one per-lane offset register per k-half
     const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
     const int ntile32 = (p.Cout + 31) / 32;
     const int ct = bid.x * NW + wave;
     const unsigned foff = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
     const unsigned foff1 = foff == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff + 1024u;      // k-half 1
     uint4 fr[9][2];
-    auto fetch = [&](auto tap_, int j) {                   // fragments of tap TAP of slab j into their slot
-        constexpr int TAP = decltype(tap_)::value;
-        const unsigned s_f = (unsigned)((j * 9 + TAP) * 2048);
-        fr[TAP][0] = sy_buffer_load16_s(buff, foff, s_f);
-        fr[TAP][1] = sy_buffer_load16_s(buff, foff1, s_f);
-    };
 
     f32x16 acc[1][TP];
 #pragma unroll
@@ -117,82 +141,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) ba[kw][g] = (unsigned)(hx * 64 + (((g * 2 + half) ^ ((hx >> 2) & 3)) << 4));
     }
+    uint4 b[BD][TP];
+    auto read_frag = [&](auto s_, auto u_) {               // pixel fragment of step S (mod 18: of the window `ba` points at), tile row U
+        constexpr int S = decltype(s_)::value % 18, U = decltype(u_)::value;
+        constexpr int TAP = S >> 1, G = S & 1, KH = TAP / 3, KW = TAP % 3;
+        constexpr int OY = DGRAD ? 2 - KH : KH;
+        b[decltype(s_)::value % BD][U] = *reinterpret_cast<const uint4*>(smem + ba[KW][G] + (unsigned)((U + OY) * RB));
+    };
 
     sy_probe(0);
     sy_static_for<0, NI>([&](auto i_) { issue_piece(i_, 0); });
-    sy_static_for<0, 9>([&](auto t_) { fetch(t_, 0); sy_sched_fence(); });   // in tap order: the compiler's vmcnt waits count on it
+    sy_static_for<0, 9>([&](auto t_) {                     // in tap order: the compiler's vmcnt waits count on it
+        constexpr int TAP = decltype(t_)::value;
+        fr[TAP][0] = sy_buffer_load16_s(buff, foff, (unsigned)(TAP * 2048));
+        fr[TAP][1] = sy_buffer_load16_s(buff, foff1, (unsigned)(TAP * 2048));
+        sy_sched_fence();
+    });
     sy_probe(1);
+    sy_wait_vmcnt<18>();                          // this wave's pieces of slab 0 (older than the 18 fragment loads)
+    sy_barrier();                                 // ... everybody's
+    sy_probe(2);
+    sy_static_for<0, PF>([&](auto s_) { sy_static_for<0, TP>([&](auto u_) { read_frag(s_, u_); }); });
 
-    // one slab: 18 (tap, k-half) steps of TP MFMAs; the pixel fragments are read BD - 1 steps ahead; behind tap t the slot of tap t is
-    // refilled with the next slab's fragments and (t < NI) piece t of the next slab is issued — unless this is the LAST slab
+    // One slab = 18 (tap, k-half) steps of TP MFMAs.  The stream is placed by hand: behind EVERY MFMA exactly one fragment read of the
+    // step PF ahead and at most one global load, a scheduling fence after each such group — an in-order wave can use an MFMA's 32-cycle
+    // shadow only for what stands in front of the NEXT MFMA in program order (left to itself the compiler gathers a step's reads, two
+    // fragment loads and the DMA piece behind one MFMA and issues the other four back to back).  One explicit LGKM wait per step (the
+    // step's fragments were requested PF steps ago) instead of the compiler's wait in front of every MFMA.  The steps SB .. 17 prefetch
+    // steps 0 .. PF - 1 of the NEXT slab's window, so the rendezvous that publishes that window (my pieces landed; every read of this
+    // window complete, for every wave: its buffer is DMA'd again one slab later) stands in front of step SB, not between the slabs.
     auto slab = [&](auto last_, int j) {
         constexpr bool LAST = decltype(last_)::value != 0;
-        uint4 b[BD][TP];
-        auto read_step = [&](auto s_) {
+        sy_static_for<0, 18>([&](auto s_) {
             constexpr int S = decltype(s_)::value;
-            constexpr int TAP = S >> 1, G = S & 1, KH = TAP / 3, KW = TAP % 3;
-            constexpr int OY = DGRAD ? 2 - KH : KH;
+            constexpr int TAP = S >> 1, G = S & 1;
+            if constexpr (!LAST && S == SB) {
+                sy_wait_vmcnt<halo3_loads_behind_pieces(NI, SB)>();
+                sy_wait_lgkm<0>();
+                sy_barrier();
+                const unsigned flip = (j & 1) ? (unsigned)(-BUF) : (unsigned)BUF;       // the other halo buffer from here on
 #pragma unroll
-            for (int u = 0; u < TP; ++u)
-                b[S % BD][u] = *reinterpret_cast<const uint4*>(smem + ba[KW][G] + (unsigned)((u + OY) * RB));
-        };
-        sy_static_for<0, BD - 1>([&](auto s_) { read_step(s_); });
-        if constexpr (!ILV) {
-            sy_static_for<0, 18>([&](auto s_) {
-                constexpr int S = decltype(s_)::value;
-                constexpr int TAP = S >> 1, G = S & 1;
-                if constexpr (S + BD - 1 < 18) read_step(sy_int<S + BD - 1>());
-#pragma unroll
-                for (int u = 0; u < TP; ++u) acc[0][u] = sy_mfma_group(T(), fr[TAP][G], b[S % BD][u], acc[0][u]);
+                for (int kw = 0; kw < 3; ++kw) { ba[kw][0] += flip; ba[kw][1] += flip; }
+            } else {
+                sy_wait_lgkm<(LAST && S + PF > 18) ? TP * (17 - S) : TP * (PF - 1)>();   // this step's fragments are in
+            }
+            sy_static_for<0, TP>([&](auto u_) {
+                constexpr int U = decltype(u_)::value;
+                acc[0][U] = sy_mfma_group(T(), fr[TAP][G], b[S % BD][U], acc[0][U]);
+                if constexpr (!LAST || S + PF < 18) read_frag(sy_int<S + PF>(), u_);
                 if constexpr (G == 1 && !LAST) {
-                    fetch(sy_int<TAP>(), j + 1);
-                    if constexpr (TAP < NI) issue_piece(sy_int<TAP>(), j + 1);
+                    const unsigned s_f = (unsigned)(((j + 1) * 9 + TAP) * 2048);
+                    if constexpr (U == 0) fr[TAP][0] = sy_buffer_load16_s(buff, foff, s_f);          // k-half 0: its MFMAs are a step behind
+                    if constexpr (U == (TP > 2 ? 1 : 0) && TAP < NI) issue_piece(sy_int<TAP>(), j + 1);
+                    if constexpr (U == TP - 1) fr[TAP][1] = sy_buffer_load16_s(buff, foff1, s_f);     // k-half 1: behind its last MFMA
                 }
                 sy_sched_fence();
             });
-        } else {
-            // ILV: the stream placed by hand — behind EVERY MFMA exactly one fragment read of the step BD - 1 ahead and at most one
-            // global load, a scheduling fence after each such group.  (Left to itself the compiler gathers a step's five reads, two
-            // fragment loads and the DMA piece between two MFMAs: ~11 instructions in the shadow of ONE 32-cycle MFMA, then four MFMAs
-            // back to back with nothing to hide behind them.)  An in-order wave can only use an MFMA's shadow for what stands in front
-            // of the next MFMA in program order.
-            sy_static_for<0, 18>([&](auto s_) {
-                constexpr int S = decltype(s_)::value;
-                constexpr int TAP = S >> 1, G = S & 1;
-                sy_static_for<0, TP>([&](auto u_) {
-                    constexpr int U = decltype(u_)::value;
-                    acc[0][U] = sy_mfma_group(T(), fr[TAP][G], b[S % BD][U], acc[0][U]);
-                    if constexpr (S + BD - 1 < 18) {
-                        constexpr int S2 = S + BD - 1, TAP2 = S2 >> 1, G2 = S2 & 1, KH = TAP2 / 3, KW = TAP2 % 3;
-                        constexpr int OY = DGRAD ? 2 - KH : KH;
-                        b[S2 % BD][U] = *reinterpret_cast<const uint4*>(smem + ba[KW][G2] + (unsigned)((U + OY) * RB));
-                    }
-                    if constexpr (G == 1 && !LAST) {
-                        const unsigned s_f = (unsigned)(((j + 1) * 9 + TAP) * 2048);
-                        if constexpr (U == 0) fr[TAP][0] = sy_buffer_load16_s(buff, foff, s_f);          // k-half 0: its MFMAs are a step behind
-                        if constexpr (U == (TP > 2 ? 1 : 0) && TAP < NI) issue_piece(sy_int<TAP>(), j + 1);
-                        if constexpr (U == TP - 1) fr[TAP][1] = sy_buffer_load16_s(buff, foff1, s_f);     // k-half 1: behind its last MFMA
-                    }
-                    sy_sched_fence();
-                });
-            });
-        }
+        });
     };
 
-    for (int j = 0; j < ncs - 1; ++j) {
-        sy_wait_vmcnt<(9 - NI) * 2 + (ILV ? 1 : 0)>();   // the slab's DMA pieces (older than the last 9 - NI taps of fragment loads; ILV: + k-half 1 of the last piece's tap)
-        sy_barrier();                             // ... everybody's; every wave is done reading the other buffer
-        if (j == 0) sy_probe(2);
-        slab(sy_int<0>(), j);
-        const unsigned flip = (j & 1) ? (unsigned)(-BUF) : (unsigned)BUF;      // the other halo buffer
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) { ba[kw][0] += flip; ba[kw][1] += flip; }
-    }
-    sy_wait_vmcnt<(9 - NI) * 2 + (ILV ? 1 : 0)>();
-    sy_barrier();
-    if (ncs == 1) sy_probe(2);
+    for (int j = 0; j < ncs - 1; ++j) slab(sy_int<0>(), j);
     slab(sy_int<1>(), ncs - 1);
-    sy_wait_vmcnt<0>();
     sy_barrier();                                 // every wave is done with the window: the epilogue reuses the LDS
     sy_probe(7);
 
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
     SY_TL_END();
 }
 
-template <typename T, int TP, int BD, int ILV = 0>
+template <typename T, int TP, int BD, int ILV = 1>
 int launch_halo3(const ConvArgs& a_in, void* stream) {
     constexpr int NW = 4, CT = 128, TH = TP, PT = TH * 32;
     constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
@@ -248,19 +257,15 @@ int launch_halo3(const ConvArgs& a_in, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-// tile codes 120, 125..127 of sy_conv_desc::tile
+// tile codes 98, 100, 101, 109 of sy_conv_desc::tile.  (A ring of 6 for the 2- / 3-row tiles — five steps of reads in flight — measured
+// the same or slower than the ring of 3: profiles/r05 stage h.)
 template <typename T>
 int launch_halo3_typed(const ConvArgs& a, void* stream) {
     switch (a.tile) {
-        case 127: return launch_halo3<T, 2, 3>(a, stream);     // 128 ch x (2 rows x 32 px)   (second generation: 117)
-        case 126: return launch_halo3<T, 3, 3>(a, stream);     // 128 ch x (3 rows x 32 px)   (107)
-        case 120: return launch_halo3<T, 4, 3>(a, stream);     // 128 ch x (4 rows x 32 px)   (118)
-        case 125: return launch_halo3<T, 5, 3>(a, stream);     // 128 ch x (5 rows x 32 px)   (104)
-        // the same with the hand-placed instruction stream (ILV)
-        case 109: return launch_halo3<T, 5, 3, 1>(a, stream);
-        case 100: return launch_halo3<T, 3, 3, 1>(a, stream);
-        case 101: return launch_halo3<T, 2, 3, 1>(a, stream);
-        case 98: return launch_halo3<T, 4, 3, 1>(a, stream);
+        case 101: return launch_halo3<T, 2, 3>(a, stream);     // 128 ch x (2 rows x 32 px)   (second generation: 117)
+        case 100: return launch_halo3<T, 3, 3>(a, stream);     // 128 ch x (3 rows x 32 px)   (107)
+        case 98: return launch_halo3<T, 4, 3>(a, stream);      // 128 ch x (4 rows x 32 px)   (118)
+        case 109: return launch_halo3<T, 5, 3>(a, stream);     // 128 ch x (5 rows x 32 px)   (104)
         default: return SY_ERR_ARG;
     }
 }

@@ -17,7 +17,15 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     if (d->stride != 1 && d->stride != 2) return SY_ERR_UNSUPPORTED;
     if (d->KH < 1 || d->KW < 1 || d->KH * d->KW > 49) return SY_ERR_UNSUPPORTED;
     if ((d->stat_sum == nullptr) != (d->stat_sqsum == nullptr)) return SY_ERR_ARG;
-    if (d->epilogue < SY_EPI_LINEAR || d->epilogue > SY_EPI_DECODE) return SY_ERR_ARG;
+    if (d->epilogue < SY_EPI_LINEAR || d->epilogue > SY_EPI_BNR) return SY_ERR_ARG;
+    if (d->epilogue == SY_EPI_BNR) {    // fused BatchNorm-backward reduce: data gradient, first write, z in `res` with y's strides
+        if (d->mode != SY_CONV_DGRAD || d->accumulate || d->y_f32 || d->dtype == SY_DT_F32 || d->res == nullptr || d->scale == nullptr ||
+            d->shift == nullptr || d->stat_sum == nullptr || d->ldr != d->ldy || d->rbs != d->ybs || d->stat_segments > 1)
+            return SY_ERR_UNSUPPORTED;
+        const int t = d->tile & 0xff;       // the staged epilogue of the 128-channel 3x3 stride-1 window tiles carries it
+        if (t != 98 && t != 100 && t != 101 && t != 109 && t != 104 && t != 107 && t != 117 && t != 118) return SY_ERR_UNSUPPORTED;
+        if (d->KH != 3 || d->stride != 1 || (d->ldy & 7) != 0 || (d->Cout & 7) != 0) return SY_ERR_UNSUPPORTED;
+    }
     if ((long long)d->N * d->Ho * d->Wo > 0x7fffffffLL) return SY_ERR_UNSUPPORTED;
     ConvArgs a;
     a.x = (const unsigned char*)d->x; a.w = (const unsigned char*)d->w;

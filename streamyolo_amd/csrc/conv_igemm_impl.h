@@ -611,7 +611,8 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
     const int c0 = bx * CT;
     const bool vec_ok = (p.epilogue != SY_EPI_DECODE) && ((p.Cout & 3) == 0) && ((p.ldy & 3) == 0) &&
                         (p.res == nullptr || (p.ldr & 3) == 0);
-    const bool want_stats = (p.stat_sum != nullptr);
+    const bool bnr = (p.epilogue == SY_EPI_BNR);                 // fused BatchNorm-backward reduce of the producing layer (data gradient)
+    const bool want_stats = (p.stat_sum != nullptr) && !bnr;
     // Output staging (16-bit outputs without residual / accumulate): the MFMA accumulator layout gives a lane 4
     // channels of one pixel, i.e. 8-byte stores 2*ldy bytes apart — 64 partial cache lines per store instruction,
     // and the 1x1 layers were bound by exactly that.  Instead the wave parks its converted tile in LDS as
@@ -626,7 +627,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
     // (residual adds — the eval Bottleneck convs — take the staged path too when the residual tile can be loaded as whole pixel
     //  rows: it is parked in the staging rows first, every lane adds its own 4-channel groups in fp32 and rounds ONCE, in place)
     constexpr bool kResStage = (WC * TC >= TP);                 // residual row offsets reuse the statistics scratch [WP][CT][2]
-    const bool res_ok = p.res == nullptr || (kResStage && !want_stats && !p.accumulate && ((p.ldr & 7) == 0) &&
+    const bool res_ok = p.res == nullptr || bnr || (kResStage && !want_stats && !p.accumulate && ((p.ldr & 7) == 0) &&
                                              (p.epilogue == SY_EPI_LINEAR || p.epilogue == SY_EPI_SILU) &&      // = the lean path below
                                              ((reinterpret_cast<unsigned long long>(p.res) & 15ull) == 0));
     const bool stage_out = kCanStage && vec_ok && !p.y_f32 && res_ok && ((p.ldy & 7) == 0) &&
@@ -638,13 +639,16 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
     //      residual): the mode, affine and statistics decisions are taken ONCE here, not per element — the general
     //      loop below re-tests them for each of its 16 x TP values per tile, and at 1x1 layers (4-16 slabs of MFMA
     //      per tile) those ~2500 scalar-ish instructions per wave were the whole kernel time.
-    const bool lean = kCanStage && stage_out && (p.epilogue == SY_EPI_LINEAR || p.epilogue == SY_EPI_SILU) &&
+    const bool lean = kCanStage && stage_out && (p.epilogue == SY_EPI_LINEAR || p.epilogue == SY_EPI_SILU || bnr) &&
                       (!want_stats || (p.epilogue == SY_EPI_LINEAR && p.scale == nullptr && p.shift == nullptr));
     if (lean) {
         if constexpr (kCanStage) {
             auto body = [&](auto silu_, auto aff_, auto stats_, auto res_) {
-                constexpr bool SILU = decltype(silu_)::value != 0, AFF = decltype(aff_)::value != 0,
-                               STATS = decltype(stats_)::value != 0, RES = decltype(res_)::value != 0;
+                // res_ = 2: BNR — the staged rows are first filled with the producing layer's raw output z (as a residual tile would
+                // be, through the output offsets: z has y's strides), every lane then turns its own values into g = acc * silu'(scale z
+                // + shift), accumulates sum g / sum g z per channel (the statistics reduction below) and overwrites z with acc
+                constexpr bool SILU = decltype(silu_)::value != 0, AFF = decltype(aff_)::value != 0, BNR = decltype(res_)::value == 2,
+                               STATS = decltype(stats_)::value != 0 || BNR, RES = decltype(res_)::value == 1;
                 long long* const stg_roff = reinterpret_cast<long long*>(smem);     // [PT] residual row offsets (RES only)
                 if (wc == 0 && half == 0) {                         // output element offset of every tile pixel, once
 #pragma unroll
@@ -658,6 +662,19 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                         stg_off[(wp * TP + u) * 32 + l31] = off;
                         if (RES) stg_roff[(wp * TP + u) * 32 + l31] = roff;
                     }
+                }
+                if constexpr (BNR) {                                // z of the producing layer, whole pixel rows, into the staging rows
+                    __syncthreads();
+                    constexpr int CPR = CT / 8;
+                    for (int i = tid; i < PT * CPR; i += kThreads) {
+                        const int px = i / CPR, ck = i - px * CPR;
+                        const long long off = stg_off[px];
+                        const int co = c0 + ck * 8;
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (off >= 0 && co < p.Cout) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const elem*>(p.res) + off + co);
+                        *reinterpret_cast<uint4*>(stg + px * kStagePitch + ck * 16) = v;
+                    }
+                    __syncthreads();
                 }
                 if constexpr (RES) {                                // the residual tile, whole pixel rows, into the staging rows
                     __syncthreads();
@@ -677,7 +694,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                     float sc[16], sh[16], ssum[16], ssq[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (AFF) {
+                        if (AFF || BNR) {
                             const int co = sy_min(c0 + (wc * TC + t) * 32 + (r >> 2) * 8 + half * 4 + (r & 3), p.Cout - 1);
                             sc[r] = p.scale[co]; sh[r] = p.shift[co];
                         }
@@ -689,6 +706,18 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             float v[4];
+                            if constexpr (BNR) {
+                                const uint2 zz = *reinterpret_cast<const uint2*>(row + q * 16);
+                                elem ze[4];
+                                __builtin_memcpy(ze, &zz, 8);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float a = acc[t][u][q * 4 + j], zf = T::to_f32(ze[j]);
+                                    const float g = a * sy_silu_grad(zf * sc[q * 4 + j] + sh[q * 4 + j]);
+                                    ssum[q * 4 + j] += g; ssq[q * 4 + j] += g * zf;
+                                    v[j] = a;
+                                }
+                            } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const float a = acc[t][u][q * 4 + j];
@@ -696,6 +725,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                                 float z = AFF ? a * sc[q * 4 + j] + sh[q * 4 + j] : a;
                                 if (SILU) z = sy_silu(z);
                                 v[j] = z;
+                            }
                             }
                             if (RES) {                              // this lane's own 4 channels of its pixel: read, add, round once
                                 const uint2 rr = *reinterpret_cast<const uint2*>(row + q * 16);
@@ -721,7 +751,8 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             };
             const bool aff = p.scale != nullptr && p.shift != nullptr;
             const bool silu = p.epilogue == SY_EPI_SILU;
-            if (want_stats) body(sy_int<0>(), sy_int<0>(), sy_int<1>(), sy_int<0>());          // training forward: raw output + statistics
+            if (bnr) body(sy_int<0>(), sy_int<0>(), sy_int<0>(), sy_int<2>());                 // data gradient + the producer's BatchNorm-backward reduce
+            else if (want_stats) body(sy_int<0>(), sy_int<0>(), sy_int<1>(), sy_int<0>());     // training forward: raw output + statistics
             else if (p.res != nullptr) {
                 if constexpr (kResStage) {
                     if (silu && aff) body(sy_int<1>(), sy_int<1>(), sy_int<0>(), sy_int<1>());   // eval Bottleneck conv with shortcut
@@ -885,6 +916,19 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
         }
     }
     sy_probe(5);
+    if (bnr && lean) {                                          // sums [copies][2][Cout]: row 0 = sum g, row 1 = sum g z (raw moment)
+        const float* red = reinterpret_cast<const float*>(smem);
+        float* const dst = p.stat_sum + (long long)((unsigned)mp.rep % (unsigned)p.stat_copies) * 2 * p.Cout;
+        for (int cl = tid; cl < CT; cl += kThreads) {
+            const int co = c0 + cl;
+            if (co >= p.Cout) continue;
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WP; ++w) { a += red[(w * CT + cl) * 2]; b += red[(w * CT + cl) * 2 + 1]; }
+            atomicAdd(dst + co, a);
+            atomicAdd(dst + p.Cout + co, b);
+        }
+    }
     if (want_stats && !(p.ablate & 8)) {
         const float* red = reinterpret_cast<const float*>(smem);
         const int copy = mp.seg * p.stat_copies + (int)((unsigned)mp.rep % (unsigned)p.stat_copies);
@@ -943,7 +987,7 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
 }
 
 template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 104..107, 110..118)
-template <typename T> int launch_halo3_typed(const ConvArgs& a, void* stream);     // conv3x3_halo3.h (tile codes 120, 125..127)
+template <typename T> int launch_halo3_typed(const ConvArgs& a, void* stream);     // conv3x3_halo3.h (tile codes 98, 100, 101, 109)
 template <typename T> int launch_s2dgrad(const ConvArgs& a, void* stream);         // conv3x3_s2dgrad.h (tile code 108)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..124)
 template <typename T> int launch_bottleneck_fused(const ConvArgs& a, void* stream); // bottleneck_fused.h (tile code 119)
@@ -951,7 +995,7 @@ template <typename T> int launch_bottleneck_fused(const ConvArgs& a, void* strea
 template <typename T>
 int launch_typed(const ConvArgs& a, void* stream) {
     if ((a.tile >= 104 && a.tile <= 107) || (a.tile >= 110 && a.tile <= 118)) return launch_halo_typed<T>(a, stream);
-    if (a.tile == 120 || (a.tile >= 125 && a.tile <= 127) || a.tile == 109 || a.tile == 100 || a.tile == 101 || a.tile == 98) return launch_halo3_typed<T>(a, stream);
+    if (a.tile == 109 || a.tile == 100 || a.tile == 101 || a.tile == 98) return launch_halo3_typed<T>(a, stream);
     if (a.tile == 119) return launch_bottleneck_fused<T>(a, stream);
     if (a.tile == 108) return launch_s2dgrad<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 124) return launch_1x1_tile<T>(a, stream);

@@ -486,8 +486,15 @@ constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (
 // PD: (k-half, tap) steps whose x fragments are requested ahead of the step that multiplies (ring of PD + 1 fragments).  PD = 4
 // (+ 8 VGPRs, waits become lgkmcnt(6)) was measured against PD = 2 in round 4: 3-8 % SLOWER on every 3x3 layer
 // (profiles/r04/a_probe_wgrad.txt) — removed; so was the eight-wave variant of this tile (ties, round 2).
-template <typename T, int STG, int PD = 2>
-__global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
+// SPB (round 5): slabs per rendezvous.  A 32-pixel slab is 18 MFMAs = 576 cycles of the matrix pipe; the in-kernel timeline
+// (profiles/r04 stage i) has it at 1430: the counted wait + barrier + the ~70 scalar / vector instructions that place the next slab's
+// four DMA pieces stand between every 18 MFMAs of a single in-order wave.  SPB = 2 waits once for TWO landed slabs, issues two and
+// multiplies two (36 MFMAs between barriers); the ring must then hold 2 x SPB slabs at least.
+// OCC = 2: at most 256 registers per lane (accumulators included), so that two workgroups — or another chain's waves — share a CU
+// with this kernel; OCC = 1 lets the compiler take the whole file (464: one workgroup owns the CU, see the 128-workgroup cap in
+// train_engine.py).
+template <typename T, int STG, int PD = 2, int SPB = 1, int OCC = 1>
+__global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p) {
     SY_TL_BEGIN(6);
     constexpr int CT = 128, CIT = 32;
     constexpr int SB = CT / 16;                   // dy subtiles per slab
@@ -583,15 +590,19 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
     const int x_lane = ((lane >> 4) & 1) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
     const int y_lane = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 
+    static_assert(STG >= 2 * SPB, "ring: SPB slabs multiply while at least SPB are in flight");
     sy_probe(0);
-    for (int j = 0; j < STG - 1; ++j) issue_slab();
+    for (int j = 0; j < STG - SPB; ++j) issue_slab();
     sy_probe(1);
     int stage_r = 0;
-    for (int s = 0; s < nslab; ++s) {
-        sy_wait_vmcnt<4 * (STG - 2)>();           // slab s landed; the STG - 2 slabs behind it stay in flight
-        sy_barrier();                             // ... for every wave; everyone is past slab s - 1
+    for (int s = 0; s < nslab; s += SPB) {
+        sy_wait_vmcnt<4 * (STG - 2 * SPB)>();     // slabs s .. s + SPB - 1 landed; the STG - 2 SPB slabs behind them stay in flight
+        sy_barrier();                             // ... for every wave; everyone is past the slabs before s
         if (s == 0) sy_probe(2);
-        issue_slab();
+#pragma unroll
+        for (int q = 0; q < SPB; ++q) issue_slab();
+#pragma unroll
+        for (int q = 0; q < SPB; ++q) {           // (a slab past the last one: zeros from the out-of-range pieces)
         const unsigned char* const xb = smem + stage_r * STAGE + x_lane;
         const unsigned char* const yb = smem + stage_r * STAGE + 2 * kXSub + (wv * 2) * kSubPitch + y_lane;
         stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
@@ -616,6 +627,7 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad9_kernel(WgradArgs p) {
             acc[ST % 9] = sy_mfma_group(T(), a[ST % (PD + 1)], b[ST / 9], acc[ST % 9]);
             sy_sched_fence();
         });
+        }
     }
     sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
     sy_probe(3);
@@ -776,7 +788,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int STG>
+template <typename T, int STG, int SPB = 1, int OCC = 1>
 int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
     if constexpr (T::kEPC != 8) {
         return SY_ERR_UNSUPPORTED;
@@ -801,12 +813,12 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 #ifndef SY_EMU
         static bool attr_done = false;
         if (!attr_done) {
-            const void* fn = (const void*)conv_wgrad9_kernel<T, STG>;
+            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, 2, SPB, OCC>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
             attr_done = true;
         }
 #endif
-        SY_LAUNCH((conv_wgrad9_kernel<T, STG>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
+        SY_LAUNCH((conv_wgrad9_kernel<T, STG, 2, SPB, OCC>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
         if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
@@ -817,6 +829,10 @@ template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
     if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
     if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
+    if (a.tile == 50) return launch_wgrad9<T, 4, 2>(a, ws_bytes, stream);  // two slabs per rendezvous, ring of 4
+    if (a.tile == 66) return launch_wgrad9<T, 6, 2>(a, ws_bytes, stream);  // ... ring of 6
+    if (a.tile == 51) return launch_wgrad9<T, 4, 2, 2>(a, ws_bytes, stream);  // ... ring of 4, <= 256 registers (two workgroups per CU)
+    if (a.tile == 52) return launch_wgrad9<T, 3, 1, 2>(a, ws_bytes, stream);  // tile 49 in <= 256 registers
     // (rings of 6 / 8 slabs — one workgroup per CU leaves the LDS free — measured in round 4: no faster, the kernel is issue-bound)
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128

@@ -647,6 +647,11 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
         s_fold[i] = a;
     }
     __syncthreads();
+    if (dres_acc & 4) {                                 // row 1 holds the RAW moment sum dz*y (a data gradient's fused reduce,
+        for (int c = threadIdx.x; c < C; c += kBlock)   // SY_EPI_BNR): sum dz*xhat = invstd * (sum dz*y - mean * sum dz)
+            s_fold[C + c] = invstd[c] * (s_fold[C + c] - mean[c] * s_fold[c]);
+        __syncthreads();
+    }
     if (blockIdx.x == 0 && dgamma != nullptr) {
         if (gridDim.y == 1 && !(dres_acc & 2)) {        // launches on one stream are ordered: plain += is race free
             for (int c = threadIdx.x; c < C; c += kBlock) { dbeta[c] += s_fold[c]; dgamma[c] += s_fold[C + c]; }

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (CONV_DGRAD, CONV_FWD, DT_BF16, DT_F16, DT_F32, EPI_DECODE, EPI_LINEAR, EPI_SIGMOID,
+from ._lib import (CONV_DGRAD, CONV_FWD, DT_BF16, DT_F16, DT_F32, EPI_BNR, EPI_DECODE, EPI_LINEAR, EPI_SIGMOID,
                    EPI_SILU, ConvDesc, WgradDesc, check)
 
 TORCH_DTYPE = {DT_BF16: torch.bfloat16, DT_F16: torch.float16, DT_F32: torch.float32}
@@ -126,15 +126,21 @@ def conv_out_size(h, k, stride):
 
 def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EPI_LINEAR, mode=CONV_FWD,
            accumulate=False, stats=None, dec_stride=0.0, y_f32=False, y_ptr=None, y_ld=None, y_bs=None,
-           cout=None, tile=0, wfrag=None, segments=1, k_splits=0, pre=None):
+           cout=None, tile=0, wfrag=None, segments=1, k_splits=0, pre=None, bn_reduce=None):
     """One launch of sy_conv2d.  x, y, res: View;  w: packed weight tensor [Cout, k*k*Cin] in x's dtype.
-    y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc])."""
+    y_ptr/y_ld/y_bs/cout override the output addressing (head predictions write into [B,A,5+nc]).
+    bn_reduce (data gradient, first write): (z View, scale, shift, sums) of the layer that produced this launch's output
+    activation — its BatchNorm-backward reduce rides in the epilogue (SY_EPI_BNR; sums [copies][2][C], row 1 = the raw moment)."""
+    if bn_reduce is not None:
+        z, scale, shift, sums = bn_reduce
+        assert mode == CONV_DGRAD and not accumulate and res is None and stats is None and z.ld == y.ld and z.bs == y.bs
+        res, epilogue, stats = z, EPI_BNR, (sums, sums)
     d = ConvDesc()
     d.x, d.w = x.ptr(), w.data_ptr()
     d.scale, d.shift = _p(scale), _p(shift)
     d.res = None if res is None else res.ptr()
     d.stat_sum, d.stat_sqsum = (None, None) if stats is None else (stats[0].data_ptr(), stats[1].data_ptr())
-    d.stat_copies = 1 if stats is None else max(1, stats[0].numel() // (segments * (y.C if cout is None else cout)))
+    d.stat_copies = 1 if stats is None else max(1, stats[0].numel() // ((2 if bn_reduce is not None else 1) * segments * (y.C if cout is None else cout)))
     d.stat_segments = segments          # statistics arrays [segments][copies][Cout] (frame pairs: one segment per frame)
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     if y is not None:
@@ -366,15 +372,16 @@ def bn_silu_bwd_reduce(y, da, scale, shift, mean, invstd, sums, nseg=1):
 
 
 def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma=None, dbeta=None, nseg=1,
-                      dres=None, dres_accumulate=False, atomic_param_grads=False):
-    """dres: gradient View of the residual input (y = silu(bn(conv)) + res): written (or accumulated) with da in this pass."""
+                      dres=None, dres_accumulate=False, atomic_param_grads=False, raw_moment=False):
+    """dres: gradient View of the residual input (y = silu(bn(conv)) + res): written (or accumulated) with da in this pass.
+    raw_moment: row 1 of `sums` is sum dz*y (left by a data gradient's fused reduce, conv2d(bn_reduce=...)), not sum dz*xhat."""
     assert dres is None or (dres.C == y.C and dres.pixels == y.pixels)
     check(_lib.lib().sy_bn_silu_bwd_apply(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
                                           sums.numel() // (2 * y.C * nseg), dy.ptr(), dy.ld, y.pixels // nseg, y.C,
                                           _p(dgamma), _p(dbeta), None if dres is None else dres.ptr(),
                                           0 if dres is None else dres.ld,
-                                          (1 if dres_accumulate else 0) | (2 if atomic_param_grads else 0), y.dtype, nseg,
+                                          (1 if dres_accumulate else 0) | (2 if atomic_param_grads else 0) | (4 if raw_moment else 0), y.dtype, nseg,
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 
@@ -553,7 +560,10 @@ def save_tuned():
 # 107 / 104 = the software-pipelined tile on 3 / 5 output rows: a frame's 38 x 60 map is 13 x 3 or 8 x 5 rows, 416 / 256 workgroups
 # instead of 117's 608 (one ragged round of 2.4 per CU) with 0.67 / 0.4 of its weight-fragment loads per MFMA: +15 % on the
 # 256->256 @38x60 layers, +17 % on 512->512 @19x30 (profiles/r04 stage bd)
-HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,116,117,118,107,104").replace("+", ",").split(",") if t]
+# 101 / 100 / 98 / 109 (round 5) = the third generation of the same four tiles (csrc/conv3x3_halo3.h): fragment reads with immediate
+# offsets, hand-placed instruction stream, prefetch across the slab boundary; +7-17 % in the probes (profiles/r05 stages e-h); same
+# accumulation order as the second generation (bit-identical results)
+HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,116,117,118,107,104,101,100,98,109").replace("+", ",").split(",") if t]
 # stride-2 3x3 layers on the window-in-LDS kernels (tile codes 110 = forward, 108 = data gradient).  Measured in round 4
 # (profiles/r04/a_probe_s2_*.txt): forward 421 vs 395 (dark2.0) / 739 vs 585 TF/s (dark4.0) against the best implicit-GEMM
 # variant, data gradient 245 vs 250 / 504 vs 484; l step 22.61 vs 22.70 ms (b_bench_s2 / b_bench_base) — candidates by default
@@ -810,7 +820,7 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
     dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
     best, best_t = (0, 0), float("inf")
     for (t, tb) in _WGRAD_CANDIDATES + WGRAD_EXTRA:
-        if t in (49, 65):
+        if t in (49, 65, 50, 66, 51, 52):
             if k != 3 or stride != 1 or Cin % 32 or Cout % 16:
                 continue
         elif (t & 15) in (1, 5, 6) and Cout < 128:

@@ -36,7 +36,19 @@ from .ops import View, EPI_LINEAR, CONV_DGRAD
 # (default off: kernel time 2.77 vs 2.90 ms per l step, but the step itself is not faster at 32 statistic replicas, and the 8
 # replicas that make it 0.1-0.26 ms faster break the 1e-5 run-to-run reproducibility of the fp16 step — profiles/r02/t_*, u_*,
 # profiles/r04/d_bench_ff8.json)
-_FUSED_FINALIZE = __import__("os").environ.get("STREAMYOLO_FUSED_FINALIZE", "0") != "0"
+# Round 5: ON for the 16-bit modes together with 4 statistic replicas (l step 20.46-20.50 vs 20.64-20.67 ms, profiles/r05 stage l:
+# the replicas every workgroup of the apply pass re-reads shrink 8x, and -216 launches on the forward chains); the run-to-run
+# reproducibility that argued for 32 replicas is the exact mode's business now (one replica row per workgroup, bit-equal steps).
+# "auto" (default): 16-bit compute dtypes only; "1" / "0": everywhere / nowhere (A/B timing).
+_FUSED_FINALIZE = __import__("os").environ.get("STREAMYOLO_FUSED_FINALIZE", "auto")
+# Round 5: the BatchNorm-backward REDUCE of a Bottleneck's 1x1 layer can ride in the epilogue of the 3x3 layer's data gradient (the
+# only producer of its activation gradient: engine.ConvOp.pre_op) — sy_conv2d's SY_EPI_BNR; 72 launches and one read of dA less per
+# l step.  16-bit modes, frames as stream-parallel chains (per-frame launches).  Built, parity-green (kernel + model tests on the
+# MI355X) and measured: OFF by default — the reduce pass leaves the chains (-0.87 ms of kernel time), but its sigmoid / product work
+# (80 values per lane) then runs in the epilogue of a one-wave-per-SIMD MFMA kernel instead of in a memory-bound launch that other
+# kernels overlap: data gradients +0.6 ms, the l step 20.78-20.82 vs 20.68-20.75 ms (profiles/r05 stage m).  "1": on (A/B timing).
+BNR_FUSION = __import__("os").environ.get("STREAMYOLO_BNR_FUSION", "0") != "0"
+BNR_TILES = (98, 100, 101, 109, 104, 107, 117, 118)     # data-gradient tiles whose staged epilogue carries it (csrc/conv_igemm.hip)
 # exact (fp32) mode: one statistics replica row per workgroup -> run-to-run bit-equal steps (TrainPlan.__init__); "0" = the
 # replica counts of the speed modes (A/B switch)
 EXACT_STATS = __import__("os").environ.get("STREAMYOLO_EXACT_STATS", "1") != "0"
@@ -265,7 +277,9 @@ class TrainPlan:
     BWD_COPIES = int(os.environ.get("STREAMYOLO_BWD_COPIES", "2"))
     # replicas of each conv's sum / sum^2 arrays: 4 are as fast as 32 but the longer fp32 atomic chains make the batch
     # variance (E[y^2] - mean^2) visibly order-dependent (tape-replay test: 1e-4 instead of 1e-6 between identical steps)
-    STAT_COPIES = int(os.environ.get("STREAMYOLO_STAT_COPIES", "32"))
+    # (round 5: 4 in the 16-bit modes — there the order noise is far below the rounding step, and the fused finalize + apply launch
+    #  reads every replica in every workgroup; 32 stays the fp32 default when the exact one-row-per-workgroup layout is switched off)
+    STAT_COPIES = int(os.environ.get("STREAMYOLO_STAT_COPIES", "0"))     # 0 = by compute dtype: 4 (16-bit) / 32 (fp32)
     WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
     RING = int(os.environ.get("STREAMYOLO_RING", "5"))   # raw-gradient scratch slots (5 vs 3: -0.1 ms per l step, measured); (wgrad of layer i overlaps BN backward / dgrad of i-1, i-2)
     STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
@@ -325,10 +339,12 @@ class TrainPlan:
         # (tal_head.py:679-712) no longer flip between runs.  Rows: forward = pixel tiles of a frame's launch (<= N * H *
         # ceil(W / 32), whatever tile the tuner picks); backward reduce = its workgroup cap (SY_BN_REDUCE_BLOCKS, 768).
         self.exact_stats = EXACT_STATS and self.dtype == ops.DT_F32
+        self.stat_copies = self.STAT_COPIES if self.STAT_COPIES > 0 else (32 if self.dtype == ops.DT_F32 else 4)
+        self.fused_finalize = (_FUSED_FINALIZE == "1") or (_FUSED_FINALIZE == "auto" and self.dtype != ops.DT_F32)
         def copies_of(op):
             if not self.exact_stats:
-                return self.STAT_COPIES, self.BWD_COPIES
-            return max(self.STAT_COPIES, op.y.N * op.y.H * ((op.y.W + 31) // 32)), max(self.BWD_COPIES, _BN_REDUCE_BLOCKS)
+                return self.stat_copies, self.BWD_COPIES
+            return max(self.stat_copies, op.y.N * op.y.H * ((op.y.W + 31) // 32)), max(self.BWD_COPIES, _BN_REDUCE_BLOCKS)
         for op in convs:
             op.stat_copies, op.bwd_copies = copies_of(op)
         self.stat_arena = torch.zeros(2 * sum(op.stat_copies * op.y.C for op in convs), dtype=torch.float32, device=device)  # [sum | sumsq] x copies
@@ -572,10 +588,23 @@ class TrainPlan:
         return g, b_, bn.eps, mom
 
     def _bn_bwd(self, op, y, da, aff, gamma, bsum, dy, dgamma, dbeta, nseg=1, dres=None, acc=False, atomic=False):
-        """BatchNorm.SiLU backward of one launch unit: the reduce pass, then the apply pass."""
-        ops.bn_silu_bwd_reduce(y, da, *aff, bsum, nseg=nseg)
+        """BatchNorm.SiLU backward of one launch unit: the reduce pass (unless the data gradient that produced `da` carried it:
+        op.bnr_by), then the apply pass."""
+        fused = getattr(op, "bnr_by", None) is not None
+        if not fused:
+            ops.bn_silu_bwd_reduce(y, da, *aff, bsum, nseg=nseg)
         ops.bn_silu_bwd_apply(y, da, *aff, gamma, bsum, dy, dgamma, dbeta, nseg=nseg, dres=dres, dres_accumulate=acc,
-                              atomic_param_grads=atomic)
+                              atomic_param_grads=atomic, raw_moment=fused)
+
+    def _bnr_producer(self, op, dx, acc, t):
+        """The 1x1 ConvOp whose BatchNorm-backward reduce this op's data gradient can carry (SY_EPI_BNR), or None.  A static
+        property of the plan (the tapes record the decision): op reads ONLY that layer's activation, first write of its
+        gradient, 16-bit compute, a tile with the staged 128-channel epilogue, the raw output laid out like the gradient view."""
+        pre = op.pre_op
+        if (not BNR_FUSION or pre is None or acc or self.dtype == ops.DT_F32 or t not in BNR_TILES or op.k != 3 or op.stride != 1
+                or pre.res is not None or pre.yraw is None or pre.yraw.ld != dx.ld or pre.yraw.bs != dx.bs or pre.y.C % 8 or dx.ld % 8):
+            return None
+        return pre
 
     def _bn_grads(self, op):
         """(dgamma, dbeta) arena views starting at the op's first part (the parts' slots are adjacent: see the arena order)."""
@@ -594,7 +623,7 @@ class TrainPlan:
             a._tiles["fwd_stats2"] = t
         ops.conv2d(x2, self.cache.conv_weight(a.mod), raw2, a.k, a.stride, stats=(u_sum, u_sq), tile=t,
                    wfrag=self.cache.conv_weight_frag(a.mod) if t >= ops.TILE_WR else None, segments=2)
-        if _FUSED_FINALIZE:
+        if self.fused_finalize:
             ops.bn_finalize_apply(u_sum, u_sq, a.y.pixels, gamma, beta, eps, scale, shift, mean, invstd, raw2, y2,
                                   res=None if a.res is None else a.res.pair(), nseg=2)
         else:
@@ -680,7 +709,7 @@ class TrainPlan:
                        wfrag=self.cache.conv_weight_frag(op.mod) if t >= ops.TILE_WR else None)
             # running statistics: one batched launch at the end of the pass (the two frames' calls of a shared
             # module update them in call order there, whatever stream each frame ran on)
-            if _FUSED_FINALIZE:
+            if self.fused_finalize:
                 ops.bn_finalize_apply(op.stat[0], op.stat[1], op.y.pixels, gamma, beta, eps, scale, shift, mean, invstd,
                                       op.yraw, op.y, res=op.res)
             else:
@@ -820,6 +849,9 @@ class TrainPlan:
     def _backward_ops(self, d_raw):
         G = self.grads
         G.reset()
+        for op in self.ops:                                      # fused-reduce marks are per pass (set by the consumer's data gradient)
+            if op.kind == "conv":
+                op.bnr_by = None
         self.ring_i = 0
         nf = self.n_frame_ops
         if self.head is None:                                    # backbone alone: the feature gradients come from the caller
@@ -972,7 +1004,7 @@ class TrainPlan:
             # itself takes ~1.8x as long on its side stream, the step is 0.6 ms shorter (22.4-22.8 -> 21.8-22.1 ms; 96 the
             # same, 64 / 192 / 384 worse — profiles/r04 stage s)
             cap9 = int(os.environ.get("STREAMYOLO_WGRAD9_BLOCKS", "128"))
-            if cap9 > 0 and wt[0] in (49, 65) and wt[1] > cap9:
+            if cap9 > 0 and wt[0] in (49, 65, 50, 66) and wt[1] > cap9:
                 wt = (wt[0], cap9)
             op._tiles[key] = wt
         if w.shape[1] == x.C:
@@ -1050,9 +1082,13 @@ class TrainPlan:
             for k, (op, dyr) in enumerate(zip((a, b2), dys)):
                 self._mark("cur", 2 * k)
                 dx, acc = G.target(op.x)
+                pre = self._bnr_producer(op, dx, acc, t)
+                if pre is not None:                                  # ... + the BatchNorm-backward reduce of the layer that made op.x
+                    pre.bnr_by = op
                 ops.conv2d(dyr, self.cache.conv_weight(a.mod, transpose=True), dx, a.k, a.stride, mode=CONV_DGRAD,
                            accumulate=acc, tile=t,
-                           wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
+                           wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None,
+                           bn_reduce=None if pre is None else (pre.yraw, pre.aff[0], pre.aff[1], pre.bsum))
                 self._mark("slot_done", slot)                        # this chain's reader of its half of the slot
         self._mark("cur", 0)
 

@@ -176,10 +176,10 @@ def test_wgrad_many_splits_fold(backend):
     assert _rel(dw.cpu(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [98, 100, 101, 104, 106, 107, 109, 111, 112, 113, 114, 115, 116, 117, 118, 120, 125, 126, 127])
+@pytest.mark.parametrize("tile", [98, 100, 101, 104, 106, 107, 109, 111, 112, 113, 114, 115, 116, 117, 118])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "fwd"), ("bf16", "dgrad"), ("fp32", "dgrad")])
 def test_conv3x3_halo_kernel(backend, tile, dt, mode):
-    """csrc/conv3x3_halo.h (tile codes 104, 106, 107, 111..118 and csrc/conv3x3_halo3.h's 120, 125..127 / 98, 100, 101, 109 (third generation: immediate-offset fragment reads / + hand-placed instruction stream); 104 / 107 / 112 / 113 / 117 / 118 = the in-wave software-pipelined generation, 106 / 111 = the same with K groups inside the workgroup): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
+    """csrc/conv3x3_halo.h (tile codes 104, 106, 107, 111..118 and csrc/conv3x3_halo3.h's 98, 100, 101, 109 (third generation: immediate-offset fragment reads, hand-placed instruction stream, cross-slab prefetch); 104 / 107 / 112 / 113 / 117 / 118 = the in-wave software-pipelined generation, 106 / 111 = the same with K groups inside the workgroup): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
     gradient (first write, accumulate, channel-slice output), on an image whose width and height are ragged against the
     32-pixel / TH-row tiles, with Cout ragged against the channel tile; against torch and against the implicit-GEMM kernel."""
     g = torch.Generator().manual_seed(tile + len(mode))
@@ -229,10 +229,58 @@ def test_conv3x3_halo_kernel(backend, tile, dt, mode):
         assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("tile", [49, 65])
+@pytest.mark.parametrize("tile", [109, 100, 101, 98, 104, 117])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_dgrad_carries_the_producers_bn_backward_reduce(backend, tile, dt):
+    """SY_EPI_BNR: the data gradient of a 3x3 layer also reduces the BatchNorm backward sums of the layer that produced its input
+    (z -> BN -> SiLU -> a -> conv3x3): dx unchanged, and sy_bn_silu_bwd_apply fed with the fused sums (raw second moment) gives the
+    same dz / dgamma / dbeta as behind the separate sy_bn_silu_bwd_reduce launch — and as torch autograd of the chain."""
+    g = torch.Generator().manual_seed(tile)
+    N, C, cout, H, W = 2, 64, 96, 9, 37
+    code = ops.dtype_code(dt)
+    z = _q(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3, dt).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    a = F.silu(F.batch_norm(z, None, None, gamma, beta, True, 0.03, 1e-3))
+    w = _q(torch.randn(cout, C, 3, 3, generator=g) / (C * 9) ** 0.5, dt)
+    y = F.conv2d(a, w, None, 1, 1)
+    dy = _q(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    dev = backend
+    zv = View.alloc(N, H, W, C, dt, dev); zv.set_nchw(z.detach().to(dev))
+    ssum = z.detach().sum((0, 2, 3)).to(dev); ssq = (z.detach() ** 2).sum((0, 2, 3)).to(dev)
+    scale, shift, mean, invstd = [torch.empty(C, device=dev) for _ in range(4)]
+    ops.bn_finalize(ssum, ssq, N * H * W, gamma.detach().to(dev), beta.detach().to(dev), 1e-3, 0.03, None, None, scale, shift, mean, invstd)
+    dyp = View.alloc(N, H, W, cout, dt, dev); dyp.set_nchw(dy.to(dev))
+    wt = pack_conv_weight(w, code, transpose=True).to(dev)
+    wf = pack_conv_weight_frag(wt, 3)
+    # separate launches: data gradient, reduce, apply
+    da0 = View.alloc(N, H, W, C, dt, dev)
+    ops.conv2d(dyp, wt, da0, 3, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf)
+    sums0 = torch.zeros(2 * 2 * C, device=dev)
+    ops.bn_silu_bwd_reduce(zv, da0, scale, shift, mean, invstd, sums0)
+    dz0 = View.alloc(N, H, W, C, dt, dev)
+    dg0, db0 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_silu_bwd_apply(zv, da0, scale, shift, mean, invstd, gamma.detach().to(dev), sums0, dz0, dg0, db0)
+    # fused: the reduce rides in the data gradient's epilogue
+    da1 = View.alloc(N, H, W, C, dt, dev)
+    sums1 = torch.zeros(2 * 2 * C, device=dev)
+    ops.conv2d(dyp, wt, da1, 3, 1, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf, bn_reduce=(zv, scale, shift, sums1))
+    assert torch.equal(da1.buf, da0.buf)
+    dz1 = View.alloc(N, H, W, C, dt, dev)
+    dg1, db1 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_silu_bwd_apply(zv, da1, scale, shift, mean, invstd, gamma.detach().to(dev), sums1, dz1, dg1, db1, raw_moment=True)
+    # (the fused sums see the fp32 accumulators, the separate pass the rounded gradient: agreement to the rounding step)
+    assert _rel(db1.cpu(), db0.cpu()) < TOL[dt] and _rel(dg1.cpu(), dg0.cpu()) < TOL[dt]
+    assert _rel(dz1.nchw().cpu(), dz0.nchw().cpu()) < TOL[dt]
+    assert _rel(db1.cpu(), beta.grad) < 2 * TOL[dt] and _rel(dg1.cpu(), gamma.grad) < 2 * TOL[dt]
+    assert _rel(dz1.nchw().cpu(), z.grad) < 2 * TOL[dt]
+
+
+@pytest.mark.parametrize("tile", [49, 65, 50, 66, 51, 52])
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 144, 7, 37), (1, 32, 48, 5, 70)])
 def test_wgrad_all_taps_kernel(backend, tile, N, cin, cout, H, W):
-    """conv_wgrad9_kernel (tile codes 49 / 65): 3x3 stride-1 weight gradient with all nine taps per workgroup and the x halo
+    """conv_wgrad9_kernel (tile codes 49 / 65; 50 / 66 = two slabs per rendezvous): 3x3 stride-1 weight gradient with all nine taps per workgroup and the x halo
     window resident in LDS — ragged 32-pixel row segments, ragged Cout tile, one split and many splits (+ fold), packed and
     OIHW layouts, against torch and against the per-tap transpose-read kernel."""
     dt = "bf16"

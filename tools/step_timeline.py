@@ -23,7 +23,9 @@ ap.add_argument("--model", default="l")
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--dump", default="")
+ap.add_argument("--json", default="", help="write the summary (step, resident-launch histogram, MFMA-resident time) with the kernel-source key: bench.py reports it as roofline.in_step")
 ap.add_argument("--workload", default="train", choices=["train", "stream"], help="stream: one on_pipe frame (batch 1), decode + NMS")
+ap.add_argument("--bins", type=float, default=0.0, help="print the residency profile in bins of this many ms: mean launches resident, share of the bin with 0 / 1 resident, busiest families")
 ap.add_argument("--list", type=int, default=0, help="print the first N launches in start order (start, span, gap to the previous end)")
 a = ap.parse_args()
 import streamyolo_amd as sy                                             # noqa: E402
@@ -61,7 +63,8 @@ for _ in range(4):
     run()
 torch.cuda.synchronize()
 lib = C.CDLL(_lib.library_path())
-READERS = ["sy_probe_read_conv_extra_tl", "sy_probe_read_conv_igemm_tl", "sy_probe_read_wgrad_tl", "sy_probe_read_train_ops_tl",
+READERS = ["sy_probe_read_conv_extra_tl", "sy_probe_read_conv_igemm_tl", "sy_probe_read_conv_halo3_bf16_tl", "sy_probe_read_conv_halo3_f16_tl",
+           "sy_probe_read_conv_halo3_f32_tl", "sy_probe_read_wgrad_tl", "sy_probe_read_train_ops_tl",
            "sy_probe_read_tal_loss_tl", "sy_probe_read_api_misc_tl", "sy_probe_read_pointwise_tl"]
 ent = np.dtype([("key", "<u8"), ("t0", "<u8"), ("t1", "<u8"), ("tag", "<u4"), ("count", "<u4")])
 buf = np.zeros(65536, dtype=ent)
@@ -127,6 +130,47 @@ for tag in sorted(set(rec["tag"].tolist()), key=lambda t: -float(((e - s)[rec["t
     m = rec["tag"] == tag
     sp = (e - s)[m]
     print("%-18s %6d %8.3f ms %8.1f us %9.3f ms" % (NAMES.get(tag, "tag %d" % tag), m.sum(), sp.sum() / 1e3, sp.mean(), only_f.get(tag, 0.0) / 1e3))
+if a.json:
+    import json
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
+    if not commit and os.path.exists(os.path.join(ROOT, "tools", ".head_commit")):
+        commit = open(os.path.join(ROOT, "tools", ".head_commit")).read().strip()
+    with open(a.json, "w") as fh:
+        json.dump({"workload": a.workload, "model": a.model, "batch": a.batch, "dtype": a.dtype, "kernel_source_key": _lib.kernel_source_key(),
+                   "commit": commit, "launches": int(len(rec)), "step_ms_events": e0.elapsed_time(e1), "step_ms_first_entry_to_last_exit": wall / 1e3,
+                   "resident_launches_ms": [c / 1e3 for c in conc], "mfma_kernel_resident_ms": mfma_t / 1e3,
+                   "note": "probe build (sy_tl_* records of every launch; ~3 % slower than the product build)"}, fh)
+if a.bins > 0:
+    # residency profile: where in the step the chip holds fewer than two launches
+    nb = int(wall / 1e3 / a.bins) + 1
+    w_us = a.bins * 1e3
+    res = np.zeros(nb); low = np.zeros(nb); fam = [dict() for _ in range(nb)]
+    prev, act = 0.0, {}
+    for tm, d, tag in ev:
+        n = sum(act.values())
+        t_ = prev
+        while t_ < tm:                                  # spread [prev, tm) over the bins it crosses
+            b = min(int(t_ / w_us), nb - 1)
+            hi_ = min(tm, (b + 1) * w_us)
+            dt = hi_ - t_
+            res[b] += n * dt
+            if n <= 1:
+                low[b] += dt
+            for t2, c in act.items():
+                if c > 0:
+                    fam[b][t2] = fam[b].get(t2, 0.0) + c * dt
+            t_ = hi_ if hi_ > t_ else tm
+        act[tag] = act.get(tag, 0) + d
+        prev = tm
+    print("residency profile, %.2f ms bins: mean launches resident | share of the bin with <= 1 resident | busiest families (launch-ms)" % a.bins)
+    for b in range(nb):
+        top = sorted(fam[b].items(), key=lambda kv: -kv[1])[:3]
+        print("  %6.2f ms  %4.2f  %3.0f %%  %s" % (b * a.bins, res[b] / w_us, 100 * low[b] / w_us,
+                                                  ", ".join("%s %.2f" % (NAMES.get(t2, "tag %d" % t2), v / 1e3) for t2, v in top)))
 if a.list:
     print("launches in start order: start us, span us, workgroups, gap to the latest end so far")
     hi = 0.0
