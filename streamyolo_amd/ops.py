@@ -798,7 +798,11 @@ _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 102
                      (17, 256), (33, 256), (18, 256),
                      # 3x3 stride 1: all nine taps per workgroup (conv_wgrad9_kernel); few splits: the split-K slabs + fold are a
                      # third of its time at 1024 workgroups (profiles/r02/f_wgrad_probe.txt)
-                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512)]
+                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512),
+                     # round 5: the same kernel compiled for <= 256 registers per lane (52; 51 = + two slabs per rendezvous): as fast
+                     # alone (665 vs 648 TF/s at 256->256 @38x60 x 16) and it no longer owns the CUs it runs on — the l step 21.37-21.44 vs
+                     # 21.53-21.56 ms with the same 128-workgroup cap (profiles/r05 stages j, q)
+                     (52, 128), (52, 256), (51, 128), (51, 256)]
 # further candidates for A/B runs, "tile:blocks,tile:blocks"; part
 # of the tuner-cache key, so such a run tunes by itself
 # ("tile/blocks+tile/blocks" is accepted as well: tools/gpu.sh splits its task arguments at ":" and ",")

@@ -1004,7 +1004,7 @@ class TrainPlan:
             # itself takes ~1.8x as long on its side stream, the step is 0.6 ms shorter (22.4-22.8 -> 21.8-22.1 ms; 96 the
             # same, 64 / 192 / 384 worse — profiles/r04 stage s)
             cap9 = int(os.environ.get("STREAMYOLO_WGRAD9_BLOCKS", "128"))
-            if cap9 > 0 and wt[0] in (49, 65, 50, 66) and wt[1] > cap9:
+            if cap9 > 0 and wt[0] in (49, 65, 50, 66, 51, 52) and wt[1] > cap9:
                 wt = (wt[0], cap9)
             op._tiles[key] = wt
         if w.shape[1] == x.C:
