@@ -313,7 +313,35 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::e
 // finalize folds them, updates the running statistics and emits the per-channel affine.
 // One workgroup = 32 channels; thread = (channel c = tid & 31, replica group r = tid >> 5): the replica
 // loads of a channel are independent and run in parallel, then an LDS fold.
-__global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, const float* sqsum, int C, int copies,
+// Many replica rows (the exact mode: one row per convolution workgroup, thousands per layer) are first folded into the
+// first kFoldTo rows IN PLACE by fold_rows_kernel: output row r = the rows r, r + kFoldTo, r + 2 kFoldTo, ... added in index order
+// by four partial sums (rows j = q mod 4 of that list) that are combined in order q — a fixed tree, so the result does not
+// depend on scheduling — with (C / 64) x kFoldTo workgroups instead of eight serial threads per channel.
+constexpr int kFoldTo = 32, kFoldAbove = 64;
+__global__ __launch_bounds__(kBlock) void fold_rows_kernel(float* a0, float* a1, int C, int copies) {
+    __shared__ float part[4][64];
+    float* const arr = (blockIdx.z & 1) ? a1 : a0;
+    float* const base = arr + (long long)(blockIdx.z >> 1) * copies * C;
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, r = blockIdx.y;
+    float acc = 0.0f;
+    if (c < C) {
+        int j = q;
+        const int J = (copies - r + kFoldTo - 1) / kFoldTo;            // rows of this class
+        for (; j + 12 < J; j += 16) {                                 // four independent loads in flight, added in index order
+            const float v0 = base[(long long)(r + kFoldTo * j) * C + c], v1 = base[(long long)(r + kFoldTo * (j + 4)) * C + c];
+            const float v2 = base[(long long)(r + kFoldTo * (j + 8)) * C + c], v3 = base[(long long)(r + kFoldTo * (j + 12)) * C + c];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; j < J; j += 4) acc += base[(long long)(r + kFoldTo * j) * C + c];
+    }
+    part[q][cl] = acc;
+    __syncthreads();
+    if (q == 0 && c < C) base[(long long)r * C + c] = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+}
+
+// `copies` rows are read, `stride` rows lie between the segments (stride > copies after fold_rows_kernel)
+__global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, const float* sqsum, int C, int copies, int stride,
                                                              double count, const float* gamma, const float* beta,
                                                              float eps, float momentum, float* running_mean,
                                                              float* running_var, float* scale, float* shift,
@@ -323,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(const float* sum, c
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     {   // segment blockIdx.y: statistics [seg][copies][C], outputs [seg][C] (gamma / beta are shared)
-        const long long so = (long long)blockIdx.y * copies * C, ao = (long long)blockIdx.y * C;
+        const long long so = (long long)blockIdx.y * stride * C, ao = (long long)blockIdx.y * C;
         sum += so; sqsum += so; scale += ao; shift += ao;
         if (mean_out != nullptr) mean_out += ao;
         if (invstd_out != nullptr) invstd_out += ao;
@@ -698,13 +726,26 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
 }
 
 // sums[0][i] = sum over replicas k of sums[k][i]  (i in [0, 2C)): run once before the apply pass
+// (64 elements x 4 row classes per workgroup: class q adds the rows k = q mod 4 in index order, the four partial sums are combined
+//  in order q — a fixed tree; the exact mode folds 768 rows per layer here, a serial loop per element was 30 % of its step)
 __global__ __launch_bounds__(kBlock) void fold_replicas_kernel(float* sums, int n, int copies) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float part[4][64];
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + el;
     sums += (long long)blockIdx.y * copies * n;
     float a = 0.0f;
-    for (int k = 0; k < copies; ++k) a += sums[(long long)k * n + i];
-    sums[i] = a;
+    if (i < n) {
+        int k = q;
+        for (; k + 12 < copies; k += 16) {
+            const float v0 = sums[(long long)k * n + i], v1 = sums[(long long)(k + 4) * n + i];
+            const float v2 = sums[(long long)(k + 8) * n + i], v3 = sums[(long long)(k + 12) * n + i];
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        for (; k < copies; k += 4) a += sums[(long long)k * n + i];
+    }
+    part[q][el] = a;
+    __syncthreads();
+    if (q == 0 && i < n) sums[i] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
 }
 
 inline bool chunk_rows_ok(int C, int e) { const int cpp = C / e; return cpp >= 1 && cpp <= kBlock; }
@@ -781,7 +822,13 @@ extern "C" int sy_bn_finalize(const float* sum, const float* sqsum, int C, int c
         return SY_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SY_ERR_ARG;
     if (nseg < 1 || (nseg > 1 && running_mean != nullptr)) return SY_ERR_ARG;   // running stats of several calls: sy_bn_running_update
-    SY_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32, nseg), dim3(kBlock), 0, stream, sum, sqsum, C, copies, count,
+    int read = copies;
+    if (copies > kFoldAbove) {          // (writes the folded rows back into the caller's arrays: rows [0, kFoldTo) then hold the totals)
+        SY_LAUNCH(fold_rows_kernel, dim3((C + 63) / 64, kFoldTo, 2 * nseg), dim3(kBlock), 0, stream, const_cast<float*>(sum),
+                  const_cast<float*>(sqsum), C, copies);
+        read = kFoldTo;
+    }
+    SY_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32, nseg), dim3(kBlock), 0, stream, sum, sqsum, C, read, copies, count,
               gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
@@ -864,7 +911,7 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
     if (!chunk_rows_ok(C, e) || C > 1024) return SY_ERR_UNSUPPORTED;
     static const int fold_inline = env_cap("SY_BN_FOLD_INLINE", 2);      // replicas <= this: every workgroup folds them itself
     if (copies > fold_inline) {       // many replicas: fold once here instead of in every workgroup of the apply pass
-        SY_LAUNCH(fold_replicas_kernel, dim3((2 * C + kBlock - 1) / kBlock, nseg), dim3(kBlock), 0, stream,
+        SY_LAUNCH(fold_replicas_kernel, dim3((2 * C + 63) / 64, nseg), dim3(kBlock), 0, stream,
                   const_cast<float*>(sums), 2 * C, copies);
         copies = 1;
     }

@@ -512,7 +512,9 @@ class TrainPlan:
             mods = {}
             for op in self.ops:                                      # plan order == the reference's call order
                 if op.kind == "conv":
-                    c0, ctot, SC = 0, op.y.C, op.stat_copies
+                    # (sy_bn_finalize folds more than 64 replica rows — the exact mode's one row per workgroup — into the first 32
+                    #  in place: csrc/train_ops.hip kFoldAbove / kFoldTo; the running-statistics launch reads those)
+                    c0, ctot, SC = 0, op.y.C, (32 if op.stat_copies > 64 else op.stat_copies)
                     for m in base_convs(op.mod):                     # a stacked launch: each module's channel slice of the arrays
                         mods.setdefault(id(m.bn), (m.bn, []))[1].append((op.stat[0][c0:], op.stat[1][c0:], op.y.pixels, SC, ctot))
                         c0 += m.bn.num_features

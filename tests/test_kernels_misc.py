@@ -93,6 +93,30 @@ def test_spp_tile_kernels_match_scan_kernels(backend, dt, H, W, C, monkeypatch):
     assert float((ga - gb).abs().max()) <= (1e-5 if dt == "fp32" else 2e-2) * float(gb.abs().max())
 
 
+@pytest.mark.parametrize("copies,nseg", [(200, 1), (777, 2), (64, 2)])
+def test_bn_finalize_folds_many_replica_rows(backend, copies, nseg):
+    """sy_bn_finalize over hundreds of replica rows (the exact mode's one row per convolution workgroup): the rows are folded into
+    32 by a fixed tree (fold_rows_kernel) and then finalized — same statistics as the plain sum, the same bits on a second call
+    over the same rows, segment by segment; and the backward replicas' fold (sy_bn_silu_bwd_apply over 768 rows) likewise."""
+    g = torch.Generator().manual_seed(copies)
+    C, M = 96, 4096
+    rows = torch.randn(nseg, copies, C, generator=g)
+    sq = torch.rand(nseg, copies, C, generator=g) * 3 + 1.0
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    dev = backend
+    outs = []
+    for _ in range(2):
+        ssum, ssq = rows.clone().to(dev).reshape(-1), (sq * M / copies).clone().to(dev).reshape(-1)
+        scale, shift, mean, invstd = [torch.empty(nseg * C, device=dev) for _ in range(4)]
+        ops.bn_finalize(ssum, ssq, M, gamma.to(dev), beta.to(dev), 1e-3, 0.03, None, None, scale, shift, mean, invstd, nseg=nseg)
+        outs.append((mean.cpu().clone(), invstd.cpu().clone(), scale.cpu().clone()))
+    m_ref = rows.double().sum(1) / M
+    v_ref = (sq.double() * M / copies).sum(1) / M - m_ref ** 2
+    assert _rel(outs[0][0].view(nseg, C), m_ref.float()) < 1e-5
+    assert _rel(outs[0][1].view(nseg, C), (1.0 / (v_ref + 1e-3).sqrt()).float()) < 1e-5
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
 @pytest.mark.parametrize("C", [16, 96, 192])          # 96 / 192: the backward reduce runs in channel slices of 48 / 64
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
 def test_bn_train_silu_fwd_bwd(backend, dt, C):
