@@ -256,6 +256,9 @@ BWD_SPLIT_FRAMES = os.environ.get("STREAMYOLO_BWD_SPLIT_FRAMES", "auto")
 # between two streams (1 and 3, a split-K workspace each) so that one layer's fold runs beside the next layer's wgrad.  Measured
 # on one box (profiles/r03/l_*): 22.66-22.77 (neither) / 22.73 (head chain) / 22.54 (two wgrad streams) / 22.27 ms (both).
 HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "1") != "0"
+# Round 5, forward: a head level (+ its two DFP fusion convs) starts as soon as its PAN output exists in both frames, on a third
+# chain beside the rest of the frame chains (TrainPlan._early_levels).  "0": the levels behind the join of the frame chains.
+HEAD_EARLY = os.environ.get("STREAMYOLO_HEAD_EARLY", "1") != "0"
 DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "1") != "0"
 WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD_STREAMS", "2")) if DUAL_WGRAD else 1))]
 # (Weight gradients on streams of their own instead of sharing stream 1 with the forward pass's support-frame chain, with or without
@@ -538,13 +541,32 @@ class TrainPlan:
         if FWD_SPLIT_FRAMES and nf:
             # the two frames as two independent chains, current frame on the main stream, support frame on the side stream,
             # issued alternately (half-size launches, but one chain's tails and BatchNorm passes fill the other's gaps)
+            early = self._early_levels() if (HEAD_EARLY and self.head is not None and self.side2 is not None) else {}
             self._mark("fork")
             for i in range(nf):
                 self._forward_op(self.ops[i])
                 self._mark("side_nw")
                 self._forward_op(self.ops[nf + i])
                 self._mark("main", None)
+                for lvl_ops in early.get(i, ()):
+                    # PAN output k of BOTH frames is complete here: its DFP fusion convs and head level are a third chain (stream
+                    # 2) beside the rest of the two frame chains (the stride-8 level — the largest head level — beside the whole
+                    # bottom-up path, 18 BaseConvs per frame), instead of three small chains behind the join (round 5: the launch
+                    # timeline had <= 1.2 launches resident for the 1.5 ms around the head and the loss)
+                    self._mark("dep", (0, 2))
+                    self._mark("dep", (1, 2))
+                    self._mark("cur", 2)
+                    for op in lvl_ops:
+                        self._forward_op(op)
+                    self._mark("cur", 0)
             self._mark("join")
+            if early:
+                done = {id(op) for v in early.values() for lvl_ops in v for op in lvl_ops}
+                for op in self.ops[2 * nf:]:                      # the level whose PAN output is the frame network's last op: main stream
+                    if id(op) not in done:
+                        self._forward_op(op)
+                self._mark("dep", (2, 0))
+                return
         for i in range(nf if not (FWD_SPLIT_FRAMES and nf) else 0):
             a, b2 = self.ops[i], self.ops[nf + i]
             if a.kind == "conv":
@@ -576,6 +598,26 @@ class TrainPlan:
         self._side_region = False
         self._mark("main", None)
         self._mark("join")
+
+    def _early_levels(self):
+        """{index i of the per-frame op list: [ops of a level that can start behind op i of both frames]}: level k = its two DFP
+        fusion convs (engine.build_fuse_net order: level-major, current / support) + the head ops of that level; it can start when
+        the last per-frame op that writes the buffer its fusion reads has been issued.  The level that is ready only behind the
+        last frame op stays where it was (after the join, on the main stream)."""
+        nf = self.n_frame_ops
+        fuse = self.ops[2 * nf:self.n_head_start]
+        head_ops = self.ops[self.n_head_start:]
+        nlev = len(self.preds)
+        if len(fuse) != 2 * nlev:
+            return {}
+        out = {}
+        for k in range(nlev):
+            src = fuse[2 * k].x.buf.data_ptr()                   # (the tensor's own start: buffers may share one pooled storage)
+            writers = [i for i in range(nf) if self.ops[i].kind == "conv" and self.ops[i].y.buf.data_ptr() == src]
+            if not writers or max(writers) >= nf - 1:
+                continue
+            out.setdefault(max(writers), []).append([fuse[2 * k], fuse[2 * k + 1]] + [op for op in head_ops if op.level == k])
+        return out
 
     # ---- parameters of a (possibly stacked) BaseConv op -------------------------------------------------------------------
     def _bn_params(self, op):
