@@ -56,7 +56,7 @@ enum { SY_TILE_AUTO = 0, SY_TILE_256x256 = 1, SY_TILE_128x256 = 2, SY_TILE_128x1
                              needs wfrag): 128 ch x 2 rows x 32 px (8 waves) | 128 x 2 | 64 x 8 | 128 x 2 and 128 x 4 software-pipelined;
                              112, 113: software-pipelined, one 32 x 32 MFMA tile per wave (small launches): 64 ch x 2 rows | 128 ch x 2 rows;
                              107, 104: software-pipelined, 128 ch x 3 rows | 128 ch x 5 rows (three / five MFMAs per weight fragment);
-                             101, 100, 98, 109: THIRD generation (csrc/conv3x3_halo3.h) of 117 / 107 / 118 / 104: fragment reads with immediate
+                             101, 100, 98, 109 (96, 97: on 64 channels): THIRD generation (csrc/conv3x3_halo3.h) of 117 / 107 / 118 / 104: fragment reads with immediate
                              offsets, hand-placed instruction stream, prefetch across the channel-slab boundary (same summation order);
                              105, 106, 111: K GROUPS inside the workgroup (small launches; partial tiles summed through LDS in group order — another
                              fp32 summation order than the tiles above): 105 stride 2 forward 64 ch x 1 row, 2 groups | 106 32 ch, 4 groups |

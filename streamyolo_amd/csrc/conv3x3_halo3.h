@@ -68,14 +68,16 @@ constexpr int halo3_loads_behind_pieces(int NI, int SB) {
 
 // BD: pixel-fragment ring — the fragments of step S + BD - 1 are requested while step S multiplies.
 // ILV = 1: this generation's stream; ILV = 0 keeps the compiler-ordered step of the first halo3 measurement (profiles/r05 stage e).
-template <typename T, int TP, int DGRAD, int BD, int ILV = 1>
+// WC: waves over the channel blocks (4 = the 128-channel tiles; 2 = 64 channels x two groups of TP tile rows, for the 64-channel
+// layers of the 150x240 maps, where the 128-channel tile leaves two of its four waves without channels)
+template <typename T, int TP, int DGRAD, int BD, int ILV = 1, int WC = 4>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
     SY_TL_BEGIN(2 + (DGRAD ? 32 : 0));
-    constexpr int NW = 4;
+    constexpr int NW = 4, WP = NW / WC;
     constexpr int EPC = T::kEPC;
     constexpr int ESZ = 16 / EPC;
     constexpr int BK = 4 * EPC;
-    constexpr int TH = TP;
+    constexpr int TH = WP * TP;
     constexpr int RW = kHaloW;                             // 34 window columns per tile row
     constexpr int HR = (TH + 2) * RW;
     constexpr int NI = ((HR + 15) / 16 + NW - 1) / NW;     // DMA pieces (16 window rows each) per wave and slab
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = sy_uniform(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;               // channel block, group of TP tile rows
     const int l31 = lane & 31;
     const int half = lane >> 5;
     const sy_block_id bid = sy_xcd_block_id();
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
     // ---- weight fragments [ct][slab][tap][g][64 lanes][16 B]: the wave's 32 channels, one per-lane offset register per k-half
     const sy_buffer buff = sy_make_buffer(p.wfrag, p.wfrag_extent);
     const int ntile32 = (p.Cout + 31) / 32;
-    const int ct = bid.x * NW + wave;
+    const int ct = bid.x * WC + wc;
     const unsigned foff = (ct < ntile32 && !(p.ablate & 2)) ? (unsigned)((((long long)ct * ncs * 9) * 128 + lane) * 16) : 0xFFFFFFFFu;
     const unsigned foff1 = foff == 0xFFFFFFFFu ? 0xFFFFFFFFu : foff + 1024u;      // k-half 1
     uint4 fr[9][2];
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
     for (int kw = 0; kw < 3; ++kw) {
         const int hx = l31 + (DGRAD ? 2 - kw : kw);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) ba[kw][g] = (unsigned)(hx * 64 + (((g * 2 + half) ^ ((hx >> 2) & 3)) << 4));
+        for (int g = 0; g < 2; ++g) ba[kw][g] = (unsigned)(wp * TP * RB + hx * 64 + (((g * 2 + half) ^ ((hx >> 2) & 3)) << 4));
     }
     uint4 b[BD][TP];
     auto read_frag = [&](auto s_, auto u_) {               // pixel fragment of step S (mod 18: of the window `ba` points at), tile row U
@@ -217,28 +220,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo3_kernel(ConvArgs p) {
 #pragma unroll
     for (int u = 0; u < TP; ++u) {
         int n_, rem_;
-        if (!mp.map(u * 32 + l31, n_, rem_)) {
+        if (!mp.map((wp * TP + u) * 32 + l31, n_, rem_)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][u][r] = 0.0f;
         }
     }
-    conv_epilogue<T, NW, 1, 1, TP>(p_late, mp, e_bx, acc, smem, tid);
+    conv_epilogue<T, WC, WP, 1, TP>(p_late, mp, e_bx, acc, smem, tid);
     sy_probe(6);
     SY_TL_END();
 }
 
-template <typename T, int TP, int BD, int ILV = 1>
+template <typename T, int TP, int BD, int ILV = 1, int WC = 4>
 int launch_halo3(const ConvArgs& a_in, void* stream) {
-    constexpr int NW = 4, CT = 128, TH = TP, PT = TH * 32;
+    constexpr int NW = 4, WP = NW / WC, CT = WC * 32, TH = WP * TP, PT = TH * 32;
     constexpr int HR = (TH + 2) * kHaloW, NI = ((HR + 15) / 16 + NW - 1) / NW, BUF = NW * NI * 16 * 64;
     ConvArgs a = a_in;
     a.s2_classes = 0;
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W || a.ksplit > 1) return SY_ERR_UNSUPPORTED;
     if (a.Cin % (4 * T::kEPC) != 0 || a.Cin < 4 * T::kEPC || a.x_extent == 0 || a.wfrag == nullptr || a.wfrag_extent == 0) return SY_ERR_UNSUPPORTED;
     constexpr size_t smem_k = (size_t)2 * BUF;
-    constexpr size_t smem_e = (size_t)EpiLds<1, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
-    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= StageLimit<NW, 1, 1, TP>::kBytes);
-    constexpr size_t smem_s = (size_t)CT * 8;
+    constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
+    constexpr bool can_stage = (T::kEPC == 8 && smem_e <= StageLimit<WC, WP, 1, TP>::kBytes);
+    constexpr size_t smem_s = (size_t)WP * CT * 8;
     constexpr size_t smem = (can_stage && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
     const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
     dim3 grid((a.Cout + CT - 1) / CT, tiles, 1);
@@ -246,18 +249,18 @@ int launch_halo3(const ConvArgs& a_in, void* stream) {
 #ifndef SY_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 0, BD, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 1, BD, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 0, BD, ILV, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 1, BD, ILV, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
         attr_done = true;
     }
 #endif
-    if (dgrad) { SY_LAUNCH((conv3x3_halo3_kernel<T, TP, 1, BD, ILV>), grid, dim3(NW * 64), smem, stream, a); }
-    else { SY_LAUNCH((conv3x3_halo3_kernel<T, TP, 0, BD, ILV>), grid, dim3(NW * 64), smem, stream, a); }
+    if (dgrad) { SY_LAUNCH((conv3x3_halo3_kernel<T, TP, 1, BD, ILV, WC>), grid, dim3(NW * 64), smem, stream, a); }
+    else { SY_LAUNCH((conv3x3_halo3_kernel<T, TP, 0, BD, ILV, WC>), grid, dim3(NW * 64), smem, stream, a); }
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-// tile codes 98, 100, 101, 109 of sy_conv_desc::tile.  (A ring of 6 for the 2- / 3-row tiles — five steps of reads in flight — measured
+// tile codes 98, 100, 101, 109 (128 channels) and 96, 97 (64 channels) of sy_conv_desc::tile.  (A ring of 6 for the 2- / 3-row tiles — five steps of reads in flight — measured
 // the same or slower than the ring of 3: profiles/r05 stage h.)
 template <typename T>
 int launch_halo3_typed(const ConvArgs& a, void* stream) {
@@ -266,6 +269,8 @@ int launch_halo3_typed(const ConvArgs& a, void* stream) {
         case 100: return launch_halo3<T, 3, 3>(a, stream);     // 128 ch x (3 rows x 32 px)   (107)
         case 98: return launch_halo3<T, 4, 3>(a, stream);      // 128 ch x (4 rows x 32 px)   (118)
         case 109: return launch_halo3<T, 5, 3>(a, stream);     // 128 ch x (5 rows x 32 px)   (104)
+        case 96: return launch_halo3<T, 2, 3, 1, 2>(a, stream);   //  64 ch x (4 rows x 32 px): 2 channel blocks x 2 row groups
+        case 97: return launch_halo3<T, 3, 3, 1, 2>(a, stream);   //  64 ch x (6 rows x 32 px)
         default: return SY_ERR_ARG;
     }
 }

@@ -562,8 +562,8 @@ def save_tuned():
 # 256->256 @38x60 layers, +17 % on 512->512 @19x30 (profiles/r04 stage bd)
 # 101 / 100 / 98 / 109 (round 5) = the third generation of the same four tiles (csrc/conv3x3_halo3.h): fragment reads with immediate
 # offsets, hand-placed instruction stream, prefetch across the slab boundary; +7-17 % in the probes (profiles/r05 stages e-h); same
-# accumulation order as the second generation (bit-identical results)
-HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,116,117,118,107,104,101,100,98,109").replace("+", ",").split(",") if t]
+# accumulation order as the second generation (bit-identical results); 96 / 97 = the same kernel on 64 channels x (2 x 2 | 2 x 3) rows
+HALO_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_TILES", "114,115,116,117,118,107,104,101,100,98,109,96,97").replace("+", ",").split(",") if t]
 # stride-2 3x3 layers on the window-in-LDS kernels (tile codes 110 = forward, 108 = data gradient).  Measured in round 4
 # (profiles/r04/a_probe_s2_*.txt): forward 421 vs 395 (dark2.0) / 739 vs 585 TF/s (dark4.0) against the best implicit-GEMM
 # variant, data gradient 245 vs 250 / 504 vs 484; l step 22.61 vs 22.70 ms (b_bench_s2 / b_bench_base) — candidates by default
@@ -631,7 +631,7 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
     cands = list(_TILE_CANDIDATES["c32" if Cout <= 32 else "c64" if Cout <= 64 else "wide" if Cout < 256 else "wide256"])
     if k == 3 and stride == 1 and wf is not None and HALO_TILES:
         # 3x3 stride-1 layers: the halo-resident kernel (csrc/conv3x3_halo.h), tiles of 64 / 128 / 256 channels
-        cands += [t for t in HALO_TILES if not (t == 116 and Cout > 64)]
+        cands += [t for t in HALO_TILES if not (t in (116, 96, 97) and Cout > 64)]      # 116 / 96 / 97: the 64-channel tiles
         if N * Ho * Wo <= HALO_SMALL_PIXELS:
             cands += HALO_SMALL_TILES
     if k == 3 and stride == 2 and wf is not None and Cin % (16 if code == DT_F32 else 32) == 0:

@@ -176,10 +176,10 @@ def test_wgrad_many_splits_fold(backend):
     assert _rel(dw.cpu(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [98, 100, 101, 104, 106, 107, 109, 111, 112, 113, 114, 115, 116, 117, 118])
+@pytest.mark.parametrize("tile", [96, 97, 98, 100, 101, 104, 106, 107, 109, 111, 112, 113, 114, 115, 116, 117, 118])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "fwd"), ("bf16", "dgrad"), ("fp32", "dgrad")])
 def test_conv3x3_halo_kernel(backend, tile, dt, mode):
-    """csrc/conv3x3_halo.h (tile codes 104, 106, 107, 111..118 and csrc/conv3x3_halo3.h's 98, 100, 101, 109 (third generation: immediate-offset fragment reads, hand-placed instruction stream, cross-slab prefetch); 104 / 107 / 112 / 113 / 117 / 118 = the in-wave software-pipelined generation, 106 / 111 = the same with K groups inside the workgroup): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
+    """csrc/conv3x3_halo.h (tile codes 104, 106, 107, 111..118 and csrc/conv3x3_halo3.h's 96, 97 (64 channels), 98, 100, 101, 109 (third generation: immediate-offset fragment reads, hand-placed instruction stream, cross-slab prefetch); 104 / 107 / 112 / 113 / 117 / 118 = the in-wave software-pipelined generation, 106 / 111 = the same with K groups inside the workgroup): 3x3 stride-1 forward with per-frame BatchNorm statistics, and the data
     gradient (first write, accumulate, channel-slice output), on an image whose width and height are ragged against the
     32-pixel / TH-row tiles, with Cout ragged against the channel tile; against torch and against the implicit-GEMM kernel."""
     g = torch.Generator().manual_seed(tile + len(mode))

@@ -46,7 +46,7 @@ NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
          22: "rs128x64", 23: "rs64x64", 35: "d2-128x128", 36: "d2-64x256", 38: "d2-128x64", 39: "d2-64x64",
          51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64",
-         100: "halo3-128x3", 101: "halo3-128x2", 98: "halo3-128x4", 121: "k1-128x64", 122: "k1-64x128", 123: "k1-128x128", 117: "halo2-128x2", 118: "halo2-128x4w", 107: "halo2-128x3", 104: "halo2-128x5",
+         96: "halo3-64x4", 97: "halo3-64x6", 100: "halo3-128x3", 101: "halo3-128x2", 98: "halo3-128x4", 121: "k1-128x64", 122: "k1-64x128", 123: "k1-128x128", 117: "halo2-128x2", 118: "halo2-128x4w", 107: "halo2-128x3", 104: "halo2-128x5",
          112: "halo128x4", 113: "halo128x4w", 114: "halo128x2-8w", 115: "halo128x2", 116: "halo64x8",
          119: "halo2-128x8/8acc", 111: "halo2-256x4/8acc", 109: "halo3-128x5", 110: "halo2-s2-128x2", 108: "s2dgrad-128x2",
          99: "w3-128x128", 102: "w3-128x64", 103: "w3-64x64", 24: "rs256x64", 88: "wr256x64", 89: "wr256x128", 83: "wr128x128", 84: "wr64x256", 85: "wr32x256", 86: "wr128x64", 87: "wr64x64"}
@@ -102,7 +102,7 @@ def main():
                                             or ((t & 255) == 123 and cin > 256) or ((t & 255) != 121 and cin > 512)):
                 res.append(float("nan"))
                 continue
-            if (112 <= (t & 255) < 120 or (t & 255) in (111, 104, 106, 107, 109, 100, 101, 98)) and (k != 3 or st != 1):
+            if (112 <= (t & 255) < 120 or (t & 255) in (111, 104, 106, 107, 109, 100, 101, 98, 96, 97)) and (k != 3 or st != 1):
                 res.append(float("nan"))
                 continue
             if (t & 255) == 108 and (k != 3 or st != 2 or a.mode != "dgrad"):
@@ -111,7 +111,7 @@ def main():
             if (t & 255) == 110 and (k != 3 or st != 2 or a.mode == "dgrad"):
                 res.append(float("nan"))
                 continue
-            if (t & 255) < 104 and (t & 255) not in (98, 100, 101) and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
+            if (t & 255) < 104 and (t & 255) not in (96, 97, 98, 100, 101) and (((t & 15) in (4, 5) and cout > 64) or ((t & 15) in (8, 9) and cout < 256)):
                 res.append(float("nan"))
                 continue
             try:

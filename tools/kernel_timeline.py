@@ -46,7 +46,7 @@ y = View.alloc(N, Ho, Wo, cout, "bf16", dev); y.buf.copy_(torch.randn(y.buf.shap
 w = (torch.randn(cout, k * k * cin, generator=g) / (cin * k * k) ** 0.5).to(x.buf.dtype).to(dev)
 from streamyolo_amd.model.packing import pack_conv_weight_frag      # noqa: E402
 wf = pack_conv_weight_frag(w, k)
-reader = {"conv": ("sy_probe_read_conv_halo3_bf16" if (a.tile & 255) in (109, 100, 101, 98) else "sy_probe_read_conv_extra") if (((a.tile & 255) >= 104 or (a.tile & 255) in (98, 100, 101)) and (a.tile & 255) != 119) else "sy_probe_read_conv_igemm", "wgrad": "sy_probe_read_wgrad",
+reader = {"conv": ("sy_probe_read_conv_halo3_bf16" if (a.tile & 255) in (109, 100, 101, 98, 96, 97) else "sy_probe_read_conv_extra") if (((a.tile & 255) >= 104 or (a.tile & 255) in (96, 97, 98, 100, 101)) and (a.tile & 255) != 119) else "sy_probe_read_conv_igemm", "wgrad": "sy_probe_read_wgrad",
           "bnred": "sy_probe_read_train_ops"}[a.kind]
 read = getattr(C.CDLL(_lib.library_path()), reader)
 read.argtypes, read.restype = [C.c_void_p, C.c_int], C.c_int
