@@ -15,7 +15,8 @@ ARGS = ["--model", "nano", "--height", "32", "--width", "64", "--batch", "1", "-
 
 def _env(**extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(STREAMYOLO_BENCH_EMU="1", OMP_NUM_THREADS="2", **extra)
+    env.update(STREAMYOLO_BENCH_EMU="1", OMP_NUM_THREADS="2")
+    env.update(extra)
     return env
 
 
