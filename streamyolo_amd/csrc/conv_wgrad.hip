@@ -493,12 +493,18 @@ constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (
 // OCC = 2: at most 256 registers per lane (accumulators included), so that two workgroups — or another chain's waves — share a CU
 // with this kernel; OCC = 1 lets the compiler take the whole file (464: one workgroup owns the CU, see the 128-workgroup cap in
 // train_engine.py).
-template <typename T, int STG, int PD = 2, int SPB = 1, int OCC = 1>
-__global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p) {
+// CI2 = 2 (round 5): EIGHT waves, 64 input channels per workgroup — wave (cw = w & 3, ch = w >> 2) owns output channels [32 cw, + 32)
+// x input channels [32 ch, + 32) x nine taps.  The dy slab (the larger stream, re-read by every input-channel tile of the layer) is
+// staged once for twice the MFMAs: 21.3 KB of LDS-DMA per 144 MFMAs instead of 14.5 KB per 72 (-27 % L2 -> LDS bytes per MFMA), three
+// DMA pieces per wave and slab instead of four.  Run chip-wide the four-wave kernel is bound by exactly that stream (profiles/r05 k).
+template <typename T, int STG, int PD = 2, int SPB = 1, int OCC = 1, int CI2 = 1>
+__global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(WgradArgs p) {
     SY_TL_BEGIN(6);
-    constexpr int CT = 128, CIT = 32;
+    constexpr int CT = 128, CIT = 32 * CI2;
     constexpr int SB = CT / 16;                   // dy subtiles per slab
-    constexpr int STAGE = 2 * kXSub + SB * kSubPitch;
+    constexpr int NWV = 4 * CI2;                  // waves
+    constexpr int XP = 8 * CI2 / NWV, YP = SB / NWV;             // x / dy DMA pieces per wave and slab (2 / 2, or 2 / 1)
+    constexpr int STAGE = 2 * CI2 * kXSub + SB * kSubPitch;
     static_assert(T::kEPC == 8, "16-bit elements");
     SY_DYN_SMEM(smem);
     const int tid = threadIdx.x;
@@ -524,21 +530,21 @@ __global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p
     const sy_buffer bufdy = sy_make_buffer(p.dy, p.dy_extent);
     const sy_lds_base_t lds0 = sy_lds_base(smem);
     const int half8 = (lane & 1) * 8;
-    int x_rel[2], x_hy1[2], x_hx1[2];               // element offset relative to pixel (cur_h, w0); window row / column - 1
+    int x_rel[XP], x_hy1[XP], x_hx1[XP];            // element offset relative to pixel (cur_h, w0); window row / column - 1
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int j = wv + 4 * i;
+    for (int i = 0; i < XP; ++i) {
+        const int j = wv + NWV * i;
         const int pp = (j & 3) * 32 + (lane >> 1);             // flattened halo pixel
         const int hy = pp / 34, hx = pp - hy * 34;
         x_hy1[i] = pp < kHaloPix ? hy - 1 : 0x40000000;        // beyond the window: never valid
         x_hx1[i] = hx - 1;
         x_rel[i] = ((hy - 1) * p.W + (hx - 1)) * p.ldx + ci0 + (j >> 2) * 16 + half8;
     }
-    int y_rel[2];
-    bool y_cok[2];
+    int y_rel[YP];
+    bool y_cok[YP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int co = c0 + (wv + 4 * i) * 16 + half8;
+    for (int i = 0; i < YP; ++i) {
+        const int co = c0 + (wv + NWV * i) * 16 + half8;
         y_cok[i] = co < p.Cout;
         y_rel[i] = (lane >> 1) * p.lddy + co;
     }
@@ -559,8 +565,8 @@ __global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p
         const int xbase = cur_n * (int)p.xbs + (cur_h * p.W + w0) * p.ldx;        // wave-uniform
         const int ybase = cur_n * (int)p.dybs + (cur_h * p.Wo + w0) * p.lddy;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = wv + 4 * i;
+        for (int i = 0; i < XP; ++i) {
+            const int j = wv + NWV * i;
             const bool ok = live && (unsigned)(x_hy1[i] + cur_h) < (unsigned)p.H && (unsigned)(x_hx1[i] + w0) < (unsigned)p.W &&
                             !(p.ablate & 1);
             // (OR with an all-ones mask instead of a select: hipcc turns the select into an exec-mask branch around the add)
@@ -568,11 +574,11 @@ __global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p
                              stage + (unsigned)((j >> 2) * kXSub + (j & 3) * 1024));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = wv + 4 * i;
+        for (int i = 0; i < YP; ++i) {
+            const int j = wv + NWV * i;
             const bool ok = live && y_cok[i] && w0 + y_px < p.Wo && !(p.ablate & 2);
             sy_glds16_buf_at(bufdy, (unsigned)((ybase + y_rel[i]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0,
-                             stage + (unsigned)(2 * kXSub + j * kSubPitch));
+                             stage + (unsigned)(2 * CI2 * kXSub + j * kSubPitch));
         }
         if (++cur_ws == wsegs) { cur_ws = 0; if (++cur_h == p.Ho) { cur_h = 0; ++cur_n; } }
         ++issued;
@@ -587,7 +593,8 @@ __global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p
 
     // fragment gather (see conv_wgrad_tr_kernel): lane (g = lane >> 5, parity = (lane >> 4) & 1, i = lane & 15) addresses pixel
     // row 8 g + (i >> 2) (+ 4 for the second half of its 8 k-values), channel quad i & 3 of subtile `parity`
-    const int x_lane = ((lane >> 4) & 1) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+    const int cw = CI2 > 1 ? (wv & 3) : wv, ch = CI2 > 1 ? (wv >> 2) : 0;      // output-channel block, input-channel half of this wave
+    const int x_lane = (2 * ch + ((lane >> 4) & 1)) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
     const int y_lane = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 
     static_assert(STG >= 2 * SPB, "ring: SPB slabs multiply while at least SPB are in flight");
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p
     sy_probe(1);
     int stage_r = 0;
     for (int s = 0; s < nslab; s += SPB) {
-        sy_wait_vmcnt<4 * (STG - 2 * SPB)>();     // slabs s .. s + SPB - 1 landed; the STG - 2 SPB slabs behind them stay in flight
+        sy_wait_vmcnt<(XP + YP) * (STG - 2 * SPB)>();   // slabs s .. s + SPB - 1 landed; the STG - 2 SPB slabs behind them stay in flight
         sy_barrier();                             // ... for every wave; everyone is past the slabs before s
         if (s == 0) sy_probe(2);
 #pragma unroll
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p
 #pragma unroll
         for (int q = 0; q < SPB; ++q) {           // (a slab past the last one: zeros from the out-of-range pieces)
         const unsigned char* const xb = smem + stage_r * STAGE + x_lane;
-        const unsigned char* const yb = smem + stage_r * STAGE + 2 * kXSub + (wv * 2) * kSubPitch + y_lane;
+        const unsigned char* const yb = smem + stage_r * STAGE + 2 * CI2 * kXSub + (cw * 2) * kSubPitch + y_lane;
         stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
         // fragments of step (k-half, tap) + 2 are read while step (k-half, tap) multiplies
         uint4 a[PD + 1], b[2];
@@ -634,13 +641,13 @@ __global__ __launch_bounds__(kThreadsW, OCC) void conv_wgrad9_kernel(WgradArgs p
 
     // ---- epilogue: D[row = (tap, ci)][col = co]; partial slab of this split, or += into dW (one split)
     const int l31 = lane & 31, half = lane >> 5;
-    const int co = c0 + wv * 32 + l31;
+    const int co = c0 + cw * 32 + l31;
     if (co >= p.Cout) return;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ci = ci0 + q * 8 + half * 4;
+            const int ci = ci0 + ch * 32 + q * 8 + half * 4;
             const int kb = t * p.Cin + ci;
             const float v0 = acc[t][q * 4 + 0], v1 = acc[t][q * 4 + 1], v2 = acc[t][q * 4 + 2], v3 = acc[t][q * 4 + 3];
             if (p.splits > 1) {
@@ -788,15 +795,15 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int STG, int SPB = 1, int OCC = 1>
+template <typename T, int STG, int SPB = 1, int OCC = 1, int CI2 = 1, int PD = 2>
 int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
     if constexpr (T::kEPC != 8) {
         return SY_ERR_UNSUPPORTED;
     } else {
-        if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W || a.Cin % 32 != 0 ||
+        if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W || a.Cin % (32 * CI2) != 0 ||
             a.Cout % 16 != 0 || a.x_extent == 0 || a.dy_extent == 0)
             return SY_ERR_UNSUPPORTED;
-        const int gx = a.Cin / 32, gy = (a.Cout + 127) / 128;
+        const int gx = a.Cin / (32 * CI2), gy = (a.Cout + 127) / 128;
         const int slabs_total = a.N * a.Ho * ((a.Wo + 31) / 32);
         const int target = a.target_blocks > 0 ? a.target_blocks : 512;
         int splits = (target + gx * gy - 1) / (gx * gy);
@@ -809,16 +816,16 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
         a.slabs_per_split = (slabs_total + splits - 1) / splits;
         splits = (slabs_total + a.slabs_per_split - 1) / a.slabs_per_split;
         a.splits = splits;
-        constexpr size_t smem = (size_t)STG * (2 * kXSub + 8 * kSubPitch);
+        constexpr size_t smem = (size_t)STG * (2 * CI2 * kXSub + 8 * kSubPitch);
 #ifndef SY_EMU
         static bool attr_done = false;
         if (!attr_done) {
-            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, 2, SPB, OCC>;
+            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
             attr_done = true;
         }
 #endif
-        SY_LAUNCH((conv_wgrad9_kernel<T, STG, 2, SPB, OCC>), dim3(gx, gy, splits), dim3(kThreadsW), smem, stream, a);
+        SY_LAUNCH((conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
         if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
@@ -833,6 +840,12 @@ int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
     if (a.tile == 66) return launch_wgrad9<T, 6, 2>(a, ws_bytes, stream);  // ... ring of 6
     if (a.tile == 51) return launch_wgrad9<T, 4, 2, 2>(a, ws_bytes, stream);  // ... ring of 4, <= 256 registers (two workgroups per CU)
     if (a.tile == 52) return launch_wgrad9<T, 3, 1, 2>(a, ws_bytes, stream);  // tile 49 in <= 256 registers
+    if (a.tile == 53) return launch_wgrad9<T, 3, 1, 1, 2>(a, ws_bytes, stream);  // eight waves, 64 input channels per workgroup
+    if (a.tile == 54) return launch_wgrad9<T, 4, 2, 1, 2>(a, ws_bytes, stream);  // ... two slabs per rendezvous, ring of 4
+    if (a.tile == 55) return launch_wgrad9<T, 3, 1, 1, 2, 4>(a, ws_bytes, stream);  // 53 with the x fragments read 4 / 6 MFMAs ahead
+    if (a.tile == 56) return launch_wgrad9<T, 3, 1, 1, 2, 6>(a, ws_bytes, stream);
+    if (a.tile == 57) return launch_wgrad9<T, 3, 1, 2, 1, 4>(a, ws_bytes, stream);  // 52 with ...
+    if (a.tile == 58) return launch_wgrad9<T, 3, 1, 2, 1, 6>(a, ws_bytes, stream);
     // (rings of 6 / 8 slabs — one workgroup per CU leaves the LDS free — measured in round 4: no faster, the kernel is issue-bound)
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128
