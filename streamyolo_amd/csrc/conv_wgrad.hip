@@ -497,7 +497,16 @@ constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (
 // x input channels [32 ch, + 32) x nine taps.  The dy slab (the larger stream, re-read by every input-channel tile of the layer) is
 // staged once for twice the MFMAs: 21.3 KB of LDS-DMA per 144 MFMAs instead of 14.5 KB per 72 (-27 % L2 -> LDS bytes per MFMA), three
 // DMA pieces per wave and slab instead of four.  Run chip-wide the four-wave kernel is bound by exactly that stream (profiles/r05 k).
-template <typename T, int STG, int PD = 2, int SPB = 1, int OCC = 1, int CI2 = 1>
+//
+// PIPE = 1 (round 5): the slab loop as ONE instruction stream.  In the loop above a slab is [wait + barrier, ~55 scalar / vector
+// instructions of slab bookkeeping and DMA issue, ten fragment reads, a full LGKM drain] and THEN 18 MFMAs: the in-order wave issues
+// nothing into the matrix pipe for ~45 % of a slab (main loop 45 us for 20.5 us of MFMA at 256->256 @38x60 x 16), and neither fewer
+// L2 -> LDS bytes (tile 53), deeper fragment prefetch (55-58), two slabs per rendezvous (50 / 51) nor deeper rings moved it.  Here
+// the rendezvous of slab s + 1 sits in front of MFMA 9 of slab s (ring of >= 4 slabs: the DMA of slab s + STG - 1 is issued behind
+// it, one piece behind each of the next MFMAs), the first fragments of slab s + 1 are read behind MFMAs 14 / 16 / 17 of slab s, and
+// the fragment ring (18 % 3 == 0) runs on across the slab boundary — every MFMA has two fragment reads and at most one DMA piece or
+// one extra fragment behind it, and no MFMA waits for a barrier.
+template <typename T, int STG, int PD = 2, int SPB = 1, int OCC = 1, int CI2 = 1, int PIPE = 0>
 __global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(WgradArgs p) {
     SY_TL_BEGIN(6);
     constexpr int CT = 128, CIT = 32 * CI2;
@@ -558,31 +567,43 @@ __global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(Wgrad
         cur_ws = rem - cur_h * wsegs;
     }
     int issued = 0, stage_w = 0;
-    auto issue_slab = [&]() {
-        const unsigned stage = (unsigned)(stage_w * STAGE);
-        const int w0 = cur_ws * 32;
-        const bool live = issued < nslab;
-        const int xbase = cur_n * (int)p.xbs + (cur_h * p.W + w0) * p.ldx;        // wave-uniform
-        const int ybase = cur_n * (int)p.dybs + (cur_h * p.Wo + w0) * p.lddy;
-#pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const int j = wv + NWV * i;
-            const bool ok = live && (unsigned)(x_hy1[i] + cur_h) < (unsigned)p.H && (unsigned)(x_hx1[i] + w0) < (unsigned)p.W &&
+    // one slab's DMA = issue_begin (wave-uniform bases of the slab under the cursor), XP + YP pieces, issue_end (cursor on)
+    unsigned is_stage = 0;
+    int is_w0 = 0, is_xbase = 0, is_ybase = 0;
+    bool is_live = false;
+    auto issue_begin = [&]() {
+        is_stage = (unsigned)(stage_w * STAGE);
+        is_w0 = cur_ws * 32;
+        is_live = issued < nslab;
+        is_xbase = cur_n * (int)p.xbs + (cur_h * p.W + is_w0) * p.ldx;        // wave-uniform
+        is_ybase = cur_n * (int)p.dybs + (cur_h * p.Wo + is_w0) * p.lddy;
+    };
+    auto issue_piece = [&](auto i_) {
+        constexpr int I = decltype(i_)::value;
+        if constexpr (I < XP) {
+            const int j = wv + NWV * I;
+            const bool ok = is_live && (unsigned)(x_hy1[I] + cur_h) < (unsigned)p.H && (unsigned)(x_hx1[I] + is_w0) < (unsigned)p.W &&
                             !(p.ablate & 1);
             // (OR with an all-ones mask instead of a select: hipcc turns the select into an exec-mask branch around the add)
-            sy_glds16_buf_at(bufx, (unsigned)((xbase + x_rel[i]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0,
-                             stage + (unsigned)((j >> 2) * kXSub + (j & 3) * 1024));
+            sy_glds16_buf_at(bufx, (unsigned)((is_xbase + x_rel[I]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0,
+                             is_stage + (unsigned)((j >> 2) * kXSub + (j & 3) * 1024));
+        } else {
+            constexpr int Y = I - XP;
+            const int j = wv + NWV * Y;
+            const bool ok = is_live && y_cok[Y] && is_w0 + y_px < p.Wo && !(p.ablate & 2);
+            sy_glds16_buf_at(bufdy, (unsigned)((is_ybase + y_rel[Y]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0,
+                             is_stage + (unsigned)(2 * CI2 * kXSub + j * kSubPitch));
         }
-#pragma unroll
-        for (int i = 0; i < YP; ++i) {
-            const int j = wv + NWV * i;
-            const bool ok = live && y_cok[i] && w0 + y_px < p.Wo && !(p.ablate & 2);
-            sy_glds16_buf_at(bufdy, (unsigned)((ybase + y_rel[i]) * 2) | (ok ? 0u : 0xFFFFFFFFu), lds0,
-                             stage + (unsigned)(2 * CI2 * kXSub + j * kSubPitch));
-        }
+    };
+    auto issue_end = [&]() {
         if (++cur_ws == wsegs) { cur_ws = 0; if (++cur_h == p.Ho) { cur_h = 0; ++cur_n; } }
         ++issued;
         stage_w = (stage_w + 1 == STG) ? 0 : stage_w + 1;
+    };
+    auto issue_slab = [&]() {
+        issue_begin();
+        sy_static_for<0, XP + YP>([&](auto i_) { issue_piece(i_); });
+        issue_end();
     };
 
     f32x16 acc[9];
@@ -599,6 +620,59 @@ __global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(Wgrad
 
     static_assert(STG >= 2 * SPB, "ring: SPB slabs multiply while at least SPB are in flight");
     sy_probe(0);
+    if constexpr (PIPE) {
+        static_assert(STG >= 4 && SPB == 1 && PD == 2, "pipelined loop: ring of >= 4 slabs, fragment ring of 3");
+        constexpr int NP = XP + YP;
+        constexpr int RV = 9;                     // the rendezvous of the NEXT slab sits in front of this MFMA
+        for (int j = 0; j < STG - 1; ++j) issue_slab();
+        sy_probe(1);
+        sy_wait_vmcnt<NP * (STG - 2)>();          // slab 0 landed
+        sy_barrier();
+        sy_probe(2);
+        uint4 a[3], b[2];
+        auto read_a = [&](const unsigned char* xb, auto st_) {
+            constexpr int ST = decltype(st_)::value;
+            constexpr int KS = ST / 9, TAP = ST % 9;
+            const unsigned char* ptr = xb + ((TAP / 3) * 34 + (TAP % 3)) * 32 + KS * 512;
+            const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
+            a[ST % 3] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        };
+        auto read_b = [&](const unsigned char* yb, auto ks_) {
+            constexpr int KS = decltype(ks_)::value;
+            const uint2 lo = sy_lds_read_tr16(yb + KS * 512), hi = sy_lds_read_tr16(yb + KS * 512 + 128);
+            b[KS] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        };
+        const unsigned char* const x0 = smem + x_lane;
+        const unsigned char* const y0 = smem + 2 * CI2 * kXSub + (cw * 2) * kSubPitch + y_lane;
+        int stage_r = 0;
+        read_b(y0, sy_int<0>());
+        read_a(x0, sy_int<0>());
+        read_a(x0, sy_int<1>());
+        for (int s = 0; s < nslab; ++s) {
+            const int stage_n = (stage_r + 1 == STG) ? 0 : stage_r + 1;
+            const unsigned char* const xb = x0 + stage_r * STAGE;
+            const unsigned char* const yb = y0 + stage_r * STAGE;
+            const unsigned char* const xn = x0 + stage_n * STAGE;
+            const unsigned char* const yn = y0 + stage_n * STAGE;
+            stage_r = stage_n;
+            sy_static_for<0, 18>([&](auto st_) {
+                constexpr int ST = decltype(st_)::value;
+                if constexpr (ST == RV) {
+                    sy_wait_vmcnt<NP * (STG - 3)>();      // my pieces of slab s + 1 landed (slabs s + 2 .. s + STG - 2 stay in flight)
+                    sy_barrier();                         // ... everyone's; and everyone is done with slab s - 1: its stage is free
+                    issue_begin();
+                }
+                if constexpr (ST + 2 < 18) read_a(xb, sy_int<ST + 2>());
+                else read_a(xn, sy_int<ST + 2 - 18>());
+                if constexpr (ST == 1) read_b(yb, sy_int<1>());                       // (its registers: free since MFMA 17 of slab s - 1)
+                if constexpr (ST >= RV && ST < RV + NP) issue_piece(sy_int<ST - RV>());
+                if constexpr (ST == RV + NP) issue_end();
+                if constexpr (ST == 14) read_b(yn, sy_int<0>());                      // (free since MFMA 8)
+                acc[ST % 9] = sy_mfma_group(T(), a[ST % 3], b[ST / 9], acc[ST % 9]);
+                sy_sched_fence();
+            });
+        }
+    } else {
     for (int j = 0; j < STG - SPB; ++j) issue_slab();
     sy_probe(1);
     int stage_r = 0;
@@ -635,6 +709,7 @@ __global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(Wgrad
             sy_sched_fence();
         });
         }
+    }
     }
     sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
     sy_probe(3);
@@ -795,7 +870,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int STG, int SPB = 1, int OCC = 1, int CI2 = 1, int PD = 2>
+template <typename T, int STG, int SPB = 1, int OCC = 1, int CI2 = 1, int PD = 2, int PIPE = 0>
 int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
     if constexpr (T::kEPC != 8) {
         return SY_ERR_UNSUPPORTED;
@@ -820,12 +895,12 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 #ifndef SY_EMU
         static bool attr_done = false;
         if (!attr_done) {
-            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2>;
+            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2, PIPE>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
             attr_done = true;
         }
 #endif
-        SY_LAUNCH((conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
+        SY_LAUNCH((conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2, PIPE>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
         if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
@@ -836,16 +911,12 @@ template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
     if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
     if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
-    if (a.tile == 50) return launch_wgrad9<T, 4, 2>(a, ws_bytes, stream);  // two slabs per rendezvous, ring of 4
-    if (a.tile == 66) return launch_wgrad9<T, 6, 2>(a, ws_bytes, stream);  // ... ring of 6
-    if (a.tile == 51) return launch_wgrad9<T, 4, 2, 2>(a, ws_bytes, stream);  // ... ring of 4, <= 256 registers (two workgroups per CU)
-    if (a.tile == 52) return launch_wgrad9<T, 3, 1, 2>(a, ws_bytes, stream);  // tile 49 in <= 256 registers
+    if (a.tile == 52) return launch_wgrad9<T, 3, 1, 2>(a, ws_bytes, stream);  // tile 49 in <= 256 registers (two workgroups per CU)
     if (a.tile == 53) return launch_wgrad9<T, 3, 1, 1, 2>(a, ws_bytes, stream);  // eight waves, 64 input channels per workgroup
-    if (a.tile == 54) return launch_wgrad9<T, 4, 2, 1, 2>(a, ws_bytes, stream);  // ... two slabs per rendezvous, ring of 4
-    if (a.tile == 55) return launch_wgrad9<T, 3, 1, 1, 2, 4>(a, ws_bytes, stream);  // 53 with the x fragments read 4 / 6 MFMAs ahead
-    if (a.tile == 56) return launch_wgrad9<T, 3, 1, 1, 2, 6>(a, ws_bytes, stream);
-    if (a.tile == 57) return launch_wgrad9<T, 3, 1, 2, 1, 4>(a, ws_bytes, stream);  // 52 with ...
-    if (a.tile == 58) return launch_wgrad9<T, 3, 1, 2, 1, 6>(a, ws_bytes, stream);
+    if (a.tile == 59) return launch_wgrad9<T, 4, 1, 2, 1, 2, 1>(a, ws_bytes, stream);  // one instruction stream (PIPE): tile 52 ...
+    if (a.tile == 60) return launch_wgrad9<T, 4, 1, 1, 2, 2, 1>(a, ws_bytes, stream);  // ... tile 53
+    // (measured and not instantiated any more — profiles/r05 stages j, zb, ze: two slabs per rendezvous (SPB = 2; codes 50 / 66 / 51 /
+    //  54) +0.5-4 % alone and nothing in the step; x fragments read 4 / 6 MFMAs ahead (PD; codes 55-58) -1 %)
     // (rings of 6 / 8 slabs — one workgroup per CU leaves the LDS free — measured in round 4: no faster, the kernel is issue-bound)
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128

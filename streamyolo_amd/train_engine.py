@@ -1046,14 +1046,16 @@ class TrainPlan:
             # them, not its own duration.  128 workgroups leave half the CUs to the main chains: the kernel takes ~1.8x as long, the
             # step is 0.6 ms shorter (22.4-22.8 -> 21.8-22.1 ms; 64 / 192 / 384 worse — profiles/r04 stage s; re-measured with the
             # <= 256-register variants in round 5, stage q: same optimum)
-            nine = (49, 65, 50, 66, 51, 52, 53, 54, 55, 56, 57, 58)
+            nine = (49, 65, 52, 53, 59, 60)
             cap9 = int(os.environ.get("STREAMYOLO_WGRAD9_BLOCKS", "128"))
             # ... and wherever the layer has a multiple of 64 input channels the eight-wave variant (tile 53: 64 input channels per
             # workgroup, the dy slab staged once for twice the MFMAs) on 96 CUs: alone it is no faster than tile 52 (668 vs 671
             # TF/s at 256->256 @38x60 x 16), in the step it frees a quarter of the CUs tile 52 held — l 20.77-20.89 vs 20.93-21.00
             # ms, m 14.43-14.45 vs 14.52-14.56, 4 pairs 13.43 vs 13.50, s 7.57 vs 7.59 (profiles/r05 stages zb-zd; 80 / 112 / 128
             # workgroups: 20.91-21.03, 64 / 256: slower than tile 52)
-            wide9 = int(os.environ.get("STREAMYOLO_WGRAD9_WIDE", "53"))           # 0: off
+            # Tile 60 = 53 with the pipelined slab loop: the kernel itself -4 % at these 96 workgroups, the step unchanged (20.98-
+            # 21.01 vs 20.94-20.99 ms, stage zf): the step does not wait for this kernel, it shares the L2 / HBM path with it.
+            wide9 = int(os.environ.get("STREAMYOLO_WGRAD9_WIDE", "60"))           # 0: off
             if wide9 and wt[0] in nine and x.C % 64 == 0:
                 wt, cap9 = (wide9, wt[1]), int(os.environ.get("STREAMYOLO_WGRAD9_WIDE_BLOCKS", "96"))
             if cap9 > 0 and wt[0] in nine and wt[1] > cap9:

@@ -17,6 +17,7 @@
 #   layers                       per-layer kernel times (tools/profile_train.py)         -> train_l_layer_profile.txt
 #   host[:MODEL]                 host-side launch profile (tools/host_profile.py)        -> host_profile_train_MODEL.txt
 #   py:NAME:SCRIPT[:ARGS]        python SCRIPT ARGS                                      -> NAME.txt
+#   tl                           launch timeline of the l step from the probe build (tools/step_timeline.py) -> step_timeline_train_l.{json,txt}
 #   tunecache                    copy the tuner cache the runs above wrote (lib/tune_cache.json) -> tune_cache.json
 STAGE=$1; shift
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -52,6 +53,8 @@ for task in "$@"; do
                python tools/pmc_mfma_util.py /tmp/pmc_m_$STAGE > $O/mfma_util_train_l.txt 2>&1; tail -30 $O/mfma_util_train_l.txt ;;
         layers) (timeout 900 python tools/profile_train.py ${a//,/ } 2>&1 | grep -vE "$noise") > $O/train_l_layer_profile.txt 2>&1; tail -12 $O/train_l_layer_profile.txt ;;
         host)  m=${a:-l}; (timeout 600 python tools/host_profile.py $m 2>&1 | grep -v "^$" | tail -40) > $O/host_profile_train_$m.txt 2>&1; tail -12 $O/host_profile_train_$m.txt ;;
+        tl)    (STREAMYOLO_HIP_LIB=$PWD/tools/probes/_build/libstreamyolo_probe.so timeout 600 python tools/step_timeline.py --bins 0.5 --json $O/step_timeline_train_l.json 2>&1 | grep -vE "$noise") > $O/step_timeline_train_l.txt 2>&1
+               head -6 $O/step_timeline_train_l.txt ;;
         tunecache) cp streamyolo_amd/lib/tune_cache.json $O/tune_cache.json 2>/dev/null; ls -la $O/tune_cache.json ;;
         py)    (timeout 1200 python $b ${c//,/ } 2>&1 | grep -vE "$noise") > $O/$a.txt 2>&1; tail -40 $O/$a.txt ;;
         *) echo "unknown task $task" ;;
