@@ -284,7 +284,12 @@ class TrainPlan:
     #  reads every replica in every workgroup; 32 stays the fp32 default when the exact one-row-per-workgroup layout is switched off)
     STAT_COPIES = int(os.environ.get("STREAMYOLO_STAT_COPIES", "0"))     # 0 = by compute dtype: 4 (16-bit) / 32 (fp32)
     WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
-    RING = int(os.environ.get("STREAMYOLO_RING", "5"))   # raw-gradient scratch slots (5 vs 3: -0.1 ms per l step, measured); (wgrad of layer i overlaps BN backward / dgrad of i-1, i-2)
+    # raw-gradient scratch slots: the weight gradient of layer i (side streams) overlaps BatchNorm backward / data gradient of the
+    # layers behind it, and a frame chain that wants a slot back waits for the weight gradient that last read it.  5 vs 3: -0.1 ms
+    # per l step (round 2); with round 5's shorter frame chains the weight-gradient streams trail further behind: 9 vs 5 21.19-21.21
+    # vs 21.37-21.43 ms and 20.85-21.00 vs 21.02-21.08 on another box (7: half of it; 12 / 16 / 24: the same as 9 — profiles/r05
+    # stages zi, zj).  A slot is the largest raw gradient of the plan (l, 8 pairs: 295 MB).
+    RING = int(os.environ.get("STREAMYOLO_RING", "9"))
     STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
     TAPE_ON_CPU = True           # the SIMT-emulator test runs replay launch tapes too (same code path as the GPU)
 
