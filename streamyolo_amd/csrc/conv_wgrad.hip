@@ -483,16 +483,11 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
 constexpr int kHaloPix = 3 * 34;                  // halo pixels of a slab (3 rows x (32 + 2))
 constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (102 used) x 16 channels + bank padding
 
-// PD: (k-half, tap) steps whose x fragments are requested ahead of the step that multiplies (ring of PD + 1 fragments).  PD = 4
-// (+ 8 VGPRs, waits become lgkmcnt(6)) was measured against PD = 2 in round 4: 3-8 % SLOWER on every 3x3 layer
-// (profiles/r04/a_probe_wgrad.txt) — removed; so was the eight-wave variant of this tile (ties, round 2).
-// SPB (round 5): slabs per rendezvous.  A 32-pixel slab is 18 MFMAs = 576 cycles of the matrix pipe; the in-kernel timeline
-// (profiles/r04 stage i) has it at 1430: the counted wait + barrier + the ~70 scalar / vector instructions that place the next slab's
-// four DMA pieces stand between every 18 MFMAs of a single in-order wave.  SPB = 2 waits once for TWO landed slabs, issues two and
-// multiplies two (36 MFMAs between barriers); the ring must then hold 2 x SPB slabs at least.
+// The x fragments of step (k-half, tap) + 2 are read while step (k-half, tap) multiplies (ring of three fragments; reading 4 / 6 steps
+// ahead was measured twice, round 4 and round 5 stage ze: no faster); one slab per rendezvous (two: +0.5-4 % alone, nothing in the
+// step — round 5 stage j); rings of 6 / 8 slabs: no faster (round 4).
 // OCC = 2: at most 256 registers per lane (accumulators included), so that two workgroups — or another chain's waves — share a CU
-// with this kernel; OCC = 1 lets the compiler take the whole file (464: one workgroup owns the CU, see the 128-workgroup cap in
-// train_engine.py).
+// with this kernel; OCC = 1 (tiles 49 / 65, round 2) lets the compiler take the whole file (464 registers: one workgroup owns the CU).
 // CI2 = 2 (round 5): EIGHT waves, 64 input channels per workgroup — wave (cw = w & 3, ch = w >> 2) owns output channels [32 cw, + 32)
 // x input channels [32 ch, + 32) x nine taps.  The dy slab (the larger stream, re-read by every input-channel tile of the layer) is
 // staged once for twice the MFMAs: 21.3 KB of LDS-DMA per 144 MFMAs instead of 14.5 KB per 72 (-27 % L2 -> LDS bytes per MFMA), three
@@ -501,12 +496,12 @@ constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (
 // PIPE = 1 (round 5): the slab loop as ONE instruction stream.  In the loop above a slab is [wait + barrier, ~55 scalar / vector
 // instructions of slab bookkeeping and DMA issue, ten fragment reads, a full LGKM drain] and THEN 18 MFMAs: the in-order wave issues
 // nothing into the matrix pipe for ~45 % of a slab (main loop 45 us for 20.5 us of MFMA at 256->256 @38x60 x 16), and neither fewer
-// L2 -> LDS bytes (tile 53), deeper fragment prefetch (55-58), two slabs per rendezvous (50 / 51) nor deeper rings moved it.  Here
+// L2 -> LDS bytes (tile 53), deeper fragment prefetch, two slabs per rendezvous nor deeper rings moved it.  Here
 // the rendezvous of slab s + 1 sits in front of MFMA 9 of slab s (ring of >= 4 slabs: the DMA of slab s + STG - 1 is issued behind
 // it, one piece behind each of the next MFMAs), the first fragments of slab s + 1 are read behind MFMAs 14 / 16 / 17 of slab s, and
 // the fragment ring (18 % 3 == 0) runs on across the slab boundary — every MFMA has two fragment reads and at most one DMA piece or
 // one extra fragment behind it, and no MFMA waits for a barrier.
-template <typename T, int STG, int PD = 2, int SPB = 1, int OCC = 1, int CI2 = 1, int PIPE = 0>
+template <typename T, int STG, int OCC = 1, int CI2 = 1, int PIPE = 0>
 __global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(WgradArgs p) {
     SY_TL_BEGIN(6);
     constexpr int CT = 128, CIT = 32 * CI2;
@@ -618,10 +613,10 @@ __global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(Wgrad
     const int x_lane = (2 * ch + ((lane >> 4) & 1)) * kXSub + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
     const int y_lane = ((lane >> 4) & 1) * kSubPitch + ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 
-    static_assert(STG >= 2 * SPB, "ring: SPB slabs multiply while at least SPB are in flight");
+    static_assert(STG >= 3, "ring: one slab multiplies while at least one is in flight");
     sy_probe(0);
     if constexpr (PIPE) {
-        static_assert(STG >= 4 && SPB == 1 && PD == 2, "pipelined loop: ring of >= 4 slabs, fragment ring of 3");
+        static_assert(STG >= 4, "pipelined loop: ring of >= 4 slabs");
         constexpr int NP = XP + YP;
         constexpr int RV = 9;                     // the rendezvous of the NEXT slab sits in front of this MFMA
         for (int j = 0; j < STG - 1; ++j) issue_slab();
@@ -673,42 +668,38 @@ __global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(Wgrad
             });
         }
     } else {
-    for (int j = 0; j < STG - SPB; ++j) issue_slab();
+    for (int j = 0; j < STG - 1; ++j) issue_slab();
     sy_probe(1);
     int stage_r = 0;
-    for (int s = 0; s < nslab; s += SPB) {
-        sy_wait_vmcnt<(XP + YP) * (STG - 2 * SPB)>();   // slabs s .. s + SPB - 1 landed; the STG - 2 SPB slabs behind them stay in flight
-        sy_barrier();                             // ... for every wave; everyone is past the slabs before s
+    for (int s = 0; s < nslab; ++s) {
+        sy_wait_vmcnt<(XP + YP) * (STG - 2)>();   // slab s landed; the STG - 2 slabs behind it stay in flight
+        sy_barrier();                             // ... for every wave; everyone is past slab s - 1
         if (s == 0) sy_probe(2);
-#pragma unroll
-        for (int q = 0; q < SPB; ++q) issue_slab();
-#pragma unroll
-        for (int q = 0; q < SPB; ++q) {           // (a slab past the last one: zeros from the out-of-range pieces)
+        issue_slab();                             // (a slab past the last one: zeros from the out-of-range pieces)
         const unsigned char* const xb = smem + stage_r * STAGE + x_lane;
         const unsigned char* const yb = smem + stage_r * STAGE + 2 * CI2 * kXSub + (cw * 2) * kSubPitch + y_lane;
         stage_r = (stage_r + 1 == STG) ? 0 : stage_r + 1;
-        // fragments of step (k-half, tap) + 2 are read while step (k-half, tap) multiplies
-        uint4 a[PD + 1], b[2];
+        uint4 a[3], b[2];
         auto read_a = [&](auto st_) {
             constexpr int ST = decltype(st_)::value;
             constexpr int KS = ST / 9, TAP = ST % 9;
             const unsigned char* ptr = xb + ((TAP / 3) * 34 + (TAP % 3)) * 32 + KS * 512;
             const uint2 lo = sy_lds_read_tr16(ptr), hi = sy_lds_read_tr16(ptr + 128);
-            a[ST % (PD + 1)] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            a[ST % 3] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         };
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uint2 lo = sy_lds_read_tr16(yb + ks * 512), hi = sy_lds_read_tr16(yb + ks * 512 + 128);
             b[ks] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-        sy_static_for<0, PD>([&](auto st_) { read_a(st_); });
+        read_a(sy_int<0>());
+        read_a(sy_int<1>());
         sy_static_for<0, 18>([&](auto st_) {
             constexpr int ST = decltype(st_)::value;
-            if constexpr (ST + PD < 18) read_a(sy_int<ST + PD>());
-            acc[ST % 9] = sy_mfma_group(T(), a[ST % (PD + 1)], b[ST / 9], acc[ST % 9]);
+            if constexpr (ST + 2 < 18) read_a(sy_int<ST + 2>());
+            acc[ST % 9] = sy_mfma_group(T(), a[ST % 3], b[ST / 9], acc[ST % 9]);
             sy_sched_fence();
         });
-        }
     }
     }
     sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
@@ -870,7 +861,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int STG, int SPB = 1, int OCC = 1, int CI2 = 1, int PD = 2, int PIPE = 0>
+template <typename T, int STG, int OCC = 1, int CI2 = 1, int PIPE = 0>
 int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
     if constexpr (T::kEPC != 8) {
         return SY_ERR_UNSUPPORTED;
@@ -895,12 +886,12 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 #ifndef SY_EMU
         static bool attr_done = false;
         if (!attr_done) {
-            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2, PIPE>;
+            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, OCC, CI2, PIPE>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
             attr_done = true;
         }
 #endif
-        SY_LAUNCH((conv_wgrad9_kernel<T, STG, PD, SPB, OCC, CI2, PIPE>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
+        SY_LAUNCH((conv_wgrad9_kernel<T, STG, OCC, CI2, PIPE>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
         if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
@@ -911,13 +902,10 @@ template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
     if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
     if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
-    if (a.tile == 52) return launch_wgrad9<T, 3, 1, 2>(a, ws_bytes, stream);  // tile 49 in <= 256 registers (two workgroups per CU)
-    if (a.tile == 53) return launch_wgrad9<T, 3, 1, 1, 2>(a, ws_bytes, stream);  // eight waves, 64 input channels per workgroup
-    if (a.tile == 59) return launch_wgrad9<T, 4, 1, 2, 1, 2, 1>(a, ws_bytes, stream);  // one instruction stream (PIPE): tile 52 ...
-    if (a.tile == 60) return launch_wgrad9<T, 4, 1, 1, 2, 2, 1>(a, ws_bytes, stream);  // ... tile 53
-    // (measured and not instantiated any more — profiles/r05 stages j, zb, ze: two slabs per rendezvous (SPB = 2; codes 50 / 66 / 51 /
-    //  54) +0.5-4 % alone and nothing in the step; x fragments read 4 / 6 MFMAs ahead (PD; codes 55-58) -1 %)
-    // (rings of 6 / 8 slabs — one workgroup per CU leaves the LDS free — measured in round 4: no faster, the kernel is issue-bound)
+    if (a.tile == 52) return launch_wgrad9<T, 3, 2>(a, ws_bytes, stream);        // tile 49 in <= 256 registers (two workgroups per CU)
+    if (a.tile == 53) return launch_wgrad9<T, 3, 1, 2>(a, ws_bytes, stream);     // eight waves, 64 input channels per workgroup
+    if (a.tile == 59) return launch_wgrad9<T, 4, 2, 1, 1>(a, ws_bytes, stream);  // one instruction stream (PIPE): tile 52 ...
+    if (a.tile == 60) return launch_wgrad9<T, 4, 1, 2, 1>(a, ws_bytes, stream);  // ... tile 53
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128
         case 2: return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);   // 128 x  64

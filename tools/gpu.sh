@@ -18,6 +18,7 @@
 #   host[:MODEL]                 host-side launch profile (tools/host_profile.py)        -> host_profile_train_MODEL.txt
 #   py:NAME:SCRIPT[:ARGS]        python SCRIPT ARGS                                      -> NAME.txt
 #   tl                           launch timeline of the l step from the probe build (tools/step_timeline.py) -> step_timeline_train_l.{json,txt}
+#   install                      this run's traffic / timeline JSON -> profiles/r05/ on the box (bench.py reports them when their kernel-source key matches)
 #   tunecache                    copy the tuner cache the runs above wrote (lib/tune_cache.json) -> tune_cache.json
 STAGE=$1; shift
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -55,6 +56,7 @@ for task in "$@"; do
         host)  m=${a:-l}; (timeout 600 python tools/host_profile.py $m 2>&1 | grep -v "^$" | tail -40) > $O/host_profile_train_$m.txt 2>&1; tail -12 $O/host_profile_train_$m.txt ;;
         tl)    (STREAMYOLO_HIP_LIB=$PWD/tools/probes/_build/libstreamyolo_probe.so timeout 600 python tools/step_timeline.py --bins 0.5 --json $O/step_timeline_train_l.json 2>&1 | grep -vE "$noise") > $O/step_timeline_train_l.txt 2>&1
                head -6 $O/step_timeline_train_l.txt ;;
+        install) cp $O/traffic_train_l.json $O/step_timeline_train_l.json profiles/r05/ && echo "counter files of this run installed for the bench lines behind this task" ;;
         tunecache) cp streamyolo_amd/lib/tune_cache.json $O/tune_cache.json 2>/dev/null; ls -la $O/tune_cache.json ;;
         py)    (timeout 1200 python $b ${c//,/ } 2>&1 | grep -vE "$noise") > $O/$a.txt 2>&1; tail -40 $O/$a.txt ;;
         *) echo "unknown task $task" ;;
