@@ -265,6 +265,38 @@ WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD
 # a low hardware queue priority: 22.78-22.79 vs 22.70 ms — profiles/r04/b_bench_ownw*.json — removed.)
 
 
+NINE_TAP_WGRAD_TILES = (49, 65, 52, 53, 59, 60)     # conv_wgrad9_kernel (csrc/conv_wgrad.hip)
+
+
+def scheduled_wgrad(wt, cin, env=None):
+    """(tile, target workgroups) of a weight-gradient launch AS SCHEDULED in the training step, from the per-kernel tuner's choice
+    `wt`.  The tuner times kernels alone on an idle chip; in the step the weight gradients run on side streams BESIDE the frame
+    chains, and what counts is the CU time they take away from those chains, not their own duration:
+      * split-K workgroups capped at 512 (the tuner likes ~1024): -0.3 ms per l step although the kernels themselves get ~2 % slower
+        (round 2, tools/gpu_sweep2.sh);
+      * the all-nine-taps kernel on 128 workgroups: it takes ~1.8x as long, the step is 0.6 ms shorter (22.4-22.8 -> 21.8-22.1 ms; 64 /
+        192 / 384 worse — profiles/r04 stage s; re-measured with the <= 256-register variants in round 5, stage q: same optimum);
+      * wherever the layer has a multiple of 64 input channels, the eight-wave variant (64 input channels per workgroup, the dy slab
+        staged once for twice the MFMAs) on 96 workgroups: alone no faster than tile 52 (668 vs 671 TF/s at 256->256 @38x60 x 16), in
+        the step it frees a quarter of the CUs tile 52 held — l 20.77-20.89 vs 20.93-21.00 ms, m 14.43-14.45 vs 14.52-14.56, 4 pairs
+        13.43 vs 13.50, s 7.57 vs 7.59 (profiles/r05 stages zb-zd; 80 / 112 / 128 workgroups: 20.91-21.03, 64 / 256: slower than tile
+        52).  Tile 60 = that variant with the pipelined slab loop: the kernel itself -4 % on these 96 workgroups, the step 20.88-20.89
+        vs 20.94-20.96 ms (stages zf, zg) — the step does not wait for this kernel, it shares the L2 / HBM path with it."""
+    env = os.environ if env is None else env
+    tile, blocks = wt
+    cap = int(env.get("STREAMYOLO_WGRAD_BLOCKS_CAP", "512"))
+    if cap > 0 and blocks > cap:
+        blocks = cap
+    if tile in NINE_TAP_WGRAD_TILES:
+        cap9 = int(env.get("STREAMYOLO_WGRAD9_BLOCKS", "128"))
+        wide9 = int(env.get("STREAMYOLO_WGRAD9_WIDE", "60"))               # 0: off
+        if wide9 and cin % 64 == 0:
+            tile, cap9 = wide9, int(env.get("STREAMYOLO_WGRAD9_WIDE_BLOCKS", "96"))
+        if cap9 > 0 and blocks > cap9:
+            blocks = cap9
+    return (tile, blocks)
+
+
 def _csp_role(tag):
     """'conv2' / 'conv3' for the two CSPLayer convs named <csp>.conv2 / <csp>.conv3 by engine._Builder.csp (the
     Bottleneck convs are <csp>.m.<i>.conv1/2, SPP's are spp.conv1/2)."""
@@ -1041,30 +1073,7 @@ class TrainPlan:
         if wt is None:
             wt = ops.tuned_wgrad(x.dtype, x.N, x.H, x.W, x.C, dyraw.H, dyraw.W, dyraw.C, op.k, op.stride,
                                  self.device, self.wgrad_ws)
-            # split-K workgroups per wgrad launch: the autotuner times kernels alone and likes ~1024, but the wgrads run
-            # BESIDE the main stream's kernels — 512 leaves those their CUs: -0.3 ms per l step although the wgrad
-            # kernels themselves get ~2 % slower (measured, tools/gpu_sweep2.sh)
-            cap = int(os.environ.get("STREAMYOLO_WGRAD_BLOCKS_CAP", "512"))
-            if cap > 0 and wt[1] > cap:
-                wt = (wt[0], cap)
-            # the all-nine-taps kernel runs on a side stream BESIDE the frame chains: what counts is the CU time it takes away from
-            # them, not its own duration.  128 workgroups leave half the CUs to the main chains: the kernel takes ~1.8x as long, the
-            # step is 0.6 ms shorter (22.4-22.8 -> 21.8-22.1 ms; 64 / 192 / 384 worse — profiles/r04 stage s; re-measured with the
-            # <= 256-register variants in round 5, stage q: same optimum)
-            nine = (49, 65, 52, 53, 59, 60)
-            cap9 = int(os.environ.get("STREAMYOLO_WGRAD9_BLOCKS", "128"))
-            # ... and wherever the layer has a multiple of 64 input channels the eight-wave variant (tile 53: 64 input channels per
-            # workgroup, the dy slab staged once for twice the MFMAs) on 96 CUs: alone it is no faster than tile 52 (668 vs 671
-            # TF/s at 256->256 @38x60 x 16), in the step it frees a quarter of the CUs tile 52 held — l 20.77-20.89 vs 20.93-21.00
-            # ms, m 14.43-14.45 vs 14.52-14.56, 4 pairs 13.43 vs 13.50, s 7.57 vs 7.59 (profiles/r05 stages zb-zd; 80 / 112 / 128
-            # workgroups: 20.91-21.03, 64 / 256: slower than tile 52)
-            # Tile 60 = 53 with the pipelined slab loop: the kernel itself -4 % at these 96 workgroups, the step unchanged (20.98-
-            # 21.01 vs 20.94-20.99 ms, stage zf): the step does not wait for this kernel, it shares the L2 / HBM path with it.
-            wide9 = int(os.environ.get("STREAMYOLO_WGRAD9_WIDE", "60"))           # 0: off
-            if wide9 and wt[0] in nine and x.C % 64 == 0:
-                wt, cap9 = (wide9, wt[1]), int(os.environ.get("STREAMYOLO_WGRAD9_WIDE_BLOCKS", "96"))
-            if cap9 > 0 and wt[0] in nine and wt[1] > cap9:
-                wt = (wt[0], cap9)
+            wt = scheduled_wgrad(wt, x.C)
             op._tiles[key] = wt
         if w.shape[1] == x.C:
             ops.conv2d_wgrad(x, dyraw, self.gview[id(w)], op.k, op.stride, oihw=True, workspace=self._ws(),
