@@ -486,8 +486,9 @@ constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (
 // The x fragments of step (k-half, tap) + 2 are read while step (k-half, tap) multiplies (ring of three fragments; reading 4 / 6 steps
 // ahead was measured twice, round 4 and round 5 stage ze: no faster); one slab per rendezvous (two: +0.5-4 % alone, nothing in the
 // step — round 5 stage j); rings of 6 / 8 slabs: no faster (round 4).
-// OCC = 2: at most 256 registers per lane (accumulators included), so that two workgroups — or another chain's waves — share a CU
-// with this kernel; OCC = 1 (tiles 49 / 65, round 2) lets the compiler take the whole file (464 registers: one workgroup owns the CU).
+// Launch bounds: at most 256 registers per lane (accumulators included; the kernel takes ~180), so that two four-wave workgroups — or
+// another chain's waves — share a CU with this kernel.  (Rounds 2-4 ran it without that bound: 464 registers, one workgroup owned
+// the CU — tile codes 49 / 65, no longer instantiated.)
 // CI2 = 2 (round 5): EIGHT waves, 64 input channels per workgroup — wave (cw = w & 3, ch = w >> 2) owns output channels [32 cw, + 32)
 // x input channels [32 ch, + 32) x nine taps.  The dy slab (the larger stream, re-read by every input-channel tile of the layer) is
 // staged once for twice the MFMAs: 21.3 KB of LDS-DMA per 144 MFMAs instead of 14.5 KB per 72 (-27 % L2 -> LDS bytes per MFMA), three
@@ -501,8 +502,8 @@ constexpr int kXSub = 128 * 32 + 128;             // x subtile: 128 pixel rows (
 // it, one piece behind each of the next MFMAs), the first fragments of slab s + 1 are read behind MFMAs 14 / 16 / 17 of slab s, and
 // the fragment ring (18 % 3 == 0) runs on across the slab boundary — every MFMA has two fragment reads and at most one DMA piece or
 // one extra fragment behind it, and no MFMA waits for a barrier.
-template <typename T, int STG, int OCC = 1, int CI2 = 1, int PIPE = 0>
-__global__ __launch_bounds__(kThreadsW * CI2, OCC) void conv_wgrad9_kernel(WgradArgs p) {
+template <typename T, int STG, int CI2 = 1, int PIPE = 0>
+__global__ __launch_bounds__(kThreadsW * CI2, CI2 == 1 ? 2 : 1) void conv_wgrad9_kernel(WgradArgs p) {
     SY_TL_BEGIN(6);
     constexpr int CT = 128, CIT = 32 * CI2;
     constexpr int SB = CT / 16;                   // dy subtiles per slab
@@ -861,7 +862,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
-template <typename T, int STG, int OCC = 1, int CI2 = 1, int PIPE = 0>
+template <typename T, int STG, int CI2 = 1, int PIPE = 0>
 int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
     if constexpr (T::kEPC != 8) {
         return SY_ERR_UNSUPPORTED;
@@ -886,12 +887,12 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 #ifndef SY_EMU
         static bool attr_done = false;
         if (!attr_done) {
-            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, OCC, CI2, PIPE>;
+            const void* fn = (const void*)conv_wgrad9_kernel<T, STG, CI2, PIPE>;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
             attr_done = true;
         }
 #endif
-        SY_LAUNCH((conv_wgrad9_kernel<T, STG, OCC, CI2, PIPE>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
+        SY_LAUNCH((conv_wgrad9_kernel<T, STG, CI2, PIPE>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
         if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
@@ -900,12 +901,11 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 
 template <typename T>
 int launch_wgrad_typed(const WgradArgs& a, long long ws_bytes, void* stream) {
-    if (a.tile == 49) return launch_wgrad9<T, 3>(a, ws_bytes, stream);     // 3x3 stride 1: all nine taps per workgroup, halo in LDS
-    if (a.tile == 65) return launch_wgrad9<T, 4>(a, ws_bytes, stream);
-    if (a.tile == 52) return launch_wgrad9<T, 3, 2>(a, ws_bytes, stream);        // tile 49 in <= 256 registers (two workgroups per CU)
-    if (a.tile == 53) return launch_wgrad9<T, 3, 1, 2>(a, ws_bytes, stream);     // eight waves, 64 input channels per workgroup
-    if (a.tile == 59) return launch_wgrad9<T, 4, 2, 1, 1>(a, ws_bytes, stream);  // one instruction stream (PIPE): tile 52 ...
-    if (a.tile == 60) return launch_wgrad9<T, 4, 1, 2, 1>(a, ws_bytes, stream);  // ... tile 53
+    if (a.tile == 52) return launch_wgrad9<T, 3>(a, ws_bytes, stream);        // 3x3 stride 1: all nine taps per workgroup, halo in LDS
+    if (a.tile == 59) return launch_wgrad9<T, 4, 1, 1>(a, ws_bytes, stream);  // ... the slab loop as one instruction stream (PIPE)
+    if (a.tile == 60) return launch_wgrad9<T, 4, 2, 1>(a, ws_bytes, stream);  // ... on eight waves, 64 input channels per workgroup
+    // (49 / 65: tile 52 without the register bound; 53: tile 60 without PIPE — measured references of rounds 2-5, never the tuner's
+    //  choice any more, not instantiated)
     switch (a.tile) {          // (k rows x output channels) per workgroup
         case 1: return launch_wgrad_cfg<T, 2, 2, 2, 2>(a, ws_bytes, stream);   // 128 x 128
         case 2: return launch_wgrad_cfg<T, 4, 1, 1, 2>(a, ws_bytes, stream);   // 128 x  64

@@ -797,17 +797,14 @@ _WGRAD_CANDIDATES = [(0, 0), (1, 1024), (2, 512), (4, 1024), (17, 512), (17, 102
                      (20, 1024), (22, 1024), (21, 1024),
                      (17, 256), (33, 256), (18, 256),
                      # 3x3 stride 1: all nine taps per workgroup (conv_wgrad9_kernel); few splits: the split-K slabs + fold are a
-                     # third of its time at 1024 workgroups (profiles/r02/f_wgrad_probe.txt)
-                     (49, 128), (49, 256), (49, 512), (65, 256), (65, 512),
-                     # round 5: the same kernel compiled for <= 256 registers per lane (52): as fast alone (665 vs 648 TF/s at 256->256
-                     # @38x60 x 16) and it no longer owns the CUs it runs on — the l step 21.37-21.44 vs 21.53-21.56 ms with the same
-                     # 128-workgroup cap (profiles/r05 stages j, q)
+                     # third of its time at 1024 workgroups (profiles/r02/f_wgrad_probe.txt).  52: four waves x 32 input channels in
+                     # <= 256 registers per lane (rounds 2-4 ran it unbounded — 464 registers, one workgroup owned its CU; round 5
+                     # stages j, q: as fast alone, the l step 21.37-21.44 vs 21.53-21.56 ms)
                      (52, 128), (52, 256),
-                     # eight waves, 64 input channels per workgroup (Cin % 64 == 0): -27 % L2 -> LDS bytes per MFMA; alone +8 % at the
-                     # stride-8 head / 64-channel layers, else level with 52 — the training plan prefers it in the step (train_engine.py)
-                     (53, 128), (53, 256),
-                     # 52 / 53 with the slab loop as one instruction stream (rendezvous, DMA issue and the next slab's first fragments
-                     # behind MFMAs): +10-16 % on 128 workgroups, +2-5 % on 256 (profiles/r05 stage zf)
+                     # 59 / 60: the slab loop as one instruction stream (rendezvous, DMA issue and the next slab's first fragments
+                     # behind MFMAs): +10-16 % on 128 workgroups, +2-5 % on 256 (profiles/r05 stage zf); 60: eight waves, 64 input
+                     # channels per workgroup (Cin % 64 == 0; -27 % L2 -> LDS bytes per MFMA) — the tile the training plan schedules
+                     # (train_engine.scheduled_wgrad)
                      (59, 128), (59, 256), (60, 128), (60, 256)]
 # further candidates for A/B runs, "tile:blocks,tile:blocks"; part
 # of the tuner-cache key, so such a run tunes by itself
@@ -830,8 +827,8 @@ def tuned_wgrad(dtype, N, H, W, Cin, Ho, Wo, Cout, k, stride, device, workspace)
     dw = torch.zeros((Cout, Cin, k, k), dtype=torch.float32, device=device)
     best, best_t = (0, 0), float("inf")
     for (t, tb) in _WGRAD_CANDIDATES + WGRAD_EXTRA:
-        if t in (49, 65, 52, 53, 59, 60):
-            if k != 3 or stride != 1 or Cin % (64 if t in (53, 60) else 32) or Cout % 16:
+        if t in (52, 59, 60):
+            if k != 3 or stride != 1 or Cin % (64 if t == 60 else 32) or Cout % 16:
                 continue
         elif (t & 15) in (1, 5, 6) and Cout < 128:
             continue

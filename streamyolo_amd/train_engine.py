@@ -265,7 +265,7 @@ WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD
 # a low hardware queue priority: 22.78-22.79 vs 22.70 ms — profiles/r04/b_bench_ownw*.json — removed.)
 
 
-NINE_TAP_WGRAD_TILES = (49, 65, 52, 53, 59, 60)     # conv_wgrad9_kernel (csrc/conv_wgrad.hip)
+NINE_TAP_WGRAD_TILES = (52, 59, 60)     # conv_wgrad9_kernel (csrc/conv_wgrad.hip)
 
 
 def scheduled_wgrad(wt, cin, env=None):

@@ -21,7 +21,7 @@ def test_nine_tap_kernel_is_confined_and_widened():
 def test_switches():
     env = {"STREAMYOLO_WGRAD9_WIDE": "0"}
     assert scheduled_wgrad((59, 256), 256, env=env) == (59, 128)
-    env = {"STREAMYOLO_WGRAD9_WIDE": "53", "STREAMYOLO_WGRAD9_WIDE_BLOCKS": "112"}
-    assert scheduled_wgrad((52, 256), 512, env=env) == (53, 112)
+    env = {"STREAMYOLO_WGRAD9_WIDE_BLOCKS": "112"}
+    assert scheduled_wgrad((52, 256), 512, env=env) == (60, 112)
     env = {"STREAMYOLO_WGRAD9_WIDE": "0", "STREAMYOLO_WGRAD9_BLOCKS": "0"}
     assert scheduled_wgrad((52, 256), 512, env=env) == (52, 256)

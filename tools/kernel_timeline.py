@@ -7,7 +7,7 @@ Every workgroup's thread 0 stamps the device's 100 MHz clock at fixed points (sy
 loads issued, 2 first operands landed (after the wait + barrier), 3 main loop done, 4 epilogue: tile converted / statistics
 reduced, 5 output rows written (issued), 6 exit.  Printed: when workgroups start and end relative to the first start (the launch's
 dispatch ramp and tail), and the median / p90 duration of each phase — where a latency-bound kernel spends its life.
-kinds: conv (tools/conv_probe.py's SHAPES table; --mode fwd | stats | dgrad), wgrad (3x3 layers: tile 49 / 65), bnred (BatchNorm
+kinds: conv (tools/conv_probe.py's SHAPES table; --mode fwd | stats | dgrad), wgrad (3x3 layers: tile 52 / 59 / 60), bnred (BatchNorm
 backward reduce on the layer's output tensor)."""
 import argparse
 import ctypes as C

@@ -82,7 +82,7 @@ def apply(group, slot, value):
 
 
 HALO = [117, 118, 107, 104, 101, 100, 98, 109]        # second / third generation of the 128-channel window tiles
-WG3 = [(49, 128), (65, 128), (52, 128), (52, 96), (59, 128), (59, 96), (53, 96), (60, 96), (60, 128), (17, 256), (17, 512), (18, 256), (18, 512), (33, 256), (33, 512)]
+WG3 = [(52, 128), (52, 96), (59, 128), (59, 96), (60, 96), (60, 128), (17, 256), (17, 512), (18, 256), (18, 512), (33, 256), (33, 512)]
 WG1 = [(17, 256), (17, 512), (18, 256), (18, 512), (33, 256), (33, 512)]
 convs = [op for op in plan.ops if op.kind == "conv"]
 groups = {}                                                              # (slot, shape...) -> [ops]
@@ -103,7 +103,7 @@ for sig, group in sorted(groups.items(), key=lambda kv: -len(kv[1]) * kv[0][1] *
     if slot.startswith("wgrad"):
         cands = [c for c in (WG3 if (k == 3 and stride == 1) else WG1) if c != tuple(cur)]
         # the per-kernel tuner's own applicability rules (ops.tuned_wgrad)
-        cands = [c for c in cands if not (c[0] in (49, 65, 52, 53, 59, 60) and (cin % 32 or cout % 16)) and not (c[0] in (53, 60) and cin % 64) and not ((c[0] & 15) == 1 and c[0] < 49 and cout < 128)
+        cands = [c for c in cands if not (c[0] in (52, 59, 60) and (cin % 32 or cout % 16)) and not (c[0] == 60 and cin % 64) and not ((c[0] & 15) == 1 and c[0] < 49 and cout < 128)
                  and not ((c[0] & 15) == 2 and cout < 64)]
     elif k == 3 and stride == 1 and int(cur) in HALO and cin % 32 == 0:
         cands = [t for t in HALO if t != int(cur)]

@@ -38,7 +38,7 @@ def main():
         flops = 2.0 * cin * cout * k * k * dy.pixels
         res = []
         for (t, tb) in variants:
-            if (t & 255) in (49, 65, 52, 53, 59, 60) and (k != 3 or st != 1 or cin % (64 if (t & 255) in (53, 60) else 32)):
+            if (t & 255) in (52, 59, 60) and (k != 3 or st != 1 or cin % (64 if (t & 255) == 60 else 32)):
                 res.append(float("nan")); continue
             if (t & 255) < 48 and (t & 15) in (1, 5, 6) and cout < 128 and t != 0:
                 res.append(float("nan")); continue
