@@ -139,7 +139,14 @@ typedef struct sy_wgrad_desc {
     int32_t dw_oihw;
     void* workspace;                    /* optional fp32 scratch for split-K slabs (NULL: one split) */
     int64_t workspace_bytes;
-    int32_t tile, target_blocks;        /* tuning knobs (0 = heuristic): workgroup tile, workgroups aimed for by split-K */
+    int32_t tile, target_blocks;        /* tuning knobs (0 = heuristic): workgroup tile, workgroups aimed for by split-K.
+                                         * tile: 1-6 = (k rows x output channels) per workgroup, operands transposed into LDS by
+                                         * scatter stores; +16 / +32 = the same tiles with both operands parked in LDS as they lie in
+                                         * HBM (LDS-DMA ring of 3 / 4 slabs) and gathered by ds_read_b64_tr_b16; 3x3 stride-1, 16-bit,
+                                         * Cin % 32 == 0, Cout % 16 == 0 only: 52 = all nine taps per workgroup (x halo window in LDS),
+                                         * 59 = 52 with the slab loop as one instruction stream, 60 = 59 on eight waves with 64 input
+                                         * channels per workgroup (Cin % 64 == 0).  52 / 59 / 60 on a layer they do not cover:
+                                         * SY_ERR_UNSUPPORTED; any other unknown code: the heuristic tile. */
     int64_t x_bytes, dy_bytes;          /* bytes addressable from x / dy (buffer bounds; 0 = unknown) */
 } sy_wgrad_desc;
 SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
