@@ -53,6 +53,13 @@ BNR_TILES = (98, 100, 101, 109, 104, 107, 117, 118)     # data-gradient tiles wh
 # replica counts of the speed modes (A/B switch)
 EXACT_STATS = __import__("os").environ.get("STREAMYOLO_EXACT_STATS", "1") != "0"
 _BN_REDUCE_BLOCKS = int(__import__("os").environ.get("SY_BN_REDUCE_BLOCKS", "768"))   # csrc/train_ops.hip: cap_reduce
+# The workgroup cap of the BatchNorm-backward APPLY pass AS SCHEDULED in the step: the library's own default (1024, read once from the
+# environment by csrc/train_ops.hip's env_cap) is that kernel's optimum from round 2; beside round 5's frame chains and weight-gradient
+# streams fewer, fatter workgroups leave the MFMA kernels their CUs: 512 -> l step 20.83-20.88 vs 21.01-21.03 ms and 20.92 vs 21.00-
+# 21.14 on another box (256: 21.40-21.44; the forward apply / backward reduce caps: 1024 / 512 instead of 2048 / 768 nothing on top —
+# profiles/r05 stages zm, zn).  The pass is a grid-stride map over pixel rows (channel sums written by workgroup 0): its results do
+# not depend on the grid.  An explicit SY_BN_BAPPLY_BLOCKS wins.
+__import__("os").environ.setdefault("SY_BN_BAPPLY_BLOCKS", "512")
 # Measured and REMOVED in round 4 (profiles/r04/README.md): BatchNorm finalisation by the producing convolution's last workgroup
 # (every statistics launch got 8-13 us slower — each workgroup waits for its own atomics and a ticket round trip — the l step
 # 22.6-23.9 vs 22.3-23.0 ms at 2 ... 32 replicas) and BatchNorm backward as one resident launch whose workgroups wait for each
