@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 6
+#define SY_ABI_VERSION 7
 #define SY_API __attribute__((visibility("default")))
 
 enum { SY_DT_BF16 = 0, SY_DT_F16 = 1, SY_DT_F32 = 2 };
@@ -148,6 +148,13 @@ typedef struct sy_wgrad_desc {
                                          * channels per workgroup (Cin % 64 == 0).  52 / 59 / 60 on a layer they do not cover:
                                          * SY_ERR_UNSUPPORTED; any other unknown code: the heuristic tile. */
     int64_t x_bytes, dy_bytes;          /* bytes addressable from x / dy (buffer bounds; 0 = unknown) */
+    uint32_t* tickets;                  /* optional (ABI 7): >= tickets_count zero-initialised arrival counters.  With them a split-K launch
+                                         * folds its partial slabs ITSELF — the last workgroup of an output tile to publish its slab
+                                         * (agent-scope release -> ticket -> acquire) adds the tile's slabs in split order into dw and
+                                         * resets the ticket — instead of a second (wgrad_fold) launch; still deterministic, no float
+                                         * atomics.  NULL, or more output tiles than tickets_count: the separate fold launch.  One array
+                                         * per stream that runs weight gradients concurrently. */
+    int32_t tickets_count, reserved;
 } sy_wgrad_desc;
 SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
 
@@ -287,6 +294,8 @@ typedef struct sy_bn_running_entry {
     int32_t ld;                 /* elements between consecutive replicas (0 = C): > C when the module's channels are a slice of a
                                    wider statistics array (sibling convolutions stacked into one launch) */
     int32_t reserved;
+    int64_t* num_batches_tracked; /* NULL, or the module's counter: += calls (nn.BatchNorm2d increments it once per training-mode
+                                   forward; the shared backbone / neck modules are called once per frame) — ABI 7 */
 } sy_bn_running_entry;
 SY_API int sy_bn_running_update(const sy_bn_running_entry* entries, int n_entries, int max_C, void* stream);
 /* sy_bn_finalize + sy_bn_silu_apply in one launch (the training forward of every BaseConv: nn.BatchNorm2d in training mode
@@ -342,6 +351,18 @@ SY_API int sy_tal_loss(const float* raw, int B, int A, int num_classes, const fl
  * get_assignments returns the same pair for the foreground anchors (exps/model/tal_head.py:559-600); diagnostics and parity tests. */
 SY_API int sy_tal_loss_assignment(const void* workspace, int B, int A, int max_labels, int32_t* matched_gt,
                                   float* matched_iou, void* stream);
+
+/* Workgroup caps of the BatchNorm row kernels (grid-stride maps over pixel rows: results do not depend on them, except that the
+ * backward reduce's cap is the number of replica rows the exact mode sizes its sums for): caps4 = {sy_bn_silu_apply,
+ * sy_bn_finalize_apply, sy_bn_silu_bwd_reduce, sy_bn_silu_bwd_apply}.  set4 (may be NULL): entries > 0 replace the cap, others keep
+ * it; get4 (may be NULL) receives the caps in force afterwards.  Process-wide; defaults 2048 / 2048 / 768 / 1024 (or SY_BN_*_BLOCKS
+ * in the environment, read at first use).  Takes no stream: nothing is launched (ABI 7; replaces an import-time environment write). */
+SY_API int sy_bn_grid_caps(const int32_t* set4, int32_t* get4);
+
+/* Zero fill of rows x row_bytes bytes at pitch_bytes (all multiples of 4; rows == 1: one dense run): the clears of a training
+ * step — statistics / gradient arenas, the not-yet-written channel ranges of a gradient buffer before an accumulating data
+ * gradient (autograd's zero-initialised .grad accumulation) — as launches of the plan's own tape instead of ATen fills (ABI 7). */
+SY_API int sy_zero_rows(void* ptr, int64_t rows, int64_t row_bytes, int64_t pitch_bytes, void* stream);
 
 /* elementwise helpers on views: out (+)= in */
 SY_API int sy_view_copy(const void* in, int ldi, void* out, int ldo, int64_t pixels, int C, int dtype,

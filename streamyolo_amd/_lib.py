@@ -18,7 +18,7 @@ DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 EPI_LINEAR, EPI_SILU, EPI_SIGMOID, EPI_DECODE, EPI_BNR = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 
-ABI_VERSION = 6          # SY_ABI_VERSION of include/streamyolo_hip.h this binding was written against
+ABI_VERSION = 7          # SY_ABI_VERSION of include/streamyolo_hip.h this binding was written against
 _ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape"}
 SY_ERR_UNSUPPORTED = 3
 
@@ -47,7 +47,8 @@ class BnRunningEntry(C.Structure):
     """sy_bn_running_entry (include/streamyolo_hip.h)."""
     _fields_ = [("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("sum", C.c_void_p * 2),
                 ("sqsum", C.c_void_p * 2), ("count", C.c_double * 2), ("C", C.c_int32), ("copies", C.c_int32),
-                ("calls", C.c_int32), ("momentum", C.c_float), ("ld", C.c_int32), ("reserved", C.c_int32)]
+                ("calls", C.c_int32), ("momentum", C.c_float), ("ld", C.c_int32), ("reserved", C.c_int32),
+                ("num_batches_tracked", C.c_void_p)]
 
 
 class PackEntry(C.Structure):
@@ -81,6 +82,7 @@ class WgradDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("ldx", C.c_int32), ("lddy", C.c_int32), ("xbs", C.c_int64), ("dybs", C.c_int64),
         ("dtype", C.c_int32), ("dw_oihw", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("tile", C.c_int32), ("target_blocks", C.c_int32), ("x_bytes", C.c_int64), ("dy_bytes", C.c_int64),
+        ("tickets", C.c_void_p), ("tickets_count", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -112,6 +114,8 @@ SIGNATURES = {
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _I, _P]),
     "sy_tal_loss_assignment": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "sy_zero_rows": (_I, [_P, _L, _L, _L, _P]),
+    "sy_bn_grid_caps": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sy_view_copy": (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_splitk_epilogue": (_I, [_P, _I, _L, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sy_rows_add_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
@@ -180,7 +184,7 @@ class _TapeProxy:
     def __getattr__(self, name):
         fn = getattr(self.real, name)
         tape = self.tape
-        if name.endswith("_supported") or name.endswith("_bytes") or name.endswith("_floats") or name.endswith("version") or name.startswith("sy_tape_"):
+        if name.endswith("_supported") or name.endswith("_bytes") or name.endswith("_floats") or name.endswith("version") or name.endswith("_caps") or name.startswith("sy_tape_"):
             return fn                                           # queries: no stream argument, nothing to replay
 
         def call(*args):

@@ -242,11 +242,11 @@ int launch_bottleneck_fused_nw(const ConvArgs& a_in, void* stream) {
         const int tiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + 31) / 32);
         dim3 grid((a.Cout + CT - 1) / CT, tiles, 1);
 #ifndef SY_EMU
-        static bool attr_done = false;
-        if (!attr_done) {
+        static sy_dev_once attr_done;
+        if (attr_done.need()) {
             if (hipFuncSetAttribute((const void*)bottleneck_fused_kernel<T, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
                 return SY_ERR_LAUNCH;
-            attr_done = true;
+            attr_done.mark();
         }
 #endif
         SY_LAUNCH((bottleneck_fused_kernel<T, NW>), grid, dim3(NW * 64), smem, stream, a);

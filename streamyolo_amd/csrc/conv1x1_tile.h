@@ -174,12 +174,12 @@ int launch_1x1_tile_ns(const ConvArgs& a_in, void* stream) {
     constexpr size_t smem_s = (size_t)WP * CT * 8;
     constexpr size_t smem = (smem_e <= 48 * 1024 && smem_e > smem_k) ? smem_e : (smem_s > smem_k ? smem_s : smem_k);
 #ifndef SY_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static sy_dev_once attr_done;
+    if (attr_done.need()) {
         if (hipFuncSetAttribute((const void*)conv1x1_tile_kernel<T, WC, WP, TC, TP, NS, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
-        attr_done = true;
+        attr_done.mark();
     }
 #endif
     SY_LAUNCH((conv1x1_tile_kernel<T, WC, WP, TC, TP, NS, NCH>), grid, dim3(WC * WP * 64), smem, stream, a);

@@ -429,13 +429,13 @@ int launch_halo(const ConvArgs& a_in, void* stream) {
     if (a.ksplit > 1 && (GEN != 2 || KS > 1 || a.ksplit > a.Cin / (4 * T::kEPC))) return SY_ERR_UNSUPPORTED;
     dim3 grid((a.Cout + CT - 1) / CT, tiles, a.ksplit > 1 ? a.ksplit : 1);
 #ifndef SY_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static sy_dev_once attr_done;
+    if (attr_done.need()) {
         const void* fn;                                        // (if constexpr: only the generation this tile code launches is instantiated)
         if constexpr (GEN == 2) fn = (const void*)conv3x3_halo2_kernel<T, WC, WP, TC, TP, S2, KS>;
         else fn = (const void*)conv3x3_halo_kernel<T, WC, WP, TC, TP>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return SY_ERR_LAUNCH;
-        attr_done = true;
+        attr_done.mark();
     }
 #endif
     if constexpr (GEN == 2) {

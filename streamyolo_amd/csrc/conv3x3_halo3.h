@@ -247,12 +247,12 @@ int launch_halo3(const ConvArgs& a_in, void* stream) {
     dim3 grid((a.Cout + CT - 1) / CT, tiles, 1);
     const bool dgrad = a.mode == SY_CONV_DGRAD;
 #ifndef SY_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static sy_dev_once attr_done;
+    if (attr_done.need()) {
         if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 0, BD, ILV, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<T, TP, 1, BD, ILV, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
-        attr_done = true;
+        attr_done.mark();
     }
 #endif
     if (dgrad) { SY_LAUNCH((conv3x3_halo3_kernel<T, TP, 1, BD, ILV, WC>), grid, dim3(NW * 64), smem, stream, a); }

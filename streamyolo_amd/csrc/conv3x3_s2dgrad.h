@@ -201,12 +201,12 @@ int launch_s2dgrad(const ConvArgs& a_in, void* stream) {
     const int tiles = a.N * ((((a.Ho + 1) >> 1) + TH - 1) / TH) * ((((a.Wo + 1) >> 1) + 31) / 32);
     dim3 grid((a.Cout + CT - 1) / CT, tiles, 4);
 #ifndef SY_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static sy_dev_once attr_done;
+    if (attr_done.need()) {
         if (hipFuncSetAttribute((const void*)conv3x3_s2dgrad_kernel<T, WC, WP, TC, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess)
             return SY_ERR_LAUNCH;
-        attr_done = true;
+        attr_done.mark();
     }
 #endif
     SY_LAUNCH((conv3x3_s2dgrad_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), smem, stream, a);

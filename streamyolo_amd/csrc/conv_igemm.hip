@@ -25,6 +25,11 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
         const int t = d->tile & 0xff;       // the staged epilogue of the 128-channel 3x3 stride-1 window tiles carries it
         if (t != 98 && t != 100 && t != 101 && t != 109 && t != 104 && t != 107 && t != 117 && t != 118) return SY_ERR_UNSUPPORTED;
         if (d->KH != 3 || d->stride != 1 || (d->ldy & 7) != 0 || (d->Cout & 7) != 0) return SY_ERR_UNSUPPORTED;
+        // the reduce exists ONLY in the staged write-out of conv_epilogue (16-byte stores of y, uint4 loads of z): its run-time
+        // preconditions are checked here, because the general epilogue loop has no BNR case and would treat scale / shift / res as
+        // an affine + residual of the gradient with no sums accumulated — a silently wrong gradient through a public entry point
+        // (ADVICE r05): 16-byte aligned y and z, batch strides that keep every pixel row aligned
+        if ((((uintptr_t)d->y | (uintptr_t)d->res) & 15) != 0 || (d->ybs & 7) != 0) return SY_ERR_UNSUPPORTED;
     }
     if ((long long)d->N * d->Ho * d->Wo > 0x7fffffffLL) return SY_ERR_UNSUPPORTED;
     ConvArgs a;

@@ -988,12 +988,12 @@ int launch_one(const ConvArgs& a, void* stream) {
     constexpr size_t smem_e = (size_t)EpiLds<WP, CT>::kStatBytes + (size_t)PT * (CT * 2 + 16) + (size_t)PT * 8;
     constexpr size_t smem = (T::kEPC == 8 && smem_e <= 48 * 1024 && smem_e > smem_k) ? smem_e : smem_k;
 #ifndef SY_EMU
-    static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
-    if (!attr_done) {
+    static sy_dev_once attr_done;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
+    if (attr_done.need()) {
         if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return SY_ERR_LAUNCH;
-        attr_done = true;
+        attr_done.mark();
     }
 #endif
     SY_LAUNCH((conv_igemm_kernel<T, WC, WP, TC, TP, STG, FAST>), grid, dim3(WC * WP * 64), smem, stream, a);

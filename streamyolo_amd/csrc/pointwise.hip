@@ -135,7 +135,40 @@ __global__ __launch_bounds__(kBlock) void view_copy_kernel(const typename T::ele
     }
 }
 
+// ---- zero fill of a (strided) byte region: the plan's clears as launches of its own tape (no ATen fill kernels in a step) ----
+// rows x row_bytes bytes at pitch_bytes; everything a multiple of 4 bytes (16-byte stores where pointer, row and pitch allow).
+template <typename V>
+__global__ __launch_bounds__(kBlock) void zero_rows_kernel(V* p, long long rows, long long row_v, long long pitch_v) {
+    const long long total = rows * row_v;
+    V z;
+    __builtin_memset(&z, 0, sizeof(V));
+    if (row_v == pitch_v) {
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) p[i] = z;
+    } else {
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+            const long long r = i / row_v;
+            p[r * pitch_v + (i - r * row_v)] = z;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int sy_zero_rows(void* ptr, int64_t rows, int64_t row_bytes, int64_t pitch_bytes, void* stream) {
+    if (ptr == nullptr || rows < 0 || row_bytes < 0 || (rows > 1 && pitch_bytes < row_bytes)) return SY_ERR_ARG;
+    if (rows == 0 || row_bytes == 0) return SY_OK;
+    if (rows == 1) pitch_bytes = row_bytes;
+    const unsigned long long a = (unsigned long long)ptr | (unsigned long long)row_bytes | (unsigned long long)pitch_bytes;
+    if (a & 3) return SY_ERR_UNSUPPORTED;
+    if ((a & 15) == 0) {
+        SY_LAUNCH((zero_rows_kernel<uint4>), dim3(grid_for(rows * (row_bytes / 16))), dim3(kBlock), 0, stream, (uint4*)ptr,
+                  (long long)rows, (long long)(row_bytes / 16), (long long)(pitch_bytes / 16));
+    } else {
+        SY_LAUNCH((zero_rows_kernel<unsigned>), dim3(grid_for(rows * (row_bytes / 4))), dim3(kBlock), 0, stream, (unsigned*)ptr,
+                  (long long)rows, (long long)(row_bytes / 4), (long long)(pitch_bytes / 4));
+    }
+    return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
+}
 
 extern "C" int sy_focus_pack(const float* in, int N, int Ctot, int c0, int H, int W, void* out, int dtype, void* stream) {
     if (in == nullptr || out == nullptr || N <= 0 || (H & 1) || (W & 1) || c0 < 0 || c0 + 3 > Ctot) return SY_ERR_ARG;

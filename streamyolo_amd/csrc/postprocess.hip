@@ -327,11 +327,11 @@ extern "C" int sy_postprocess(const float* pred, int B, int A, int num_classes, 
     PostLayout L = make_layout(A);
     const size_t rank_smem = (size_t)sort_n * 8 + 128;
 #ifndef SY_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static sy_dev_once attr_done;
+    if (attr_done.need()) {
         if (hipFuncSetAttribute((const void*)nms_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + 128) != hipSuccess)
             return SY_ERR_LAUNCH;
-        attr_done = true;
+        attr_done.mark();
     }
 #endif
     SY_LAUNCH(nms_rank_kernel, dim3(B), dim3(kRankThreads), rank_smem, stream, pred, A, num_classes, conf_thre,

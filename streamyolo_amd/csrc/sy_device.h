@@ -49,6 +49,26 @@
 #endif
 
 #include <stdint.h>
+#include <atomic>
+
+// "done once" flag of a per-kernel host-side setting (hipFuncSetAttribute: the opt-in for > 64 KiB of dynamic LDS) — PER DEVICE: one
+// process may drive several GPUs, and the attribute set on one is not set on the others (a process-wide `static bool`
+// left the second device's launches of the 102 KB tiles failing with SY_ERR_LAUNCH).  Threads may race: the call is idempotent.
+inline int& sy_dev_once_current() { static thread_local int d = -1; return d; }      // device seen by this thread's last need()
+struct sy_dev_once {
+    std::atomic<unsigned long long> mask{0ull};
+    bool need() {
+#ifdef SY_EMU
+        return false;
+#else
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) { sy_dev_once_current() = -1; return true; }   // unknown device: set it every time
+        sy_dev_once_current() = d;
+        return ((mask.load(std::memory_order_relaxed) >> d) & 1ull) == 0ull;
+#endif
+    }
+    void mark() { const int d = sy_dev_once_current(); if (d >= 0) mask.fetch_or(1ull << d, std::memory_order_relaxed); }
+};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -266,6 +286,28 @@ __device__ __forceinline__ void sy_glds16_buf_at(const sy_buffer& b, unsigned vo
     // M0 as a register-constrained input: the compiler loads it (and knows it is live), no save / restore around the DMA
     asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(b), "{m0}"(dst) : "memory");
 }
+#endif
+
+// ---- cross-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16, counter form) ------------------------------
+// Producer: plain stores -> every wave sy_wait_vmcnt<0>() -> __syncthreads() -> ONE lane: sy_release_agent() (buffer_wbl2 sc1; the
+// asm wait behind it restates the post-write-back wait where the compiler cannot drop it) -> sy_ticket_take().  The workgroup that
+// draws the last ticket: sy_acquire_agent() on that lane (buffer_inv sc1: this CU's stale L1 lines) -> __syncthreads() -> plain
+// loads of what the others published.  Nobody waits for anybody (no residency requirement): whoever arrives last does the work.
+#ifdef SY_EMU
+static inline void sy_release_agent() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline void sy_acquire_agent() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline unsigned sy_ticket_take(unsigned* p) { return reinterpret_cast<std::atomic<unsigned>*>(p)->fetch_add(1u); }
+static inline void sy_ticket_reset(unsigned* p) { reinterpret_cast<std::atomic<unsigned>*>(p)->store(0u); }
+#else
+__device__ __forceinline__ void sy_release_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void sy_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ unsigned sy_ticket_take(unsigned* p) {
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sy_ticket_reset(unsigned* p) { __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 // Wave-level ordering point for wave-PRIVATE LDS hand-offs (one lane writes, another lane of the same wave reads): the

@@ -415,6 +415,7 @@ __global__ __launch_bounds__(kBlock) void bn_running_update_kernel(const sy_bn_r
         __syncthreads();
     }
     if (rg == 0 && c < e.C) { e.running_mean[c] = rm; e.running_var[c] = rv; }
+    if (blockIdx.y == 0 && threadIdx.x == 0 && e.num_batches_tracked != nullptr) *e.num_batches_tracked += e.calls;
     SY_TL_END();
 }
 
@@ -677,7 +678,8 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
     __syncthreads();
     if (dres_acc & 4) {                                 // row 1 holds the RAW moment sum dz*y (a data gradient's fused reduce,
         for (int c = threadIdx.x; c < C; c += kBlock)   // SY_EPI_BNR): sum dz*xhat = invstd * (sum dz*y - mean * sum dz)
-            s_fold[C + c] = invstd[c] * (s_fold[C + c] - mean[c] * s_fold[c]);
+            // in double: for a channel with |mean| >> std the fp32 difference cancels catastrophically
+            s_fold[C + c] = (float)((double)invstd[c] * ((double)s_fold[C + c] - (double)mean[c] * (double)s_fold[c]));
         __syncthreads();
     }
     if (blockIdx.x == 0 && dgamma != nullptr) {
@@ -755,6 +757,14 @@ inline int env_cap(const char* name, int dflt) {          // tuning knob (tools/
     return (v != nullptr && atoi(v) > 0) ? atoi(v) : dflt;
 }
 
+// workgroup caps of the four row kernels (sy_bn_grid_caps): environment defaults read once, then explicit values
+enum { kCapApply = 0, kCapFApply = 1, kCapReduce = 2, kCapBApply = 3 };
+inline std::atomic<int>& bn_cap(int which) {
+    static std::atomic<int> caps[4] = {{env_cap("SY_BN_APPLY_BLOCKS", 2048)}, {env_cap("SY_BN_FAPPLY_BLOCKS", 2048)},
+                                       {env_cap("SY_BN_REDUCE_BLOCKS", 768)}, {env_cap("SY_BN_BAPPLY_BLOCKS", 1024)}};
+    return caps[which];
+}
+
 inline int row_grid(long long pixels, int C, int e, int cap) {
     const int rows = kBlock / (C / e);
     long long b = (pixels + rows - 1) / rows;
@@ -770,16 +780,24 @@ inline bool spp_lds_ok(const void* fn, int slot) {           // slot = kernel (0
 #ifdef SY_EMU
     return true;
 #else
-    static bool done[6] = {false, false, false, false, false, false};
-    if (!done[slot]) {
+    static sy_dev_once done[6];
+    if (done[slot].need()) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppTileLds) != hipSuccess) return false;
-        done[slot] = true;
+        done[slot].mark();
     }
     return true;
 #endif
 }
 
 }  // namespace
+
+extern "C" int sy_bn_grid_caps(const int32_t* set4, int32_t* get4) {
+    for (int k = 0; k < 4; ++k) {
+        if (set4 != nullptr && set4[k] > 0) bn_cap(k).store(set4[k], std::memory_order_relaxed);
+        if (get4 != nullptr) get4[k] = bn_cap(k).load(std::memory_order_relaxed);
+    }
+    return SY_OK;
+}
 
 extern "C" int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs, void* argmax, int dtype,
                            void* stream) {
@@ -845,7 +863,7 @@ extern "C" int sy_bn_silu_apply(const void* y, int ldy, const float* scale, cons
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldo % e || (res != nullptr && ldr % e)) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    static const int cap_apply = env_cap("SY_BN_APPLY_BLOCKS", 2048);
+    const int cap_apply = bn_cap(kCapApply).load(std::memory_order_relaxed);
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_apply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, scale, shift, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C));
@@ -867,7 +885,7 @@ extern "C" int sy_bn_finalize_apply(const float* sum, const float* sqsum, int co
         if (c <= C && C % c == 0) { CS = c; break; }
     if (CS > 64) return SY_ERR_UNSUPPORTED;
     const int nsl = C / CS;
-    static const int cap_fa = env_cap("SY_BN_FAPPLY_BLOCKS", 2048);
+    const int cap_fa = bn_cap(kCapFApply).load(std::memory_order_relaxed);
     int cap = cap_fa / (nseg * nsl);
     if (cap < 1) cap = 1;
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_finalize_apply_kernel<T>), dim3(row_grid(pixels, CS, e, cap), nseg, nsl), dim3(kBlock), 0,
@@ -883,7 +901,7 @@ extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int
     const int e = epc_of(dtype);
     if (C % e || ldy % e || ldda % e) return SY_ERR_UNSUPPORTED;
     if (!chunk_rows_ok(C, e)) return SY_ERR_UNSUPPORTED;
-    static const int cap_reduce = env_cap("SY_BN_REDUCE_BLOCKS", 768);
+    const int cap_reduce = bn_cap(kCapReduce).load(std::memory_order_relaxed);
     static const int slice_max = env_cap("SY_BN_REDUCE_SLICE", 64);
     // channel slice of a workgroup: the largest chunk multiple <= 64 channels that divides C (64 = one 128-byte line per row)
     int CS = C;
@@ -917,7 +935,7 @@ extern "C" int sy_bn_silu_bwd_apply(const void* y, int ldy, const void* da, int 
     }
     // (grid caps re-swept after the instruction diet of these kernels, profiles/r02/ai_*, aj_*: fewer, fatter workgroups —
     //  apply 4096 -> 2048, backward reduce 1024 -> 768, backward apply 2048 -> 1024: -0.16 ... -0.27 ms per l step)
-    static const int cap_bapply = env_cap("SY_BN_BAPPLY_BLOCKS", 1024);
+    const int cap_bapply = bn_cap(kCapBApply).load(std::memory_order_relaxed);
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((bn_silu_bwd_apply_kernel<T>), dim3(row_grid(pixels, C, e, cap_bapply / nseg), nseg), dim3(kBlock), 0, stream,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)da, ldda, scale, shift,
                                        mean, invstd, gamma, sums, (typename T::elem*)dy, lddy, (long long)pixels, C, copies,

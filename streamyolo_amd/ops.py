@@ -174,9 +174,26 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
-def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, target_blocks=0):
+WGRAD_TICKETS = 4096          # arrival counters per split-K workspace (one per output tile of a launch)
+_wgrad_tickets = {}
+
+
+def _tickets_of(workspace):
+    """The zero-initialised arrival counters that go with a split-K workspace (sy_wgrad_desc::tickets): launches that share a
+    workspace are ordered on one stream and share its counters; every launch leaves them zero again."""
+    key = (str(workspace.device), workspace.data_ptr())
+    t = _wgrad_tickets.get(key)
+    if t is None:
+        if len(_wgrad_tickets) > 64:
+            _wgrad_tickets.clear()
+        t = _wgrad_tickets[key] = torch.zeros(WGRAD_TICKETS, dtype=torch.int32, device=workspace.device)
+    return t
+
+
+def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, target_blocks=0, fold_in_kernel=True):
     """dw fp32 += wgrad(x, dy): [Cout, k*k*Cin] packed layout, or the OIHW parameter layout.
-    workspace: optional uint8/fp32 device tensor for the split-K slabs (more parallelism on big layers)."""
+    workspace: optional uint8/fp32 device tensor for the split-K slabs (more parallelism on big layers); the launch then folds
+    its slabs itself (the last workgroup of every output tile, in split order: csrc/conv_wgrad.hip wgrad_fold_tile)."""
     d = WgradDesc()
     d.x, d.dy, d.dw = x.ptr(), dy.ptr(), dw.data_ptr()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
@@ -190,6 +207,9 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, t
     d.x_bytes, d.dy_bytes = x.bytes_from_ptr(), dy.bytes_from_ptr()
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        if fold_in_kernel:                                   # False (tests, A/B timing): the separate wgrad_fold launch of rounds 1-5
+            tk = _tickets_of(workspace)
+            d.tickets, d.tickets_count = tk.data_ptr(), tk.numel()
     check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")
 
 
@@ -328,7 +348,7 @@ class BnRunningTable:
     """Device table for sy_bn_running_update.  `modules` = [(bn_module, [(sum, sqsum, count[, copies, ld]), ...calls in order])];
     sum / sqsum start at the module's first channel; ld = replica pitch when they are a channel slice of a wider array."""
 
-    def __init__(self, modules, device):
+    def __init__(self, modules, device, count_batches=False):
         arr = (_lib.BnRunningEntry * len(modules))()
         self.max_c, self.keep = 0, []
         for e, (bn, calls) in zip(arr, modules):
@@ -342,8 +362,14 @@ class BnRunningTable:
             e.ld = calls[0][4] if len(calls[0]) > 4 else 0
             e.calls = len(calls)
             e.momentum = bn.momentum if bn.momentum is not None else 0.1
+            nbt = getattr(bn, "num_batches_tracked", None)           # += calls inside the launch (no torch._foreach_add_ per step)
+            if nbt is not None and count_batches:
+                assert nbt.dtype == torch.int64
+                e.num_batches_tracked = nbt.data_ptr()
+                self.keep.append((bn.running_mean, bn.running_var, nbt))
+            else:
+                self.keep.append((bn.running_mean, bn.running_var))
             self.max_c = max(self.max_c, e.C)
-            self.keep.append((bn.running_mean, bn.running_var))
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = raw.to(device)
         self.n = len(modules)
@@ -356,6 +382,32 @@ class BnRunningTable:
         check(_lib.lib().sy_bn_running_update(self.table.data_ptr(), self.n, self.max_c, stream_of(self.table)),
               "sy_bn_running_update")
         bump_weights_epoch()                       # running statistics changed behind torch's back
+
+
+BN_CAP_NAMES = ("apply", "finalize_apply", "bwd_reduce", "bwd_apply")
+
+
+def bn_grid_caps(**set_):
+    """sy_bn_grid_caps: set (keywords of BN_CAP_NAMES, > 0) and return the workgroup caps of the BatchNorm row kernels in force."""
+    assert all(k in BN_CAP_NAMES for k in set_), set_
+    s4 = (C.c_int32 * 4)(*[int(set_.get(k, 0)) for k in BN_CAP_NAMES])
+    g4 = (C.c_int32 * 4)()
+    check(_lib.lib().sy_bn_grid_caps(s4, g4), "sy_bn_grid_caps")
+    return dict(zip(BN_CAP_NAMES, [int(v) for v in g4]))
+
+
+def zero(t):
+    """t (a torch tensor: dense, or a 2-D strided view whose rows are dense) := 0 through sy_zero_rows — a launch the plan's tape
+    records, not an ATen fill."""
+    esz = t.element_size()
+    if t.is_contiguous():
+        rows, row_b, pitch_b = 1, t.numel() * esz, t.numel() * esz
+    else:
+        assert t.dim() == 2 and t.stride(1) == 1, "zero(): dense tensor or a row-strided 2-D view"
+        rows, row_b, pitch_b = t.shape[0], t.shape[1] * esz, t.stride(0) * esz
+    if rows == 0 or row_b == 0:
+        return
+    check(_lib.lib().sy_zero_rows(t.data_ptr(), rows, row_b, pitch_b, stream_of(t)), "sy_zero_rows")
 
 
 def bn_silu_apply(y, scale, shift, out, res=None, nseg=1):

@@ -52,14 +52,23 @@ BNR_TILES = (98, 100, 101, 109, 104, 107, 117, 118)     # data-gradient tiles wh
 # exact (fp32) mode: one statistics replica row per workgroup -> run-to-run bit-equal steps (TrainPlan.__init__); "0" = the
 # replica counts of the speed modes (A/B switch)
 EXACT_STATS = __import__("os").environ.get("STREAMYOLO_EXACT_STATS", "1") != "0"
-_BN_REDUCE_BLOCKS = int(__import__("os").environ.get("SY_BN_REDUCE_BLOCKS", "768"))   # csrc/train_ops.hip: cap_reduce
-# The workgroup cap of the BatchNorm-backward APPLY pass AS SCHEDULED in the step: the library's own default (1024, read once from the
-# environment by csrc/train_ops.hip's env_cap) is that kernel's optimum from round 2; beside round 5's frame chains and weight-gradient
-# streams fewer, fatter workgroups leave the MFMA kernels their CUs: 512 -> l step 20.83-20.88 vs 21.01-21.03 ms and 20.92 vs 21.00-
-# 21.14 on another box (256: 21.40-21.44; the forward apply / backward reduce caps: 1024 / 512 instead of 2048 / 768 nothing on top —
-# profiles/r05 stages zm, zn).  The pass is a grid-stride map over pixel rows (channel sums written by workgroup 0): its results do
-# not depend on the grid.  An explicit SY_BN_BAPPLY_BLOCKS wins.
-__import__("os").environ.setdefault("SY_BN_BAPPLY_BLOCKS", "512")
+# The workgroup cap of the BatchNorm-backward APPLY pass AS SCHEDULED in the step: the library's own default (1024) is that kernel's
+# optimum from round 2; beside round 5's frame chains and weight-gradient streams fewer, fatter workgroups leave the MFMA kernels
+# their CUs: 512 -> l step 20.83-20.88 vs 21.01-21.03 ms and 20.92 vs 21.00-21.14 on another box (256: 21.40-21.44; the forward apply
+# / backward reduce caps: 1024 / 512 instead of 2048 / 768 nothing on top — profiles/r05 stages zm, zn).  The pass is a grid-stride
+# map over pixel rows (channel sums written by workgroup 0): its results do not depend on the grid.  Set EXPLICITLY through
+# sy_bn_grid_caps when a plan is built (round 6; it was an environment write at import time, which a library that had already read
+# its caps ignored and which leaked into child processes — ADVICE r05); an explicit SY_BN_BAPPLY_BLOCKS in the environment wins.
+BN_BAPPLY_BLOCKS_SCHEDULED = 512
+
+
+def _schedule_bn_caps():
+    """Caps of the row kernels for a training plan -> the backward-reduce cap in force (the exact mode's replica-row count)."""
+    if os.environ.get("SY_BN_BAPPLY_BLOCKS"):
+        return ops.bn_grid_caps()["bwd_reduce"]
+    return ops.bn_grid_caps(bwd_apply=BN_BAPPLY_BLOCKS_SCHEDULED)["bwd_reduce"]
+
+
 # Measured and REMOVED in round 4 (profiles/r04/README.md): BatchNorm finalisation by the producing convolution's last workgroup
 # (every statistics launch got 8-13 us slower — each workgroup waits for its own atomics and a ticket round trip — the l step
 # 22.6-23.9 vs 22.3-23.0 ms at 2 ... 32 replicas) and BatchNorm backward as one resident launch whose workgroups wait for each
@@ -112,7 +121,8 @@ class _GradSpace:
             accumulate = True                                    # (partly) written: zero the holes, then +=
             flat = g.buf.view(-1, v.ld)
             for a, b in gaps:
-                self.py(lambda t=flat[:, a:b]: t.zero_())
+                ops.zero(flat[:, a:b])                           # sy_zero_rows: a launch of the plan's tape (round 6: was an ATen fill
+                                                                 # behind a return to Python at every such hole, ~30 per l step)
         if gaps:
             merged = []
             for a, b in sorted(iv + [(c0, c1)]):
@@ -387,11 +397,15 @@ class TrainPlan:
         # ceil(W / 32), whatever tile the tuner picks); backward reduce = its workgroup cap (SY_BN_REDUCE_BLOCKS, 768).
         self.exact_stats = EXACT_STATS and self.dtype == ops.DT_F32
         self.stat_copies = self.STAT_COPIES if self.STAT_COPIES > 0 else (32 if self.dtype == ops.DT_F32 else 4)
-        self.fused_finalize = (_FUSED_FINALIZE == "1") or (_FUSED_FINALIZE == "auto" and self.dtype != ops.DT_F32)
+        # (never with the exact mode's one-row-per-workgroup statistics: sy_bn_finalize_apply does not fold the thousands of rows —
+        #  only sy_bn_finalize's fold_rows_kernel does, and the running-statistics launch reads the folded rows — ADVICE r05)
+        self.fused_finalize = ((_FUSED_FINALIZE == "1") or (_FUSED_FINALIZE == "auto" and self.dtype != ops.DT_F32)) and not self.exact_stats
+        reduce_cap = _schedule_bn_caps()       # the library's own figure: one replica row per reduce workgroup in the exact mode
+
         def copies_of(op):
             if not self.exact_stats:
                 return self.stat_copies, self.BWD_COPIES
-            return max(self.stat_copies, op.y.N * op.y.H * ((op.y.W + 31) // 32)), max(self.BWD_COPIES, _BN_REDUCE_BLOCKS)
+            return max(self.stat_copies, op.y.N * op.y.H * ((op.y.W + 31) // 32)), max(self.BWD_COPIES, reduce_cap)
         for op in convs:
             op.stat_copies, op.bwd_copies = copies_of(op)
         self.stat_arena = torch.zeros(2 * sum(op.stat_copies * op.y.C for op in convs), dtype=torch.float32, device=device)  # [sum | sumsq] x copies
@@ -544,7 +558,7 @@ class TrainPlan:
             if not self.cache.valid():
                 self.cache = StagedWeights(self.ops, self.dtype, self.device)
         self.cache.refresh()                                     # this step's weights -> MFMA operand layouts (one launch)
-        self.stat_arena.zero_()
+        ops.zero(self.stat_arena)
         if self.parts == "head":                                 # x = the three fused FPN features (NCHW-shaped tensors)
             for v, t in zip(self.fused, x):
                 assert tuple(t.shape) == (v.N, v.C, v.H, v.W)
@@ -565,16 +579,10 @@ class TrainPlan:
                     for m in base_convs(op.mod):                     # a stacked launch: each module's channel slice of the arrays
                         mods.setdefault(id(m.bn), (m.bn, []))[1].append((op.stat[0][c0:], op.stat[1][c0:], op.y.pixels, SC, ctot))
                         c0 += m.bn.num_features
-            self.run_table = ops.BnRunningTable(list(mods.values()), self.device)
+            # num_batches_tracked: +1 per BN call (shared backbone / neck / jian BNs are called twice — trap T2) inside the same
+            # launch (sy_bn_running_entry::num_batches_tracked += calls; round 6: was a torch._foreach_add_ per step)
+            self.run_table = ops.BnRunningTable(list(mods.values()), self.device, count_batches=True)
         self.run_table.run()
-        # num_batches_tracked: +1 per BN call (shared backbone/neck/jian BNs are called twice — trap T2)
-        counts = {}
-        for bn in self.bn_mods:
-            if bn.num_batches_tracked is not None:
-                counts[id(bn)] = (bn.num_batches_tracked, counts.get(id(bn), (None, 0))[1] + 1)
-        if counts:
-            ts, cs = zip(*counts.values())
-            torch._foreach_add_(list(ts), list(cs))
         return self.raw if self.head is not None else self.fused
 
     def _forward_ops(self):
@@ -690,7 +698,8 @@ class TrainPlan:
         gradient, 16-bit compute, a tile with the staged 128-channel epilogue, the raw output laid out like the gradient view."""
         pre = op.pre_op
         if (not BNR_FUSION or pre is None or acc or self.dtype == ops.DT_F32 or t not in BNR_TILES or op.k != 3 or op.stride != 1
-                or pre.res is not None or pre.yraw is None or pre.yraw.ld != dx.ld or pre.yraw.bs != dx.bs or pre.y.C % 8 or dx.ld % 8):
+                or pre.res is not None or pre.yraw is None or pre.yraw.ld != dx.ld or pre.yraw.bs != dx.bs or pre.y.C % 8 or dx.ld % 8
+                or (dx.ptr() | pre.yraw.ptr()) % 16 or dx.bs % 8):     # sy_conv2d's own precondition of the staged epilogue (ADVICE r05)
             return None
         return pre
 
@@ -866,8 +875,8 @@ class TrainPlan:
         st = self.side_w.get(3) or self.side2 or self.side
         if wait:
             if self._zeroed is None:
-                self.arena.zero_()
-                self.bwd_arena.zero_()
+                ops.zero(self.arena)
+                ops.zero(self.bwd_arena)
             elif self._zeroed is not True:
                 torch.cuda.current_stream(self.device).wait_event(self._zeroed)
             self._zeroed = None
@@ -875,14 +884,14 @@ class TrainPlan:
         if self._zeroed is not None:
             return                                               # loss() called twice before a backward: already clear
         if st is None or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
-            self.arena.zero_()
-            self.bwd_arena.zero_()
+            ops.zero(self.arena)
+            ops.zero(self.bwd_arena)
             self._zeroed = True
             return
         st.wait_stream(torch.cuda.current_stream(self.device))   # whoever read the gradients last (optimizer, all-reduce) is done
         with torch.cuda.stream(st):
-            self.arena.zero_()
-            self.bwd_arena.zero_()
+            ops.zero(self.arena)
+            ops.zero(self.bwd_arena)
             if self._zero_ev is None:
                 self._zero_ev = torch.cuda.Event()
             self._zero_ev.record()

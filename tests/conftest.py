@@ -31,6 +31,31 @@ def pytest_collection_modifyitems(config, items):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def record_parity(key, **fields):
+    """When STREAMYOLO_PARITY_OUT names a JSON file, the GPU parity tests also WRITE the figures they assert on (loss / output /
+    gradient errors against the reference's goldens and the oracle) into it: rows[key] = fields.  The file of a full GPU run is
+    committed as profiles/rNN/parity_table.json and bench.py quotes the row of the benchmarked dtype and configuration
+    (`parity` of the driver line) instead of a hand-written string."""
+    import json
+    out = os.environ.get("STREAMYOLO_PARITY_OUT")
+    if not out:
+        return
+    try:
+        with open(out) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        d = {"rows": {}}
+    try:
+        d["commit"] = open(os.path.join(ROOT, "tools", ".head_commit")).read().strip()
+    except OSError:
+        pass
+    d["metric"] = "rel = max|ours - ref| / max|ref| (loss dict: over its six entries; gradients: per parameter ||g - g_ref|| / ||g_ref||)"
+    d["rows"].setdefault(key, {}).update({k: (float(v) if isinstance(v, (int, float)) or hasattr(v, "__float__") else v) for k, v in fields.items()})
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    with open(out, "w") as fh:
+        json.dump(d, fh, indent=1, sort_keys=True)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -43,7 +43,7 @@ def test_library_loads_and_reports_abi(hip_lib):
     lib = ctypes.CDLL(hip_lib)
     lib.sy_abi_version.restype = ctypes.c_int
     lib.sy_version.restype = ctypes.c_char_p
-    assert lib.sy_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.sy_abi_version() == _lib.ABI_VERSION == 7
     assert b"gfx950" in lib.sy_version()
     lib.sy_postprocess_workspace_bytes.restype = ctypes.c_int64
     assert lib.sy_postprocess_workspace_bytes(1, 11850) > 11850 * 11850 // 8

@@ -176,6 +176,39 @@ def test_wgrad_many_splits_fold(backend):
     assert _rel(dw.cpu(), ref) < 1e-4
 
 
+@pytest.mark.parametrize("dt,tile,k,cin,cout,N,H,W", [("bf16", 60, 3, 64, 144, 2, 9, 37), ("bf16", 52, 3, 32, 48, 2, 7, 70),
+                                                      ("bf16", 18, 1, 64, 80, 2, 9, 37), ("bf16", 17, 3, 32, 48, 1, 11, 21),
+                                                      ("fp32", 2, 1, 24, 40, 2, 9, 37), ("fp32", 1, 3, 8, 24, 1, 11, 21)])
+def test_wgrad_fold_inside_the_launch(backend, dt, tile, k, cin, cout, N, H, W):
+    """Round 6: a split-K weight gradient folds its partial slabs ITSELF (the last workgroup of every output tile to arrive, in split
+    order — csrc/conv_wgrad.hip wgrad_fold_tile) instead of a wgrad_fold launch behind it: all three kernels (all-taps, transpose-
+    read, scatter), packed and OIHW layouts, ragged channel tiles.  Same slabs, another fixed summation order than the fold kernel's:
+    equal to fp32 rounding of the sum over splits; the arrival counters are zero again afterwards; two launches are bit-equal
+    (no float atomics, whoever arrives last adds in the same order) and accumulate (+=)."""
+    g = torch.Generator().manual_seed(tile + cin)
+    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
+    dy = _q(torch.randn(N, cout, H, W, generator=g), dt)
+    xv = View.alloc(N, H, W, cin, dt, backend); xv.set_nchw(x.to(backend))
+    dyv = View.alloc(N, H, W, cout, dt, backend); dyv.set_nchw(dy.to(backend))
+    ws = torch.empty(1 << 24, dtype=torch.uint8, device=backend)
+    tk = ops._tickets_of(ws)
+    for oihw in (False, True):
+        shape = (cout, cin, k, k) if oihw else (cout, k * k * cin)
+        outs = {}
+        for mode in ("fold_launch", "in_kernel", "in_kernel_again"):
+            dw = torch.zeros(shape, device=backend)
+            ops.conv2d_wgrad(xv, dyv, dw, k, 1, oihw=oihw, workspace=ws, tile=tile, target_blocks=64, fold_in_kernel=mode != "fold_launch")
+            outs[mode] = dw.cpu()
+            assert int(tk.abs().sum()) == 0, "arrival counters not reset"
+        scale = float(outs["fold_launch"].abs().max())
+        assert scale > 0
+        assert float((outs["in_kernel"] - outs["fold_launch"]).abs().max()) <= 2e-6 * scale * 64
+        assert torch.equal(outs["in_kernel"], outs["in_kernel_again"])
+        dw = outs["in_kernel"].clone().to(backend)
+        ops.conv2d_wgrad(xv, dyv, dw, k, 1, oihw=oihw, workspace=ws, tile=tile, target_blocks=64)
+        assert _rel(dw.cpu(), 2 * outs["in_kernel"]) < 1e-6
+
+
 @pytest.mark.parametrize("tile", [96, 97, 98, 100, 101, 104, 106, 107, 109, 111, 112, 113, 114, 115, 116, 117, 118])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "fwd"), ("bf16", "dgrad"), ("fp32", "dgrad")])
 def test_conv3x3_halo_kernel(backend, tile, dt, mode):

@@ -224,12 +224,36 @@ def test_bn_running_update_batched(backend):
             ssq = torch.stack([(p ** 2).sum(1) for p in parts]).contiguous().to(backend)
             cl.append((ssum, ssq, y.numel() // C))
         mods.append((bn, cl)); ref.append(rbn)
-    tab = ops.BnRunningTable(mods, torch.device(backend) if not isinstance(backend, torch.device) else backend)
+    tab = ops.BnRunningTable(mods, torch.device(backend) if not isinstance(backend, torch.device) else backend, count_batches=True)
     assert tab.valid()
     tab.run()
     for (bn, _), rbn in zip(mods, ref):
         assert _rel(bn.running_mean.cpu(), rbn.running_mean) < 1e-5
         assert _rel(bn.running_var.cpu(), rbn.running_var) < 1e-5
+        # num_batches_tracked += one per training-mode call, inside the same launch (nn.BatchNorm2d.forward does it on the host)
+        assert int(bn.num_batches_tracked) == int(rbn.num_batches_tracked) and int(rbn.num_batches_tracked) in (1, 2)
+    tab.run()
+    assert [int(bn.num_batches_tracked) for bn, _ in mods] == [4, 2, 4]
+    # without count_batches the counters are left alone (a caller that counts on the host)
+    tab2 = ops.BnRunningTable(mods, torch.device(backend) if not isinstance(backend, torch.device) else backend)
+    tab2.run()
+    assert [int(bn.num_batches_tracked) for bn, _ in mods] == [4, 2, 4]
+
+
+@pytest.mark.parametrize("shape,sl", [((7, 96), (16, 80)), ((5, 40), (3, 11)), ((1000,), None), ((33, 8), (0, 8)), ((4, 6, 24), None)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_zero_rows(backend, shape, sl, dt):
+    """ops.zero (sy_zero_rows): dense tensors and row-strided column ranges are cleared, their surroundings untouched — what the
+    training plan uses for its arenas and for the unwritten channel ranges of a gradient buffer (16-byte and 4-byte store paths)."""
+    if dt == torch.bfloat16 and sl is not None and ((sl[1] - sl[0]) % 2 or sl[0] % 2):
+        pytest.skip("2-byte elements: ranges are whole 4-byte words on the training path")
+    full = torch.randn(shape).to(dt).to(backend) + 3.0
+    keep = full.clone()
+    t = full if sl is None else full[:, sl[0]:sl[1]]
+    ops.zero(t)
+    assert float(t.float().abs().max()) == 0.0
+    if sl is not None:
+        assert torch.equal(full[:, :sl[0]], keep[:, :sl[0]]) and torch.equal(full[:, sl[1]:], keep[:, sl[1]:])
 
 
 def _random_preds(B, A, nc, seed, img=(600.0, 960.0), tie_free=True):

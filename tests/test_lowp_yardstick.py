@@ -16,6 +16,7 @@ import torch
 
 import streamyolo_amd as sy
 from streamyolo_amd import ops
+from conftest import record_parity
 from oracle import streamyolo_oracle as O
 from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
 
@@ -117,7 +118,14 @@ def test_16bit_step_within_2x_of_the_references_own_autocast_error(golden_dir, n
             t_len = max(yard["dtypes"][d_]["groups"][grp]["abs_log_norm_ratio_median"] for d_ in ("bf16", "fp16"))
             assert o["abs_log_norm_ratio_median"] <= 2.0 * t_len + 0.05, (name, dt, grp, o, t_len)
         print("%s %s loss rel err %.3e (reference autocast %.3e)" % (name, dt, lerr, yard["dtypes"][dt]["loss_rel"]))
-        assert lerr < max(5e-2, 2.0 * yard["dtypes"][dt]["loss_rel"])
+        record_parity("train_%s_b%d_%s" % (name, B, dt), loss_rel=lerr, reference_autocast_loss_rel=yard["dtypes"][dt]["loss_rel"],
+                      grad_rel_l2_median_backbone=ours["backbone"]["median"], reference_autocast_grad_rel_l2_median_backbone=theirs["backbone"]["median"],
+                      shape=[B, H, W], test=__name__ + "::test_16bit_step_within_2x_of_the_references_own_autocast_error")
+        # 2x the spread measured on the MI355X over rounds 3-5 (s: bf16 3.0e-3, fp16 1.0e-3; l at one pair: bf16 5.6e-3 ... 1.6e-2, fp16
+        # 6.5e-3 ... 1.05e-2 depending on the tuner's tile choices) or 2x the reference's own autocast error, whichever is larger
+        # (VERDICT r05 "weak" #2: the former flat 5e-2 let a 3x regression pass)
+        own = {"s": {"bf16": 6e-3, "fp16": 2e-3}, "l": {"bf16": 3.2e-2, "fp16": 2.1e-2}}[name][dt]
+        assert lerr < max(own, 2.0 * yard["dtypes"][dt]["loss_rel"])
         del model, out
         torch.cuda.empty_cache()
 
@@ -155,6 +163,8 @@ def test_headline_batch_l_8x600x960_exact_mode_vs_oracle():
           % (lerr, errs[-1][0], errs[-1][1], errs[len(errs) // 2][0]))
     for e_, n_ in errs[-8:]:
         print("    %.3e  %s" % (e_, n_))
+    record_parity("train_l_b8_fp32", loss_rel=lerr, grad_rel_l2_worst=errs[-1][0], grad_rel_l2_median=errs[len(errs) // 2][0],
+                  reference="oracle autograd on the host cores (oracle pinned to the reference's own outputs)", test=__name__ + "::test_headline_batch_l_8x600x960_exact_mode_vs_oracle")
     assert lerr < 1e-3
     plan = next(p_ for k_, p_ in model._plans.plans.items() if str(k_[0]).startswith("train"))
     assert plan.exact_stats
@@ -176,16 +186,31 @@ def test_headline_batch_l_8x600x960_exact_mode_vs_oracle():
         assert vals[-1] < 2e-2 and nerr < 2e-3, (errs[-3:], nerr)
     else:                                                    # a proven rounding-level tie: bounded, and reported
         assert flips <= 4 and vals[-1] < 0.25 and nerr < 2e-2, (flips, errs[-3:], nerr)
-    # bf16 at the same batch: the benchmarked mode produces the same loss dict to the bound asserted at batch 1
-    model.set_compute_dtype("bf16")
-    for p in model.parameters():
-        p.grad = None
-    model.load_state_dict(sd, strict=True)
-    out = model(x.to(dev), (lab.to(dev), sup.to(dev)))
-    got = np.array([float(out[k]) for k in NAMES])
-    lerr16 = np.abs(got - want).max() / np.abs(want).max()
-    print("l 8x600x960 bf16: loss rel err %.3e" % lerr16)
-    assert lerr16 < 5e-2
+    record_parity("train_l_b8_fp32", matched_gt_differ=flips, grad_norm_rel=nerr)
+    # the 16-bit modes at the same batch — bf16 is the mode bench.py times, fp16 the reference's own --fp16: the loss dict, bounded at
+    # ~2.5x what the MI355X measures (bf16 3.8e-3 ... 4.6e-3, fp16 below it: round 5 / round 6 runs; VERDICT r05 "weak" #2 — the
+    # old bound, 5e-2, let a 10x regression pass), and the per-parameter gradient figures for the record (DESIGN.md section 4:
+    # with random-init weights they are amplified rounding noise, exactly like the reference's own autocast run — the yardstick test)
+    for dt16, bound in (("bf16", 1.2e-2), ("fp16", 1.2e-2)):
+        model.set_compute_dtype(dt16)
+        for p in model.parameters():
+            p.grad = None
+        model.load_state_dict(sd, strict=True)
+        out = model(x.to(dev), (lab.to(dev), sup.to(dev)))
+        out["total_loss"].backward()
+        got = np.array([float(out[k]) for k in NAMES])
+        lerr16 = np.abs(got - want).max() / np.abs(want).max()
+        e16 = sorted(float((p.grad.detach().cpu().double() - rgrads[n]).norm() / rgrads[n].norm().clamp_min(1e-30))
+                     for n, p in model.named_parameters())
+        cos = sorted(float((p.grad.detach().cpu().double() * rgrads[n]).sum() / (p.grad.detach().cpu().double().norm() * rgrads[n].norm()).clamp_min(1e-30))
+                     for n, p in model.named_parameters())
+        print("l 8x600x960 %s: loss rel err %.3e; per-parameter rel-L2 median %.3e, cosine median %.3f" % (dt16, lerr16, e16[len(e16) // 2], cos[len(cos) // 2]))
+        record_parity("train_l_b8_" + dt16, loss_rel=lerr16, grad_rel_l2_median=e16[len(e16) // 2], grad_rel_l2_worst=e16[-1],
+                      grad_cosine_median=cos[len(cos) // 2], reference="oracle autograd on the host cores, fp32",
+                      note="16-bit per-parameter gradients of a random-init l are rounding noise amplified by ~100 BatchNorms, as in the "
+                           "reference's own autocast run (tests/golden/lowp_yardstick.json); the loss dict is the comparable figure",
+                      test=__name__ + "::test_headline_batch_l_8x600x960_exact_mode_vs_oracle")
+        assert lerr16 < bound, (dt16, lerr16)
 
 
 def _run_curve(name, B, H, W, dt, steps, lr, dev):

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import streamyolo_amd as sy
+from conftest import record_parity
 from oracle import streamyolo_oracle as O
 from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, load_bn_stats
 
@@ -162,6 +163,8 @@ def test_eval_s_600x960_full_size(golden_dir, dt, tol):
         out = model(x)
     r = _rel(out.cpu(), z["decoded"])
     print("s 600x960 %s rel err vs reference: %.3e" % (dt, r))
+    record_parity("infer_s_b1_" + dt, decoded_rel=r, reference="tests/golden/s_eval_1x600x960.npz (the reference's own output)",
+                  nms_keep_list="bit-exact incl. order on the reference's decoded tensor", test=__name__ + "::test_eval_s_600x960_full_size")
     assert out.shape == (1, 11850, 13) and r < tol
     # NMS on the REFERENCE's decoded tensor: bit-exact keep list at full size
     det, idx, cnt = sy.postprocess.__globals__["postprocess_device"](torch.from_numpy(z["decoded"]).to(dev), 8, 0.01, 0.65)

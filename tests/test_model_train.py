@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import streamyolo_amd as sy
+from conftest import record_parity
 from oracle import streamyolo_oracle as O
 from streamyolo_amd.utils.synth import synth_state_dict, synth_frames, synth_labels
 
@@ -265,7 +266,7 @@ L_GRAD_TOL = {"fp32": 1e-2, "fp16": None, "bf16": None}
 def test_train_step_l_600x960_full_size_vs_oracle():
     """BASELINE.json's configuration itself (StreamYOLO-l, 600x960; one frame pair so the CPU oracle finishes in
     seconds): the six loss-dict entries and every parameter-gradient norm of the HIP step against the oracle's autograd
-    — 1e-3 in the exact-fp32 mode (north_star's bound), and the loss within 5e-2 in the bf16 speed mode bench.py times."""
+    — 1e-3 in the exact-fp32 mode (north_star's bound), and the loss within 3.2e-2 (bf16, the speed mode bench.py times) / 2.1e-2 (fp16): twice the upper end of the measured spread."""
     from streamyolo_amd import _lib
     _lib.use_library(_lib.DEFAULT_PATH)
     dev = torch.device("cuda:0")
@@ -280,7 +281,7 @@ def test_train_step_l_600x960_full_size_vs_oracle():
     want = np.array([float(ref[k]) for k in NAMES])
     rgrads = {k: v.grad for k, v in osd.items() if v.is_floating_point() and v.requires_grad}
     med = {}
-    for dt, ltol, gtol in (("fp32", 1e-3, L_GRAD_TOL["fp32"]), ("fp16", 3e-2, None), ("bf16", 5e-2, None)):   # measured fp16 6.5e-3 .. 1.05e-2, bf16 5.6e-3 .. 1.6e-2 (tuner-dependent)
+    for dt, ltol, gtol in (("fp32", 1e-3, L_GRAD_TOL["fp32"]), ("fp16", 2.1e-2, None), ("bf16", 3.2e-2, None)):   # measured fp16 6.5e-3 .. 1.05e-2, bf16 5.6e-3 .. 1.6e-2 (tuner-dependent): bounds = 2x the upper end
         model = sy.build_model("l")
         model.load_state_dict(sd, strict=True)
         model = model.to(dev).train().set_compute_dtype(dt)
@@ -290,9 +291,11 @@ def test_train_step_l_600x960_full_size_vs_oracle():
         got = np.array([float(out[k]) for k in NAMES])
         lerr = np.abs(got - want).max() / np.abs(want).max()
         print("l 600x960 %s: loss rel err %.3e" % (dt, lerr))
+        record_parity("train_l_b1_" + dt, loss_rel=lerr, reference="oracle autograd, fp32", test=__name__ + "::test_train_step_l_600x960_full_size_vs_oracle")
         assert lerr < ltol
         worst, wname, med[dt] = _per_param_l2(model, rgrads)
         print("l 600x960 %s: per-parameter gradient rel L2 error worst %.3e (%s), median %.3e" % (dt, worst, wname, med[dt]))
+        record_parity("train_l_b1_" + dt, grad_rel_l2_worst=worst, grad_rel_l2_median=med[dt])
         assert gtol is None or worst < gtol
         if dt == "fp32":
             gn, rn = [], []

@@ -18,7 +18,7 @@
 #   host[:MODEL]                 host-side launch profile (tools/host_profile.py)        -> host_profile_train_MODEL.txt
 #   py:NAME:SCRIPT[:ARGS]        python SCRIPT ARGS                                      -> NAME.txt
 #   tl                           launch timeline of the l step from the probe build (tools/step_timeline.py) -> step_timeline_train_l.{json,txt}
-#   install                      this run's traffic / timeline JSON -> profiles/r05/ on the box (bench.py reports them when their kernel-source key matches)
+#   install                      this run's traffic / timeline / rocprof-step JSON -> profiles/r06/ on the box (bench.py reports them when their kernel-source key matches)
 #   tunecache                    copy the tuner cache the runs above wrote (lib/tune_cache.json) -> tune_cache.json
 STAGE=$1; shift
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -44,7 +44,7 @@ for task in "$@"; do
         prof)  rm -rf /tmp/prof_$STAGE
                (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$STAGE -- python $OLDPWD/bench.py --workload train --model l --steps 5 --warmup 4 --no-cpu-baseline --extras 0 ${a//,/ } 2>&1 | tail -1) > $O/rocprof_bench_line.json 2>&1
                cp /tmp/prof_$STAGE/*/*kernel_stats.csv $O/train_l_b8_bf16_kernel_stats.csv 2>/dev/null
-               python tools/trace_analyze.py $(ls /tmp/prof_$STAGE/*/*kernel_trace.csv | head -1) > $O/rocprof_last_step.txt 2>&1
+               python tools/trace_analyze.py $(ls /tmp/prof_$STAGE/*/*kernel_trace.csv | head -1) --json $O/rocprof_step_train_l.json > $O/rocprof_last_step.txt 2>&1
                head -40 $O/rocprof_last_step.txt ;;
         traffic) w=${a:-train}; m=${b:-l}
                (timeout 1200 python tools/pmc_traffic.py --out $O/traffic_${w}_$m.json -- --workload $w --model $m 2>&1 | tail -20) > $O/traffic_${w}_$m.txt 2>&1
@@ -56,7 +56,7 @@ for task in "$@"; do
         host)  m=${a:-l}; (timeout 600 python tools/host_profile.py $m 2>&1 | grep -v "^$" | tail -40) > $O/host_profile_train_$m.txt 2>&1; tail -12 $O/host_profile_train_$m.txt ;;
         tl)    (STREAMYOLO_HIP_LIB=$PWD/tools/probes/_build/libstreamyolo_probe.so timeout 600 python tools/step_timeline.py --bins 0.5 --json $O/step_timeline_train_l.json 2>&1 | grep -vE "$noise") > $O/step_timeline_train_l.txt 2>&1
                head -6 $O/step_timeline_train_l.txt ;;
-        install) cp $O/traffic_train_l.json $O/step_timeline_train_l.json profiles/r05/ && echo "counter files of this run installed for the bench lines behind this task" ;;
+        install) mkdir -p profiles/r06; for f in traffic_train_l.json step_timeline_train_l.json rocprof_step_train_l.json; do [ -f $O/$f ] && cp $O/$f profiles/r06/; done; echo "counter files of this run installed for the bench lines behind this task" ;;
         tunecache) cp streamyolo_amd/lib/tune_cache.json $O/tune_cache.json 2>/dev/null; ls -la $O/tune_cache.json ;;
         py)    (timeout 1200 python $b ${c//,/ } 2>&1 | grep -vE "$noise") > $O/$a.txt 2>&1; tail -40 $O/$a.txt ;;
         *) echo "unknown task $task" ;;

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Timeline summary of a rocprofv3 --kernel-trace CSV: for the last full training step (delimited by
 pack_weights_kernel launches) report wall time, union-busy time, per-queue busy time, idle gaps and the
-per-kernel-family totals.  Usage: python tools/trace_analyze.py <kernel_trace.csv>"""
+per-kernel-family totals.  Usage: python tools/trace_analyze.py <kernel_trace.csv> [--json OUT.json]
+--json: the last step's per-kernel totals as a file bench.py reads (roofline.dominant.in_step_frac), stamped
+with the kernel-source key of the tree it was measured on."""
 import csv
+import json
+import os
 import re
 import sys
 from collections import defaultdict
@@ -49,3 +53,22 @@ for k, (n, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:28]:
 MFMA_NAMES = ("conv_igemm_kernel", "conv3x3_halo", "conv1x1_tile_kernel", "conv_wgrad", "wgrad_fold")
 mfma = sum(d for k, (n, d) in fam.items() if any(m in k for m in MFMA_NAMES))
 print("MFMA kernels (conv_igemm + conv3x3_halo + conv1x1_tile + conv_wgrad + wgrad_fold) in the last step: %.3f ms  (bench.py roofline.kernel_ms_per_step measures the same set with HIP events)" % (mfma / 1e6))
+
+if "--json" in sys.argv:
+    out = sys.argv[sys.argv.index("--json") + 1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from streamyolo_amd import _lib
+    try:
+        commit = open(os.path.join(root, "tools", ".head_commit")).read().strip()
+    except OSError:
+        commit = None
+    halo = sum(d for k, (n, d) in fam.items() if "conv3x3_halo" in k)
+    rec = {"kernel_source_key": _lib.kernel_source_key(), "commit": commit,
+           "what": "rocprofv3 --kernel-trace of bench.py (train l, 8 pairs, bf16): the LAST taped step between two pack_weights launches; "
+                   "the trace serialises the streams on this stack, so these are per-launch durations of the step's own launch list",
+           "launches_in_step": len(step), "sum_kernel_ms": sum(e - s for s, e, _, _ in step) / 1e6, "mfma_kernels_ms": mfma / 1e6,
+           "conv3x3_halo_ms": halo / 1e6,
+           "families_ms": {k: [n, round(d / 1e6, 4)] for k, (n, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
+    with open(out, "w") as fh:
+        json.dump(rec, fh, indent=1)
