@@ -148,13 +148,6 @@ typedef struct sy_wgrad_desc {
                                          * channels per workgroup (Cin % 64 == 0).  52 / 59 / 60 on a layer they do not cover:
                                          * SY_ERR_UNSUPPORTED; any other unknown code: the heuristic tile. */
     int64_t x_bytes, dy_bytes;          /* bytes addressable from x / dy (buffer bounds; 0 = unknown) */
-    uint32_t* tickets;                  /* optional (ABI 7): >= tickets_count zero-initialised arrival counters.  With them a split-K launch
-                                         * folds its partial slabs ITSELF — the last workgroup of an output tile to publish its slab
-                                         * (agent-scope release -> ticket -> acquire) adds the tile's slabs in split order into dw and
-                                         * resets the ticket — instead of a second (wgrad_fold) launch; still deterministic, no float
-                                         * atomics.  NULL, or more output tiles than tickets_count: the separate fold launch.  One array
-                                         * per stream that runs weight gradients concurrently. */
-    int32_t tickets_count, reserved;
 } sy_wgrad_desc;
 SY_API int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream);
 

@@ -82,7 +82,6 @@ class WgradDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("ldx", C.c_int32), ("lddy", C.c_int32), ("xbs", C.c_int64), ("dybs", C.c_int64),
         ("dtype", C.c_int32), ("dw_oihw", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("tile", C.c_int32), ("target_blocks", C.c_int32), ("x_bytes", C.c_int64), ("dy_bytes", C.c_int64),
-        ("tickets", C.c_void_p), ("tickets_count", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -8,6 +8,7 @@
 namespace sy_conv {
 template int launch_halo_typed<BF16>(const ConvArgs&, void*);
 template int launch_s2dgrad<BF16>(const ConvArgs&, void*);
+template int launch_s2dgrad4<BF16>(const ConvArgs&, void*);
 template int launch_1x1_tile<BF16>(const ConvArgs&, void*);
 template int launch_bottleneck_fused<BF16>(const ConvArgs&, void*);
 }  // namespace sy_conv

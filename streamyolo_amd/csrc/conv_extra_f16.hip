@@ -8,6 +8,7 @@
 namespace sy_conv {
 template int launch_halo_typed<F16>(const ConvArgs&, void*);
 template int launch_s2dgrad<F16>(const ConvArgs&, void*);
+template int launch_s2dgrad4<F16>(const ConvArgs&, void*);
 template int launch_1x1_tile<F16>(const ConvArgs&, void*);
 template int launch_bottleneck_fused<F16>(const ConvArgs&, void*);
 }  // namespace sy_conv

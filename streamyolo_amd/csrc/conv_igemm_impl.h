@@ -1017,6 +1017,7 @@ int launch_cfg(const ConvArgs& a_in, void* stream) {
 template <typename T> int launch_halo_typed(const ConvArgs& a, void* stream);      // conv3x3_halo.h (tile codes 104..107, 110..118)
 template <typename T> int launch_halo3_typed(const ConvArgs& a, void* stream);     // conv3x3_halo3.h (tile codes 96..98, 100, 101, 109)
 template <typename T> int launch_s2dgrad(const ConvArgs& a, void* stream);         // conv3x3_s2dgrad.h (tile code 108)
+template <typename T> int launch_s2dgrad4(const ConvArgs& a, void* stream);        // conv3x3_s2dgrad.h (tile codes 125 - 127: all four classes per workgroup)
 template <typename T> int launch_1x1_tile(const ConvArgs& a, void* stream);        // conv1x1_tile.h (tile codes 121..124)
 template <typename T> int launch_bottleneck_fused(const ConvArgs& a, void* stream); // bottleneck_fused.h (tile code 119)
 
@@ -1026,6 +1027,7 @@ int launch_typed(const ConvArgs& a, void* stream) {
     if (a.tile == 109 || (a.tile >= 96 && a.tile <= 98) || a.tile == 100 || a.tile == 101) return launch_halo3_typed<T>(a, stream);
     if (a.tile == 119) return launch_bottleneck_fused<T>(a, stream);
     if (a.tile == 108) return launch_s2dgrad<T>(a, stream);
+    if (a.tile >= 125 && a.tile <= 127) return launch_s2dgrad4<T>(a, stream);
     if (a.tile >= 121 && a.tile <= 124) return launch_1x1_tile<T>(a, stream);
     // Tile choice.  The kernel is fed from L2: bytes staged per MFMA flop fall with the tile area, so wide
     // layers use 256 ch x 256 px (8 waves, 128 accumulator registers per lane).  Layers too small to give

@@ -18,6 +18,10 @@
 // caller's workspace (plain 16-byte stores) and a fold kernel sums the slabs INTO dW (+=), which is
 // how the current-frame and support-frame passes of the shared backbone weights add up
 // (SURVEY.md §8(e)); the caller zeroes the gradient arena once per step.  Deterministic: no atomics.
+// (Round 6 measured the fold INSIDE the launch — the last workgroup of an output tile to publish its slab, behind an agent-scope
+//  release / ticket / acquire, adds the tile's slabs in split order; parity-green on the MI355X — and removed it: a tile's `splits`
+//  slabs are 0.5-1.8 MB that ONE workgroup then pulls alone, the weight gradients took 15.75 instead of 8.95 ms one at a time and the
+//  l step 24.9-25.1 instead of 21.9-22.0 ms on the same box (profiles/r06 stage b); the fold stays a chip-wide launch.)
 #include <stdlib.h>
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
@@ -38,10 +42,6 @@ struct WgradArgs {
     float* part;                // split > 1: partial slabs [splits][K / 4][Cout][4], folded by wgrad_fold_kernel
     int splits;
     int part_bf16;              // slabs stored as bf16 (bf16 compute mode): half the slab traffic of the kernels and of the fold
-    int grid_x;                 // gridDim.x (tile id = blockIdx.y * grid_x + blockIdx.x of the XCD-remapped block id)
-    unsigned* tickets;          // fold_in != 0: one zero-initialised arrival counter per output tile (gridDim.x * gridDim.y)
-    int n_tickets;
-    int fold_in;                // the launch folds its slabs itself (wgrad_fold_tile): no wgrad_fold_kernel launch behind it
     int ablate;                 // profiling only (tools/wgrad_probe.py): 1 = no x loads, 2 = no dy loads
 };
 
@@ -85,89 +85,6 @@ struct PixelCursor {            // (n, ho, wo) of one output pixel, advanced sla
         }
     }
 };
-
-// ---- the split-K seam INSIDE the launch (round 6) --------------------------------------------------------------
-// Until round 5 every split-K weight gradient was followed by a wgrad_fold launch (123 per l step, 1.95 ms of kernel time spread
-// over the whole chip on the weight-gradient streams).  Now the workgroups of an output tile (same blockIdx.x / .y, one per split)
-// publish their partial slabs and draw a ticket; the one that draws the LAST ticket adds the tile's `splits` slabs — in split order,
-// so the sum does not depend on who arrived last: deterministic, no float atomics — into dW and resets the ticket.  Nobody waits:
-// no residency requirement, no spin.  The fold of a tile is one workgroup's tail instead of a chip-wide launch.
-// A tile's rows are `n_runs` runs of `run_len` consecutive k = (tap, ci) rows, `run_stride` apart (one run for the (tap, ci)-tiled
-// kernels; nine runs of the workgroup's input channels, Cin apart, for the all-taps kernel); columns [c0, c0 + ncols).
-// `flag` = 4 bytes of LDS nobody else touches any more.  Must be called by every thread of the workgroup.
-template <int NT>
-__device__ __forceinline__ void wgrad_fold_tile(const WgradArgs& p, unsigned* flag, int tile_id, int k0, int run_len, int n_runs,
-                                                int run_stride, int c0, int ncols, int tid) {
-    sy_wait_vmcnt<0>();                                      // this wave's slab stores have left the CU
-    __syncthreads();
-    if (tid == 0) {
-        sy_release_agent();                                  // ... and are written back past this XCD's L2
-        const unsigned t = sy_ticket_take(p.tickets + tile_id);
-        const unsigned last = (t == (unsigned)p.splits - 1u) ? 1u : 0u;
-        if (last) {
-            sy_ticket_reset(p.tickets + tile_id);            // every split has arrived: the counter is free for the next launch
-            sy_acquire_agent();
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (*flag == 0u) return;
-    int cw = p.Cout - c0;
-    if (cw > ncols) cw = ncols;
-    const int qpr = run_len >> 2;                            // float4 groups (four consecutive k) per run
-    const int items = n_runs * qpr * cw;
-    const long long slab4 = ((long long)p.Cout * p.K) >> 2;  // float4 groups per split
-    const int taps = p.KH * p.KW;
-    constexpr int G = 4;                                     // items in flight per thread (x splits loads each, issued split-major)
-    for (int it0 = tid; it0 < items; it0 += NT * G) {
-        long long g[G];
-        int kb[G], co[G];
-        float v[G][4];
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int it = it0 + j * NT;
-            const int itc = it < items ? it : 0;
-            co[j] = c0 + itc % cw;
-            const int q = itc / cw;
-            const int run = q / qpr, qi = q - run * qpr;
-            kb[j] = (it < items) ? k0 + run * run_stride + qi * 4 : p.K;       // p.K: nothing to do
-            g[j] = (long long)((kb[j] < p.K ? kb[j] : 0) >> 2) * p.Cout + co[j];
-            v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.0f;
-        }
-        for (int z = 0; z < p.splits; ++z) {
-            if (p.part_bf16) {
-                uint2 u[G];
-#pragma unroll
-                for (int j = 0; j < G; ++j) u[j] = reinterpret_cast<const uint2*>(p.part)[(long long)z * slab4 + g[j]];
-#pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    v[j][0] += BF16::to_f32((unsigned short)(u[j].x & 0xffffu)); v[j][1] += BF16::to_f32((unsigned short)(u[j].x >> 16));
-                    v[j][2] += BF16::to_f32((unsigned short)(u[j].y & 0xffffu)); v[j][3] += BF16::to_f32((unsigned short)(u[j].y >> 16));
-                }
-            } else {
-                float4 u[G];
-#pragma unroll
-                for (int j = 0; j < G; ++j) u[j] = reinterpret_cast<const float4*>(p.part)[(long long)z * slab4 + g[j]];
-#pragma unroll
-                for (int j = 0; j < G; ++j) { v[j][0] += u[j].x; v[j][1] += u[j].y; v[j][2] += u[j].z; v[j][3] += u[j].w; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            if (kb[j] >= p.K) continue;
-            if (p.oihw) {
-                const int tap = kb[j] / p.Cin, ci = kb[j] - tap * p.Cin;
-                float* row = p.dw + (long long)co[j] * p.K + (long long)ci * taps + tap;
-                row[0] += v[j][0]; row[taps] += v[j][1]; row[2 * taps] += v[j][2]; row[3 * taps] += v[j][3];
-            } else {
-                float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co[j] * p.K + kb[j]);
-                float4 o = *dst;
-                o.x += v[j][0]; o.y += v[j][1]; o.z += v[j][2]; o.w += v[j][3];
-                *dst = o;
-            }
-        }
-    }
-}
 
 // ---- epilogue: D[row = k][col = co].  One split: every dW element belongs to exactly one workgroup, so a
 //      plain += into dW is race free.  Several splits: each writes its tile to a private slab (16-byte
@@ -400,7 +317,6 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_kernel(WgradArgs p) {
     }
 
     wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
-    if (p.fold_in) wgrad_fold_tile<kThreadsW>(p, reinterpret_cast<unsigned*>(sA), bid.y * p.grid_x + bid.x, r0, RT, 1, 0, c0, CT, tid);
     SY_TL_END();
 }
 
@@ -558,8 +474,6 @@ __global__ __launch_bounds__(kThreadsW) void conv_wgrad_tr_kernel(WgradArgs p) {
     }
     sy_wait_vmcnt<0>();                           // the out-of-range pieces past the last slab (LDS must be quiet at exit)
     wgrad_epilogue<TR, TC>(p, acc, r0, c0, wr, wcn, lane, bid.z);
-    // (the fold's own first barrier is behind every wave's last fragment read: the LDS image is free for its flag)
-    if (p.fold_in) wgrad_fold_tile<kThreadsW>(p, reinterpret_cast<unsigned*>(smem), bid.y * p.grid_x + bid.x, r0, RT, 1, 0, c0, CT, tid);
     SY_TL_END();
 }
 
@@ -799,32 +713,27 @@ __global__ __launch_bounds__(kThreadsW * CI2, CI2 == 1 ? 2 : 1) void conv_wgrad9
     // ---- epilogue: D[row = (tap, ci)][col = co]; partial slab of this split, or += into dW (one split)
     const int l31 = lane & 31, half = lane >> 5;
     const int co = c0 + cw * 32 + l31;
-    if (co < p.Cout) {
+    if (co >= p.Cout) return;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ci = ci0 + ch * 32 + q * 8 + half * 4;
-                const int kb = t * p.Cin + ci;
-                const float v0 = acc[t][q * 4 + 0], v1 = acc[t][q * 4 + 1], v2 = acc[t][q * 4 + 2], v3 = acc[t][q * 4 + 3];
-                if (p.splits > 1) {
-                    wgrad_store_slab(p, bid.z, co, kb, v0, v1, v2, v3);
-                } else if (p.oihw) {
-                    float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
-                    row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
-                } else {
-                    float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co * p.K + kb);
-                    float4 o = *dst;
-                    o.x += v0; o.y += v1; o.z += v2; o.w += v3;
-                    *dst = o;
-                }
+        for (int q = 0; q < 4; ++q) {
+            const int ci = ci0 + ch * 32 + q * 8 + half * 4;
+            const int kb = t * p.Cin + ci;
+            const float v0 = acc[t][q * 4 + 0], v1 = acc[t][q * 4 + 1], v2 = acc[t][q * 4 + 2], v3 = acc[t][q * 4 + 3];
+            if (p.splits > 1) {
+                wgrad_store_slab(p, bid.z, co, kb, v0, v1, v2, v3);
+            } else if (p.oihw) {
+                float* row = p.dw + (long long)co * p.K + (long long)ci * 9 + t;
+                row[0] += v0; row[9] += v1; row[18] += v2; row[27] += v3;
+            } else {
+                float4* dst = reinterpret_cast<float4*>(p.dw + (long long)co * p.K + kb);
+                float4 o = *dst;
+                o.x += v0; o.y += v1; o.z += v2; o.w += v3;
+                *dst = o;
             }
-    }
+        }
     sy_probe(6);
-    // the tile's last workgroup folds its splits (nine runs of CIT input channels, Cin apart; the fold's own first barrier is
-    // behind every wave's last fragment read: the LDS image is free for its flag)
-    if (p.fold_in) wgrad_fold_tile<kThreadsW * CI2>(p, reinterpret_cast<unsigned*>(smem), bid.y * p.grid_x + bid.x, ci0, CIT, 9, p.Cin, c0, CT, tid);
-    sy_probe(7);
     SY_TL_END();
 }
 
@@ -940,8 +849,6 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
     a.slabs_per_split = (slabs_total + splits - 1) / splits;
     splits = (slabs_total + a.slabs_per_split - 1) / a.slabs_per_split;
     a.splits = splits;
-    a.grid_x = gx;
-    a.fold_in = (splits > 1 && a.tickets != nullptr && (long long)gx * gy <= a.n_tickets) ? 1 : 0;
     if constexpr (TRV != 0) {
         // transpose-read variant preconditions; otherwise the scatter kernel of the same tile runs
         const bool tr_ok = T::kEPC == 8 && a.Cin % 16 == 0 && a.Cout % 16 == 0 && a.x_extent != 0 && a.dy_extent != 0;
@@ -955,7 +862,7 @@ int launch_wgrad_cfg(WgradArgs a, long long ws_bytes, void* stream) {
         SY_LAUNCH((conv_wgrad_kernel<T, WR, WC, TR, TC>), dim3(gx, gy, splits), dim3(kThreadsW), 0, stream, a);
     }
     if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
-    if (splits > 1 && !a.fold_in) return launch_fold(a, splits, a.KH * a.KW, stream);
+    if (splits > 1) return launch_fold(a, splits, a.KH * a.KW, stream);
     return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
 }
 
@@ -980,8 +887,6 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
         a.slabs_per_split = (slabs_total + splits - 1) / splits;
         splits = (slabs_total + a.slabs_per_split - 1) / a.slabs_per_split;
         a.splits = splits;
-        a.grid_x = gx;
-        a.fold_in = (splits > 1 && a.tickets != nullptr && (long long)gx * gy <= a.n_tickets) ? 1 : 0;
         constexpr size_t smem = (size_t)STG * (2 * CI2 * kXSub + 8 * kSubPitch);
 #ifndef SY_EMU
         static sy_dev_once attr_done;
@@ -993,7 +898,7 @@ int launch_wgrad9(WgradArgs a, long long ws_bytes, void* stream) {
 #endif
         SY_LAUNCH((conv_wgrad9_kernel<T, STG, CI2, PIPE>), dim3(gx, gy, splits), dim3(kThreadsW * CI2), smem, stream, a);
         if (SY_LAUNCH_OK() != 0) return SY_ERR_LAUNCH;
-        if (splits > 1 && !a.fold_in) return launch_fold(a, splits, 9, stream);
+        if (splits > 1) return launch_fold(a, splits, 9, stream);
         return SY_LAUNCH_OK() == 0 ? SY_OK : SY_ERR_LAUNCH;
     }
 }
@@ -1052,11 +957,6 @@ extern "C" int sy_conv2d_wgrad(const sy_wgrad_desc* d, void* stream) {
     a.target_blocks = d->target_blocks;
     a.part = (float*)d->workspace;
     a.splits = 1;
-    static const bool fold_in_kernel = [] { const char* e = getenv("SY_WGRAD_FOLD_IN_KERNEL"); return e == nullptr || atoi(e) != 0; }();
-    a.tickets = fold_in_kernel ? d->tickets : nullptr;
-    a.n_tickets = d->tickets != nullptr ? d->tickets_count : 0;
-    a.grid_x = 0;
-    a.fold_in = 0;
     static const bool slab_bf16 = [] { const char* e = getenv("SY_WGRAD_SLAB_BF16"); return e == nullptr || atoi(e) != 0; }();
     a.part_bf16 = (d->dtype == SY_DT_BF16 && slab_bf16) ? 1 : 0;
     const long long wsb = d->workspace != nullptr ? (long long)d->workspace_bytes : 0;

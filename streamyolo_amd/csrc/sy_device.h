@@ -288,28 +288,6 @@ __device__ __forceinline__ void sy_glds16_buf_at(const sy_buffer& b, unsigned vo
 }
 #endif
 
-// ---- cross-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16, counter form) ------------------------------
-// Producer: plain stores -> every wave sy_wait_vmcnt<0>() -> __syncthreads() -> ONE lane: sy_release_agent() (buffer_wbl2 sc1; the
-// asm wait behind it restates the post-write-back wait where the compiler cannot drop it) -> sy_ticket_take().  The workgroup that
-// draws the last ticket: sy_acquire_agent() on that lane (buffer_inv sc1: this CU's stale L1 lines) -> __syncthreads() -> plain
-// loads of what the others published.  Nobody waits for anybody (no residency requirement): whoever arrives last does the work.
-#ifdef SY_EMU
-static inline void sy_release_agent() { std::atomic_thread_fence(std::memory_order_seq_cst); }
-static inline void sy_acquire_agent() { std::atomic_thread_fence(std::memory_order_seq_cst); }
-static inline unsigned sy_ticket_take(unsigned* p) { return reinterpret_cast<std::atomic<unsigned>*>(p)->fetch_add(1u); }
-static inline void sy_ticket_reset(unsigned* p) { reinterpret_cast<std::atomic<unsigned>*>(p)->store(0u); }
-#else
-__device__ __forceinline__ void sy_release_agent() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ void sy_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-__device__ __forceinline__ unsigned sy_ticket_take(unsigned* p) {
-    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sy_ticket_reset(unsigned* p) { __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
-
 // Wave-level ordering point for wave-PRIVATE LDS hand-offs (one lane writes, another lane of the same wave reads): the
 // hardware executes a wave's LDS instructions in order, so nothing is needed beyond keeping the compiler from reordering;
 // the host emulator runs lanes as fibers and needs a real rendezvous of the wave.

@@ -174,26 +174,9 @@ def conv2d(x, w, y, ksize, stride, scale=None, shift=None, res=None, epilogue=EP
     check(_lib.lib().sy_conv2d(C.byref(d), stream_of(x.buf)), "sy_conv2d")
 
 
-WGRAD_TICKETS = 4096          # arrival counters per split-K workspace (one per output tile of a launch)
-_wgrad_tickets = {}
-
-
-def _tickets_of(workspace):
-    """The zero-initialised arrival counters that go with a split-K workspace (sy_wgrad_desc::tickets): launches that share a
-    workspace are ordered on one stream and share its counters; every launch leaves them zero again."""
-    key = (str(workspace.device), workspace.data_ptr())
-    t = _wgrad_tickets.get(key)
-    if t is None:
-        if len(_wgrad_tickets) > 64:
-            _wgrad_tickets.clear()
-        t = _wgrad_tickets[key] = torch.zeros(WGRAD_TICKETS, dtype=torch.int32, device=workspace.device)
-    return t
-
-
-def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, target_blocks=0, fold_in_kernel=True):
+def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, target_blocks=0):
     """dw fp32 += wgrad(x, dy): [Cout, k*k*Cin] packed layout, or the OIHW parameter layout.
-    workspace: optional uint8/fp32 device tensor for the split-K slabs (more parallelism on big layers); the launch then folds
-    its slabs itself (the last workgroup of every output tile, in split order: csrc/conv_wgrad.hip wgrad_fold_tile)."""
+    workspace: optional uint8/fp32 device tensor for the split-K slabs (more parallelism on big layers)."""
     d = WgradDesc()
     d.x, d.dy, d.dw = x.ptr(), dy.ptr(), dw.data_ptr()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
@@ -207,9 +190,6 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, oihw=False, workspace=None, tile=0, t
     d.x_bytes, d.dy_bytes = x.bytes_from_ptr(), dy.bytes_from_ptr()
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-        if fold_in_kernel:                                   # False (tests, A/B timing): the separate wgrad_fold launch of rounds 1-5
-            tk = _tickets_of(workspace)
-            d.tickets, d.tickets_count = tk.data_ptr(), tk.numel()
     check(_lib.lib().sy_conv2d_wgrad(C.byref(d), stream_of(x.buf)), "sy_conv2d_wgrad")
 
 
@@ -625,7 +605,11 @@ HALO_SMALL_PIXELS = 12000
 # K groups inside the workgroup (csrc/conv3x3_halo.h, KS): eval / streaming plans that allow another fp32 summation order
 HALO_KGROUP_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_KGROUP_TILES", "111,106").replace("+", ",").split(",") if t]
 HALO_S2_KGROUP_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_KGROUP_TILES", "105").replace("+", ",").split(",") if t]
-HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "110,108").replace("+", ",").split(",") if t]
+# 125 / 126 / 127 (round 6, csrc/conv3x3_s2dgrad.h): the data gradient with ALL FOUR parity classes in one workgroup — the dy window
+# parked once, 18 TP MFMAs per wave and slab instead of 4 ... 16, no light / heavy workgroups (126: 128 ch x 2 class rows; 125: one
+# class row, two waves per SIMD; 127: the 64-channel tile)
+HALO_S2_TILES = [int(t) for t in _os.environ.get("STREAMYOLO_HALO_S2_TILES", "110,108,125,126,127").replace("+", ",").split(",") if t]
+S2_DGRAD_TILES = (108, 125, 126, 127)
 TILE_1X1K = [int(t) for t in _os.environ.get("STREAMYOLO_TILE_1X1K", "121,122,123,124").replace("+", ",").split(",") if t]
 
 
@@ -687,7 +671,8 @@ def tuned_tile(mode, dtype, N, H, W, Cin, Cout, k, stride, device, with_stats=Fa
         if N * Ho * Wo <= HALO_SMALL_PIXELS:
             cands += HALO_SMALL_TILES
     if k == 3 and stride == 2 and wf is not None and Cin % (16 if code == DT_F32 else 32) == 0:
-        cands += [t for t in HALO_S2_TILES if (t == 108) == (mode == CONV_DGRAD)]     # 110: forward, 108: data gradient
+        cands += [t for t in HALO_S2_TILES if (t in S2_DGRAD_TILES) == (mode == CONV_DGRAD)       # 110: forward; 108 / 126 / 127: data gradient
+                  and not (t == 127 and Cout > 64)]
     if k == 1 and stride == 1 and wf is not None and Cin in (64, 128, 256, 512, 1024, 2048) and code != DT_F32:
         # whole-K burst kernel (csrc/conv1x1_tile.h): 128 ch x 64 px | 64 ch x 128 px | 128 ch x 128 px (Cin <= 256)
         cands += [t for t in TILE_1X1K if not (t == 122 and Cout > 64) and not (t == 123 and Cin > 256) and not (t not in (121, 124) and Cin > 512)

@@ -74,6 +74,39 @@ def test_bench_gpus_4_ranks_buckets_and_disjoint_core_slices(emu_built):
         assert comm["rank_cores"] == list(range(slices[0][0], slices[0][1] + 1))
 
 
+@pytest.mark.timeout(1500)
+def test_bench_gpus_8_under_the_drivers_own_launcher(emu_built):
+    """the command the driver runs for the scaling curve — `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` (BASELINE.json configs[3] is eight ranks) —
+    end to end on the emulator + gloo: bench.py uses the ranks it was given (no second launcher), rank 0 prints ONE line for the
+    8-rank aggregate, the gradient buckets cover the arena exactly and every all-reduce starts during backward, the exchange time
+    backward did not hide is reported, and the eight launch threads sit on disjoint host-core slices."""
+    import socket
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if ncores < 8:
+        pytest.skip("eight ranks need eight host cores")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8"] + ARGS
+    r = subprocess.run(cmd, env=_env(OMP_NUM_THREADS="1"), cwd=ROOT, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["config"]["global_batch"] == 8
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 1
+    comm = line["comm"]
+    assert len(comm["rank_ms_per_step"]) == 8 and abs(line["ms_per_step"] - max(comm["rank_ms_per_step"])) < 1e-3
+    assert abs(line["value"] - 8 * 1 * line["steps"] / (line["ms_per_step"] * line["steps"] * 1e-3)) < 1e-6 * line["value"]   # whole-job aggregate
+    assert comm["buckets"] >= 1 and comm["buckets_overlapped_with_backward"] == comm["buckets"]
+    assert len(comm["bucket_bytes"]) == comm["buckets"] and sum(comm["bucket_bytes"]) == comm["allreduce_bytes_per_step"]
+    assert comm["exposed_allreduce_ms"] is not None and comm["exposed_allreduce_ms"] >= 0.0
+    slices = comm["all_rank_cores"]
+    assert len(slices) == 8 and all(sl is not None for sl in slices)
+    owned = [c for lo, hi in slices for c in range(lo, hi + 1)]
+    assert len(owned) == len(set(owned)) == 8 * (slices[0][1] - slices[0][0] + 1), "ranks share host cores: %s" % slices
+
+
 def test_bench_never_prints_a_one_gpu_line_for_gpus_n(emu_built):
     """--gpus 2 inside a 1-rank environment (a launcher that started too few ranks) is an error, not a 1-GPU line."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS,

@@ -176,39 +176,6 @@ def test_wgrad_many_splits_fold(backend):
     assert _rel(dw.cpu(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("dt,tile,k,cin,cout,N,H,W", [("bf16", 60, 3, 64, 144, 2, 9, 37), ("bf16", 52, 3, 32, 48, 2, 7, 70),
-                                                      ("bf16", 18, 1, 64, 80, 2, 9, 37), ("bf16", 17, 3, 32, 48, 1, 11, 21),
-                                                      ("fp32", 2, 1, 24, 40, 2, 9, 37), ("fp32", 1, 3, 8, 24, 1, 11, 21)])
-def test_wgrad_fold_inside_the_launch(backend, dt, tile, k, cin, cout, N, H, W):
-    """Round 6: a split-K weight gradient folds its partial slabs ITSELF (the last workgroup of every output tile to arrive, in split
-    order — csrc/conv_wgrad.hip wgrad_fold_tile) instead of a wgrad_fold launch behind it: all three kernels (all-taps, transpose-
-    read, scatter), packed and OIHW layouts, ragged channel tiles.  Same slabs, another fixed summation order than the fold kernel's:
-    equal to fp32 rounding of the sum over splits; the arrival counters are zero again afterwards; two launches are bit-equal
-    (no float atomics, whoever arrives last adds in the same order) and accumulate (+=)."""
-    g = torch.Generator().manual_seed(tile + cin)
-    x = _q(torch.randn(N, cin, H, W, generator=g), dt)
-    dy = _q(torch.randn(N, cout, H, W, generator=g), dt)
-    xv = View.alloc(N, H, W, cin, dt, backend); xv.set_nchw(x.to(backend))
-    dyv = View.alloc(N, H, W, cout, dt, backend); dyv.set_nchw(dy.to(backend))
-    ws = torch.empty(1 << 24, dtype=torch.uint8, device=backend)
-    tk = ops._tickets_of(ws)
-    for oihw in (False, True):
-        shape = (cout, cin, k, k) if oihw else (cout, k * k * cin)
-        outs = {}
-        for mode in ("fold_launch", "in_kernel", "in_kernel_again"):
-            dw = torch.zeros(shape, device=backend)
-            ops.conv2d_wgrad(xv, dyv, dw, k, 1, oihw=oihw, workspace=ws, tile=tile, target_blocks=64, fold_in_kernel=mode != "fold_launch")
-            outs[mode] = dw.cpu()
-            assert int(tk.abs().sum()) == 0, "arrival counters not reset"
-        scale = float(outs["fold_launch"].abs().max())
-        assert scale > 0
-        assert float((outs["in_kernel"] - outs["fold_launch"]).abs().max()) <= 2e-6 * scale * 64
-        assert torch.equal(outs["in_kernel"], outs["in_kernel_again"])
-        dw = outs["in_kernel"].clone().to(backend)
-        ops.conv2d_wgrad(xv, dyv, dw, k, 1, oihw=oihw, workspace=ws, tile=tile, target_blocks=64)
-        assert _rel(dw.cpu(), 2 * outs["in_kernel"]) < 1e-6
-
-
 @pytest.mark.parametrize("tile", [96, 97, 98, 100, 101, 104, 106, 107, 109, 111, 112, 113, 114, 115, 116, 117, 118])
 @pytest.mark.parametrize("dt,mode", [("bf16", "fwd"), ("fp32", "fwd"), ("bf16", "dgrad"), ("fp32", "dgrad")])
 def test_conv3x3_halo_kernel(backend, tile, dt, mode):
@@ -473,11 +440,13 @@ def test_conv3x3_stride2_halo_kernel(backend, tile, dt, N, cin, cout, H, W):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
-@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 72, 11, 37), (1, 32, 160, 8, 66), (2, 64, 128, 6, 129)])
-def test_conv3x3_stride2_data_gradient_kernel(backend, dt, N, cin, cout, H, W):
+@pytest.mark.parametrize("tile", [108, 125, 126, 127])
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 72, 11, 37), (1, 32, 160, 8, 66), (2, 64, 128, 6, 129), (1, 160, 64, 9, 70)])
+def test_conv3x3_stride2_data_gradient_kernel(backend, dt, tile, N, cin, cout, H, W):
     """conv3x3_s2dgrad_kernel (tile code 108): the data gradient of a 3x3 stride-2 convolution as four output-parity classes of 1 / 2 /
-    2 / 4 taps read from a (TH + 1) x 34 window of dy in LDS — odd and even input sizes (ragged last class row / column), ragged
-    channel tiles, first write and +=, against torch and against the implicit-GEMM kernel."""
+    2 / 4 taps read from a (TH + 1) x 34 window of dy in LDS; conv3x3_s2dgrad4_kernel (125 / 126 / 127, round 6): the same with all four
+    classes in one workgroup (window parked once, four accumulator sets, one epilogue per class) — odd and even input sizes (ragged
+    last class row / column), ragged channel tiles, first write and +=, against torch and against the implicit-GEMM kernel."""
     code = ops.dtype_code(dt)
     slab = 16 if dt == "fp32" else 32
     g = torch.Generator().manual_seed(cin + cout + W)
@@ -493,17 +462,17 @@ def test_conv3x3_stride2_data_gradient_kernel(backend, dt, N, cin, cout, H, W):
     wt = pack_conv_weight(torch.cat([w, w.new_zeros(cpad - cout, cin, 3, 3)], 0), code, transpose=True).to(backend)
     wf = pack_conv_weight_frag(wt, 3)
     dxv = View.alloc(N, H, W, cin + 8, dt, backend, zero=True).slice(8, cin)
-    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=108, wfrag=wf)
+    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf)
     assert _rel(dxv.nchw().cpu(), x.grad) < TOL[dt]
     assert float(dxv.buf[..., :8].float().abs().max()) == 0.0
-    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=108, wfrag=wf, accumulate=True)
+    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf, accumulate=True)
     assert _rel(dxv.nchw().cpu(), 2 * x.grad) < 2 * TOL[dt]
     ref = View.alloc(N, H, W, cin, dt, backend, zero=True)
     ops.conv2d(dyp, wt, ref, 3, 2, mode=ops.CONV_DGRAD, tile=19)      # implicit GEMM (four parity classes), same operands
-    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=108, wfrag=wf)
+    ops.conv2d(dyp, wt, dxv, 3, 2, mode=ops.CONV_DGRAD, tile=tile, wfrag=wf)
     assert _rel(dxv.nchw().cpu(), ref.nchw().cpu()) < (1e-5 if dt == "fp32" else 1e-2)
     with pytest.raises(ops._lib.HipLibraryError):                    # forward launches are not this kernel's
-        ops.conv2d(dxv, wt, dyp, 3, 2, tile=108, wfrag=wf)
+        ops.conv2d(dxv, wt, dyp, 3, 2, tile=tile, wfrag=wf)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])

@@ -41,6 +41,13 @@ SHAPES = [
     ("d3.m.c2/f", 8, 75, 120, 128, 128, 3, 1),
     ("d5.m.c2/f", 8, 19, 30, 512, 512, 3, 1),
     ("d2.m.c2/f", 8, 150, 240, 64, 64, 3, 1),
+    # the stride-2 layers of one frame (indices 27-32): --mode dgrad times their data gradients (tiles 108, 125-127 + the implicit GEMM)
+    ("dark2.0/f", 8, 150, 240, 64, 128, 3, 2),
+    ("dark3.0/f", 8, 75, 120, 128, 256, 3, 2),
+    ("dark4.0/f", 8, 38, 60, 256, 512, 3, 2),
+    ("dark5.0/f", 8, 19, 30, 512, 1024, 3, 2),
+    ("bu_conv2/f", 8, 38, 60, 256, 256, 3, 2),
+    ("bu_conv1/f", 8, 19, 30, 512, 512, 3, 2),
 ]
 NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256", 6: "dma128x64",
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",
@@ -48,7 +55,7 @@ NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64
          51: "d3-128x128", 52: "d3-64x256", 54: "d3-128x64", 55: "d3-64x64",
          96: "halo3-64x4", 97: "halo3-64x6", 100: "halo3-128x3", 101: "halo3-128x2", 98: "halo3-128x4", 121: "k1-128x64", 122: "k1-64x128", 123: "k1-128x128", 117: "halo2-128x2", 118: "halo2-128x4w", 107: "halo2-128x3", 104: "halo2-128x5",
          112: "halo128x4", 113: "halo128x4w", 114: "halo128x2-8w", 115: "halo128x2", 116: "halo64x8",
-         119: "halo2-128x8/8acc", 111: "halo2-256x4/8acc", 109: "halo3-128x5", 110: "halo2-s2-128x2", 108: "s2dgrad-128x2",
+         119: "halo2-128x8/8acc", 111: "halo2-256x4/8acc", 109: "halo3-128x5", 110: "halo2-s2-128x2", 108: "s2dgrad-128x2", 125: "s2dgrad4-128x1", 126: "s2dgrad4-128x2", 127: "s2dgrad4-64x2",
          99: "w3-128x128", 102: "w3-128x64", 103: "w3-64x64", 24: "rs256x64", 88: "wr256x64", 89: "wr256x128", 83: "wr128x128", 84: "wr64x256", 85: "wr32x256", 86: "wr128x64", 87: "wr64x64"}
 
 
@@ -105,7 +112,7 @@ def main():
             if (112 <= (t & 255) < 120 or (t & 255) in (111, 104, 106, 107, 109, 100, 101, 98, 96, 97)) and (k != 3 or st != 1):
                 res.append(float("nan"))
                 continue
-            if (t & 255) == 108 and (k != 3 or st != 2 or a.mode != "dgrad"):
+            if (t & 255) in (108, 125, 126, 127) and (k != 3 or st != 2 or a.mode != "dgrad"):
                 res.append(float("nan"))
                 continue
             if (t & 255) == 110 and (k != 3 or st != 2 or a.mode == "dgrad"):
