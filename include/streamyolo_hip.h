@@ -198,7 +198,9 @@ SY_API int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_t bs
 /* The head's output transform as a stand-alone in-place pass over out [B, A, 5+nc] fp32 (anchors level-major, row-major):
  * flags & 1: boxes (xy + grid) * stride, exp(wh) * stride — TALHead.decode_outputs (exps/model/tal_head.py:245-260), what
  * tools/eval.py:187-188 calls when the head ran with decode_in_inference = False; flags & 2: sigmoid of the objectness column
- * (tal_head.py:197-199 applies it in both modes).  level_h / level_w / level_stride: HOST arrays of nlevels (<= 8) entries
+ * (tal_head.py:197-199 applies it in both modes); flags & 4 (after the others): boxes (cx, cy, w, h) -> corners (cx - w/2, cy - h/2,
+ * cx + w/2, cy + h/2), the in-place rewrite yolox.utils.postprocess performs on its argument before the confidence filter (the
+ * reference's evaluator sees it: exps/evaluators/onex_stream_evaluator.py:148-150).  level_h / level_w / level_stride: HOST arrays of nlevels (<= 8) entries
  * (copied into the launch by value), sum h*w == A. */
 SY_API int sy_head_decode(float* out, int B, int A, int nch, const int32_t* level_h, const int32_t* level_w,
                           const float* level_stride, int nlevels, int flags, void* stream);

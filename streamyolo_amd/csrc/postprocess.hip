@@ -286,13 +286,17 @@ __global__ __launch_bounds__(256) void head_decode_kernel(float* out, int B, int
         r[3] = expf(r[3]) * st;
     }
     if (flags & 2) r[4] = 1.0f / (1.0f + expf(-r[4]));
+    if (flags & 4) {            // (cx, cy, w, h) -> (x1, y1, x2, y2) in place: yolox.utils.postprocess's first four statements, each rounded once
+        const float cx = r[0], cy = r[1], hw = r[2] / 2.0f, hh = r[3] / 2.0f;
+        r[0] = cx - hw; r[1] = cy - hh; r[2] = cx + hw; r[3] = cy + hh;
+    }
 }
 
 }  // namespace
 
 extern "C" int sy_head_decode(float* out, int B, int A, int nch, const int32_t* level_h, const int32_t* level_w,
                               const float* level_stride, int nlevels, int flags, void* stream) {
-    if (out == nullptr || B <= 0 || A <= 0 || nch < 5 || (flags & ~3) != 0) return SY_ERR_ARG;
+    if (out == nullptr || B <= 0 || A <= 0 || nch < 5 || (flags & ~7) != 0) return SY_ERR_ARG;
     DecodeLevels L;
     L.n = 0;
     if (flags & 1) {

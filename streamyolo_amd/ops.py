@@ -417,12 +417,12 @@ def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 
-def head_decode(out, hw=None, strides=None, boxes=True, obj_sigmoid=False):
+def head_decode(out, hw=None, strides=None, boxes=True, obj_sigmoid=False, corners=False):
     """sy_head_decode in place on out [B, A, 5+nc] fp32 contiguous: boxes -> (xy + grid) * stride, exp(wh) * stride over the
-    levels hw = [(h, w)] with `strides`; obj_sigmoid -> sigmoid of column 4."""
+    levels hw = [(h, w)] with `strides`; obj_sigmoid -> sigmoid of column 4; corners -> (cx, cy, w, h) to (x1, y1, x2, y2)."""
     assert out.dtype == torch.float32 and out.is_contiguous() and out.dim() == 3
     B, A, nch = out.shape
-    flags = (1 if boxes else 0) | (2 if obj_sigmoid else 0)
+    flags = (1 if boxes else 0) | (2 if obj_sigmoid else 0) | (4 if corners else 0)
     if boxes:
         n = len(hw)
         lh = (C.c_int32 * n)(*[int(h) for h, _ in hw])

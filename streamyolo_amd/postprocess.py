@@ -28,7 +28,10 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
         raise NotImplementedError("class_agnostic NMS is not used on the StreamYOLO path")
     det, idx, cnt = postprocess_device(prediction, num_classes, conf_thre, nms_thre)
     counts = cnt.cpu().tolist()
-    cx, cy, w, h = prediction[..., 0].clone(), prediction[..., 1].clone(), prediction[..., 2].clone(), prediction[..., 3].clone()
-    prediction[..., 0], prediction[..., 1] = cx - w / 2, cy - h / 2
-    prediction[..., 2], prediction[..., 3] = cx + w / 2, cy + h / 2
+    if prediction.dtype == torch.float32 and prediction.is_contiguous() and prediction.dim() == 3:
+        ops.head_decode(prediction, boxes=False, corners=True)          # one launch (sy_head_decode, flag 4)
+    else:                                                               # a caller's half / strided tensor: its own dtype's arithmetic
+        cx, cy, w, h = prediction[..., 0].clone(), prediction[..., 1].clone(), prediction[..., 2].clone(), prediction[..., 3].clone()
+        prediction[..., 0], prediction[..., 1] = cx - w / 2, cy - h / 2
+        prediction[..., 2], prediction[..., 3] = cx + w / 2, cy + h / 2
     return [det[i, :n].clone().to(prediction.dtype) if n else None for i, n in enumerate(counts)]

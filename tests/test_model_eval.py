@@ -142,10 +142,23 @@ def test_postprocess_dropin_on_reference_decoded(backend, golden_dir):
     for i in range(dec.shape[0]):
         n = int(cnt[i])
         assert np.array_equal(idx[i, :n].cpu().numpy(), z["keep%d" % i])
-    outs = sy.postprocess(dec.clone(), 8, 0.01, 0.65)
+    arg = dec.clone()
+    outs = sy.postprocess(arg, 8, 0.01, 0.65)
     ref = O.postprocess(torch.from_numpy(z["decoded"]), 8, 0.01, 0.65)
     for o, (rdet, _) in zip(outs, ref):
         assert torch.equal(o.cpu(), rdet)
+    # like yolox.utils.postprocess, the call rewrites its argument's boxes to corner form IN PLACE (one sy_head_decode launch): bit-equal
+    # to the reference's four eager statements on the same tensor, the other columns untouched
+    want = torch.from_numpy(z["decoded"]).clone()
+    cx, cy, w, h = want[..., 0].clone(), want[..., 1].clone(), want[..., 2].clone(), want[..., 3].clone()
+    want[..., 0], want[..., 1], want[..., 2], want[..., 3] = cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2
+    assert torch.equal(arg.cpu(), want)
+    # a strided (non-contiguous) argument takes the eager branch and gets the same rewrite
+    wide = torch.zeros(dec.shape[0], dec.shape[1], dec.shape[2] + 3, device=dec.device)
+    wide[..., :dec.shape[2]] = dec
+    view = wide[..., :dec.shape[2]]
+    sy.postprocess(view, 8, 0.01, 0.65)
+    assert torch.equal(view.cpu(), want)
 
 
 @pytest.mark.gpu

@@ -48,6 +48,11 @@ SHAPES = [
     ("dark5.0/f", 8, 19, 30, 512, 1024, 3, 2),
     ("bu_conv2/f", 8, 38, 60, 256, 256, 3, 2),
     ("bu_conv1/f", 8, 19, 30, 512, 512, 3, 2),
+    # one frame's 1x1 launches (indices 33-36): --mode stats with tiles 121, 121 + 8 * 256 (no atomics), 121 + 24 * 256 (no statistics)
+    ("d3.m.c1/f", 8, 75, 120, 128, 128, 1, 1),
+    ("d4.m.c1/f", 8, 38, 60, 256, 256, 1, 1),
+    ("d5.m.c1/f", 8, 19, 30, 512, 512, 1, 1),
+    ("d4.conv3/f", 8, 38, 60, 512, 512, 1, 1),
 ]
 NAMES = {0: "auto", 1: "dma256x256", 2: "dma128x256", 3: "dma128x128", 4: "dma64x256", 5: "dma32x256", 6: "dma128x64",
          7: "dma64x64", 17: "rs256x256", 18: "rs128x256", 19: "rs128x128", 20: "rs64x256", 21: "rs32x256",

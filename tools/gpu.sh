@@ -6,7 +6,7 @@
 #   gpurun --timeout 900 -- 'bash tools/gpu.sh a tests smoke bench:train_l bench:train_l_b4:--batch,4,--no-cpu-baseline prof'
 #
 # tasks
-#   tests[:K_EXPR[:ARGS]]        pytest tests -m gpu -q [-k "K_EXPR" with + for spaces] [args] -> pytest_gpu.log
+#   tests[:K_EXPR[:ARGS]]        pytest tests -m gpu -q [-k "K_EXPR" with + for spaces] [args] -> pytest_gpu.log, parity_table.json
 #   tenv:K=V,K=V:K_EXPR          the same subset under environment switches                 -> pytest_gpu_env.log
 #   smoke                        __graft_entry__.smoke()                                -> smoke.log
 #   bench:NAME[:ARGS]            python bench.py ARGS                                   -> bench_NAME.json
@@ -32,7 +32,8 @@ for task in "$@"; do
     t0=$(date +%s)
     case $kind in
         tests) if [ -n "$a" ]; then kexpr=(-k "${a//+/ }"); else kexpr=(); fi
-               (timeout 900 python -m pytest tests -m gpu -q --durations=12 "${kexpr[@]}" ${b//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
+               rm -f $O/parity_table.json        # the parity tests write the figures they assert on (tests/conftest.py record_parity)
+               (STREAMYOLO_PARITY_OUT=$PWD/$O/parity_table.json timeout 1200 python -m pytest tests -m gpu -q --durations=12 "${kexpr[@]}" ${b//,/ } 2>&1 | grep -vE "$noise") > $O/pytest_gpu.log 2>&1
                grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
         tenv)  (env ${a//,/ } timeout 900 python -m pytest tests -m gpu -q -k "${b//+/ }" 2>&1 | grep -vE "$noise") > $O/pytest_gpu_env.log 2>&1
                grep -E "passed|failed|error" $O/pytest_gpu_env.log | tail -3 ;;
@@ -56,7 +57,7 @@ for task in "$@"; do
         host)  m=${a:-l}; (timeout 600 python tools/host_profile.py $m 2>&1 | grep -v "^$" | tail -40) > $O/host_profile_train_$m.txt 2>&1; tail -12 $O/host_profile_train_$m.txt ;;
         tl)    (STREAMYOLO_HIP_LIB=$PWD/tools/probes/_build/libstreamyolo_probe.so timeout 600 python tools/step_timeline.py --bins 0.5 --json $O/step_timeline_train_l.json 2>&1 | grep -vE "$noise") > $O/step_timeline_train_l.txt 2>&1
                head -6 $O/step_timeline_train_l.txt ;;
-        install) mkdir -p profiles/r06; for f in traffic_train_l.json step_timeline_train_l.json rocprof_step_train_l.json; do [ -f $O/$f ] && cp $O/$f profiles/r06/; done; echo "counter files of this run installed for the bench lines behind this task" ;;
+        install) mkdir -p profiles/r06; for f in traffic_train_l.json step_timeline_train_l.json rocprof_step_train_l.json parity_table.json; do [ -f $O/$f ] && cp $O/$f profiles/r06/; done; echo "counter files of this run installed for the bench lines behind this task" ;;
         tunecache) cp streamyolo_amd/lib/tune_cache.json $O/tune_cache.json 2>/dev/null; ls -la $O/tune_cache.json ;;
         py)    (timeout 1200 python $b ${c//,/ } 2>&1 | grep -vE "$noise") > $O/$a.txt 2>&1; tail -40 $O/$a.txt ;;
         *) echo "unknown task $task" ;;
