@@ -347,18 +347,6 @@ SY_API int sy_tal_loss(const float* raw, int B, int A, int num_classes, const fl
 SY_API int sy_tal_loss_assignment(const void* workspace, int B, int A, int max_labels, int32_t* matched_gt,
                                   float* matched_iou, void* stream);
 
-/* sy_bn_silu_bwd_reduce + sy_bn_silu_bwd_apply as ONE launch for tensors small enough to be held in registers by a grid that is
- * resident at once (its workgroups wait for each other: csrc/train_ops.hip).  sums: [nseg][2][C] fp32, ZERO on entry (one replica);
- * tickets: [nseg][C / slice][2] zero-initialised counters (at least nseg * 2 * C / 8 words), left zero again; the other arguments as
- * in the two passes (dres_accumulate bits 0 and 1).  Returns SY_ERR_UNSUPPORTED — nothing launched — when the tensor does not fit
- * half of the device's guaranteed residency (SY_BN_FUSED_SHARE launches of this kernel may run concurrently, default 2: the caller
- * must not run more): the caller then runs the two passes.  Same arithmetic per element as the two passes; the channel sums are
- * float atomics over the workgroups of a slice (order-dependent in the last bits, like the 16-bit modes' statistics). */
-SY_API int sy_bn_silu_bwd_fused(const void* y, int ldy, const void* da, int ldda, const float* scale, const float* shift,
-                                const float* mean, const float* invstd, const float* gamma, float* sums, uint32_t* tickets,
-                                void* dy, int lddy, int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
-                                int dres_accumulate, int dtype, int nseg, void* stream);
-
 /* Workgroup caps of the BatchNorm row kernels (grid-stride maps over pixel rows: results do not depend on them, except that the
  * backward reduce's cap is the number of replica rows the exact mode sizes its sums for): caps4 = {sy_bn_silu_apply,
  * sy_bn_finalize_apply, sy_bn_silu_bwd_reduce, sy_bn_silu_bwd_apply}.  set4 (may be NULL): entries > 0 replace the cap, others keep

@@ -110,7 +110,6 @@ SIGNATURES = {
     "sy_bn_finalize_apply": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_reduce": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
     "sy_bn_silu_bwd_apply": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "sy_bn_silu_bwd_fused": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sy_tal_loss_workspace_bytes": (_L, [_I, _I, _I]),
     "sy_tal_loss": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _I, _P]),
     "sy_tal_loss_assignment": (_I, [_P, _I, _I, _I, _P, _P, _P]),

@@ -23,20 +23,6 @@
         if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
         sy_launch_fn_(nullptr);                                                                                      \
     } while (0)
-// a launch whose workgroups wait for one another (sy_bn_silu_bwd_fused): the caller bounds the grid by the device's residency; the
-// emulator runs every workgroup of such a launch on its own OS thread
-#define SY_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...)                                                   \
-    do {                                                                                                             \
-        const dim3 sy_grid_ = (grid), sy_block_ = (block);                                                           \
-        const size_t sy_smem_ = (smem);                                                                              \
-        auto sy_args_ = std::make_tuple(__VA_ARGS__);                                                                \
-        auto sy_launch_fn_ = [=](void*) {                                                                            \
-            emu::launch(sy_grid_, sy_block_, sy_smem_,                                                               \
-                        [=]() { std::apply([](auto... sy_a_) { kernel(sy_a_...); }, sy_args_); }, true);             \
-        };                                                                                                           \
-        if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
-        sy_launch_fn_(nullptr);                                                                                      \
-    } while (0)
 #define SY_LAUNCH_OK() 0
 #else
 #include <hip/hip_runtime.h>
@@ -59,15 +45,11 @@
         if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \
         sy_launch_fn_((void*)(stream));                                                                              \
     } while (0)
-#define SY_LAUNCH_RESIDENT SY_LAUNCH
 #define SY_LAUNCH_OK() ((int)hipGetLastError())
 #endif
 
 #include <stdint.h>
 #include <atomic>
-#ifdef SY_EMU
-#include <thread>
-#endif
 
 // "done once" flag of a per-kernel host-side setting (hipFuncSetAttribute: the opt-in for > 64 KiB of dynamic LDS) — PER DEVICE: one
 // process may drive several GPUs, and the attribute set on one is not set on the others (a process-wide `static bool`
@@ -303,30 +285,6 @@ __device__ __forceinline__ void sy_glds16_buf_at(const sy_buffer& b, unsigned vo
     const unsigned dst = __builtin_amdgcn_readfirstlane(base + off);
     // M0 as a register-constrained input: the compiler loads it (and knows it is live), no save / restore around the DMA
     asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(b), "{m0}"(dst) : "memory");
-}
-#endif
-
-// ---- arrival counters of a launch whose workgroups meet (sy_bn_silu_bwd_fused): agent-scope relaxed operations on words that are
-// only ever touched atomically; ONE lane per workgroup polls, asleep between polls (cdna_hip_programming.md Guideline 16 / price row
-// "polling-cost": pollers that hammer a word slow every kernel on the chip).  The data the meeting protects travels through
-// device-scope atomics (float atomicAdd -> sy_load_agent), so no release / acquire fence is needed around it.
-#ifdef SY_EMU
-static inline unsigned sy_ticket_take(unsigned* t) { return reinterpret_cast<std::atomic<unsigned>*>(t)->fetch_add(1u); }
-static inline void sy_ticket_reset(unsigned* t) { reinterpret_cast<std::atomic<unsigned>*>(t)->store(0u); }
-static inline float sy_load_agent(const float* p) { return reinterpret_cast<const std::atomic<float>*>(p)->load(); }
-static inline void sy_spin_until_ge(const unsigned* p, unsigned target) {
-    while (reinterpret_cast<const std::atomic<unsigned>*>(p)->load() < target) std::this_thread::yield();
-}
-#else
-__device__ __forceinline__ unsigned sy_ticket_take(unsigned* t) {
-    return __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void sy_ticket_reset(unsigned* t) { __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float sy_load_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void sy_spin_until_ge(const unsigned* p, unsigned target) {
-    // ~0.5 us between polls; BOUNDED (~1 s): a launch whose grid the host sized wrongly ends with wrong sums instead of hanging the GPU
-    for (unsigned n = 0; n < (1u << 21) && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++n)
-        __builtin_amdgcn_s_sleep(16);
 }
 #endif
 

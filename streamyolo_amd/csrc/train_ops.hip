@@ -750,151 +750,6 @@ __global__ __launch_bounds__(kBlock) void fold_replicas_kernel(float* sums, int 
     if (q == 0 && i < n) sums[i] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
 }
 
-// ---- BatchNorm.SiLU backward in ONE launch (sy_bn_silu_bwd_fused; rounds 3-4 built and removed a first version, round 6 this one) ----
-// tools/ablate_step.py on the round-6 tree: the l step WITHOUT its 216 reduce launches is 1.77 ms shorter (20.68 -> 18.92 ms) — the
-// bound on what reduce + apply as one launch can buy.  A workgroup owns (channel slice of CS channels = one 128-byte line per pixel
-// row) x (rows * R pixels) and keeps its piece of the raw output and of the incoming gradient in REGISTERS: it reduces the piece, adds
-// to the slice's two sums (device-scope float atomics), announces itself on the slice's arrival counter and waits until the slice's
-// other pieces have arrived — statistics are per channel, so the wait is among the workgroups of ONE slice, all resident because the
-// host bounds the grid — then applies from registers.  One launch and one read of both tensors instead of two.
-// What the first version (24.58 vs 22.70 ms, profiles/r04 stage b) did differently: it preferred the SMALLEST piece (R = 4: up to 570
-// waiting workgroups spread over every CU, each polling its counter every ~100 cycles); here the host picks the FEWEST workgroups
-// that still fit half the chip's guaranteed residency (R up to 16 rows per thread) and a waiting workgroup polls every ~0.5 us.
-// Counters: [segment][slice][2] = arrivals, departures; the last workgroup to depart resets both.  `sums` ([segment][2][C]) must be
-// zero on entry.
-template <typename T, int R>
-__global__ __launch_bounds__(kBlock, 2) void bn_silu_bwd_fused_kernel(const typename T::elem* y, int ldy, const typename T::elem* da, int ldda,
-                                                                      const float* scale, const float* shift, const float* mean,
-                                                                      const float* invstd, const float* gamma, float* sums,
-                                                                      unsigned* tickets, typename T::elem* dy, int lddy, long long pixels,
-                                                                      int C, int CS, float* dgamma, float* dbeta, typename T::elem* dres,
-                                                                      int lddres, int dres_acc) {
-    SY_TL_BEGIN(14);
-    __shared__ float red[kBlock * 2 * 8];
-    __shared__ float s_tot[2 * 64];
-    const int cpp = CS / T::kEPC;
-    const int rows = kBlock / cpp;
-    const int cc = threadIdx.x % cpp;
-    const int pr = threadIdx.x / cpp;
-    const int cb = blockIdx.z * CS;
-    const int c0 = cb + cc * T::kEPC;
-    const int seg = blockIdx.y;
-    {
-        const long long ro = (long long)seg * pixels;
-        const int ao = seg * C;
-        y += ro * ldy; da += ro * ldda; dy += ro * lddy; scale += ao; shift += ao; mean += ao; invstd += ao;
-        sums += (long long)seg * 2 * C;
-        if (dres != nullptr) dres += ro * lddres;
-    }
-    const bool live = pr < rows;
-    const long long base = (long long)blockIdx.x * rows * R + pr;
-    Chunk<T> yq[R], gq[R];
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        const long long pd = base + (long long)d * rows;
-        if (live && pd < pixels) { yq[d] = Chunk<T>::load(y + pd * ldy + c0); gq[d] = Chunk<T>::load(da + pd * ldda + c0); }
-    }
-    float sc[T::kEPC], sh[T::kEPC], mu[T::kEPC], is[T::kEPC], s0[T::kEPC], s1[T::kEPC];
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) {
-        const int c = live ? c0 + j : cb;
-        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
-        s0[j] = 0.0f; s1[j] = 0.0f;
-    }
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        if (live && base + (long long)d * rows < pixels) {
-#pragma unroll
-            for (int j = 0; j < T::kEPC; ++j) {
-                const float yy = T::to_f32(yq[d].e[j]);
-                const float dz = T::to_f32(gq[d].e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
-                s0[j] += dz;
-                s1[j] += dz * ((yy - mu[j]) * is[j]);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) {
-        red[(j * 2 + 0) * kBlock + threadIdx.x] = live ? s0[j] : 0.0f;
-        red[(j * 2 + 1) * kBlock + threadIdx.x] = live ? s1[j] : 0.0f;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < cpp * T::kEPC * 2; t += kBlock) {
-        const int kind = t & 1, j = (t >> 1) % T::kEPC, ch = (t >> 1) / T::kEPC;
-        float v = 0.0f;
-        for (int r = 0; r < rows; ++r) v += red[(j * 2 + kind) * kBlock + r * cpp + ch];
-        atomicAdd(sums + kind * C + cb + ch * T::kEPC + j, v);
-    }
-    // ---- the slice's workgroups meet: arrive, wait for the others, read the totals
-    unsigned* const arrive = tickets + ((long long)seg * gridDim.z + blockIdx.z) * 2;
-    sy_wait_vmcnt<0>();                                   // this thread's atomics have been performed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sy_ticket_take(arrive);
-        sy_spin_until_ge(arrive, gridDim.x);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 2 * CS; t += kBlock) s_tot[t] = sy_load_agent(sums + (t / CS) * C + cb + (t % CS));
-    __syncthreads();
-    if (threadIdx.x == 0 && sy_ticket_take(arrive + 1) == gridDim.x - 1u) {       // last to depart: everybody has read the totals
-        sy_ticket_reset(arrive);
-        sy_ticket_reset(arrive + 1);
-    }
-    if (blockIdx.x == 0 && dgamma != nullptr) {
-        const bool atomics = gridDim.y > 1 || (dres_acc & 2);
-        for (int c = threadIdx.x; c < CS; c += kBlock) {
-            if (atomics) { atomicAdd(dbeta + cb + c, s_tot[c]); atomicAdd(dgamma + cb + c, s_tot[CS + c]); }
-            else { dbeta[cb + c] += s_tot[c]; dgamma[cb + c] += s_tot[CS + c]; }
-        }
-    }
-    if (!live) return;
-    // the apply below recomputes dz from the PACKED chunks: laundering them keeps hipcc from carrying every unpacked float of the
-    // reduction across the wait (registers decide how many rows a thread can hold)
-#ifndef SY_EMU
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        uint4 a, b;
-        __builtin_memcpy(&a, yq[d].e, 16);
-        __builtin_memcpy(&b, gq[d].e, 16);
-        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-        __builtin_memcpy(yq[d].e, &a, 16);
-        __builtin_memcpy(gq[d].e, &b, 16);
-    }
-#endif
-    const float inv_m = 1.0f / (float)pixels;
-    float gi[T::kEPC], m0[T::kEPC], m1[T::kEPC];
-#pragma unroll
-    for (int j = 0; j < T::kEPC; ++j) {
-        gi[j] = gamma[c0 + j] * is[j];
-        m0[j] = s_tot[cc * T::kEPC + j] * inv_m;
-        m1[j] = s_tot[CS + cc * T::kEPC + j] * inv_m;
-    }
-#pragma unroll
-    for (int d = 0; d < R; ++d) {
-        const long long pix = base + (long long)d * rows;
-        if (pix >= pixels) continue;
-        Chunk<T> o;
-#pragma unroll
-        for (int j = 0; j < T::kEPC; ++j) {
-            const float yy = T::to_f32(yq[d].e[j]);
-            const float dz = T::to_f32(gq[d].e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
-            o.e[j] = T::from_f32(gi[j] * (dz - m0[j] - (yy - mu[j]) * is[j] * m1[j]));
-        }
-        o.store(dy + pix * lddy + c0);
-        if (dres != nullptr) {
-            typename T::elem* dst = dres + pix * lddres + c0;
-            Chunk<T> gv = gq[d];
-            if (dres_acc & 1) {
-                Chunk<T> r = Chunk<T>::load(dst);
-#pragma unroll
-                for (int j = 0; j < T::kEPC; ++j) gv.e[j] = T::from_f32(T::to_f32(gv.e[j]) + T::to_f32(r.e[j]));
-            }
-            gv.store(dst);
-        }
-    }
-    SY_TL_END();
-}
-
 inline bool chunk_rows_ok(int C, int e) { const int cpp = C / e; return cpp >= 1 && cpp <= kBlock; }
 
 inline int env_cap(const char* name, int dflt) {          // tuning knob (tools/): workgroups per launch of the row kernels
@@ -1037,59 +892,6 @@ extern "C" int sy_bn_finalize_apply(const float* sum, const float* sqsum, int co
                                        stream, sum, sqsum, copies, count, gamma, beta, eps, scale, shift, mean, invstd,
                                        (const typename T::elem*)y, ldy, (const typename T::elem*)res, ldr,
                                        (typename T::elem*)out, ldo, (long long)pixels, C, CS));
-}
-
-/* see the header */
-extern "C" int sy_bn_silu_bwd_fused(const void* y, int ldy, const void* da, int ldda, const float* scale, const float* shift,
-                                    const float* mean, const float* invstd, const float* gamma, float* sums, uint32_t* tickets,
-                                    void* dy, int lddy, int64_t pixels, int C, float* dgamma, float* dbeta, void* dres, int lddres,
-                                    int dres_accumulate, int dtype, int nseg, void* stream) {
-    if (y == nullptr || da == nullptr || sums == nullptr || tickets == nullptr || dy == nullptr || pixels <= 0 || C <= 0 || nseg < 1)
-        return SY_ERR_ARG;
-    if ((dgamma == nullptr) != (dbeta == nullptr)) return SY_ERR_ARG;
-    if (dtype < SY_DT_BF16 || dtype > SY_DT_F32) return SY_ERR_ARG;
-    const int e = epc_of(dtype);
-    if (C % e || ldy % e || ldda % e || lddy % e || (dres != nullptr && lddres % e)) return SY_ERR_UNSUPPORTED;
-    int CS = 0;
-    for (int c = (64 / e) * e; c >= e; c -= e)
-        if (c <= C && C % c == 0 && kBlock % (c / e) == 0) { CS = c; break; }
-    if (CS == 0) return SY_ERR_UNSUPPORTED;
-    const int nsl = C / CS, rows = kBlock / (CS / e);
-    // Every workgroup of the launch must be resident at once (they wait for each other), and so must the workgroups of any OTHER
-    // launch of this kernel that runs at the same time on another stream (the two frame chains of the backward pass): two partially
-    // resident waiting launches would hold each other's slots for ever.  The kernel is built for two workgroups per CU (launch bound:
-    // <= 256 registers per lane, 16.5 KB of LDS, < 100 SGPRs: the register file admits two 256-thread workgroups per CU whatever else
-    // has drained), so the chip holds 2 x CUs of them and a launch takes at most 2 x CUs / SY_BN_FUSED_SHARE workgroups — 256 on the
-    // MI355X at the default share of 2.  Every OTHER kernel of the step finishes without waiting for anybody, so the slots it holds
-    // always come free.  The largest grid (smallest piece per thread) that fits wins.
-#ifdef SY_EMU
-    const long long cap = 64;                                      // one OS thread per workgroup
-#else
-    static sy_dev_once cus_done;
-    static std::atomic<int> cus_cached{0};
-    if (cus_done.need()) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        cus_cached.store(cus);
-        cus_done.mark();
-    }
-    static const int share = env_cap("SY_BN_FUSED_SHARE", 2);
-    const long long cap = 2LL * cus_cached.load() / share;
-#endif
-    auto blocks = [&](int r) { return ((pixels + (long long)rows * r - 1) / ((long long)rows * r)) * nseg * nsl; };
-#define SY_FUSED(RR)                                                                                                          \
-    SY_DISPATCH_DTYPE(dtype, SY_LAUNCH_RESIDENT((bn_silu_bwd_fused_kernel<T, RR>),                                            \
-                                                dim3((unsigned)((pixels + (long long)rows * RR - 1) / ((long long)rows * RR)), nseg, nsl), \
-                                                dim3(kBlock), 0, stream, (const typename T::elem*)y, ldy, (const typename T::elem*)da,    \
-                                                ldda, scale, shift, mean, invstd, gamma, sums, (unsigned*)tickets,            \
-                                                (typename T::elem*)dy, lddy, (long long)pixels, C, CS, dgamma, dbeta,          \
-                                                (typename T::elem*)dres, lddres, dres_accumulate))
-    if (blocks(4) <= cap) { SY_FUSED(4); }
-    if (blocks(8) <= cap) { SY_FUSED(8); }
-    if (blocks(12) <= cap) { SY_FUSED(12); }
-    if (blocks(16) <= cap) { SY_FUSED(16); }          // 241 registers per lane (20 rows spill within the two-per-CU bound)
-#undef SY_FUSED
-    return SY_ERR_UNSUPPORTED;                 // too large for one resident launch: the two-pass kernels take it
 }
 
 extern "C" int sy_bn_silu_bwd_reduce(const void* y, int ldy, const void* da, int ldda, const float* scale,

@@ -417,25 +417,6 @@ def bn_silu_bwd_apply(y, da, scale, shift, mean, invstd, gamma, sums, dy, dgamma
                                           stream_of(y.buf)), "sy_bn_silu_bwd_apply")
 
 
-def bn_silu_bwd_fused(y, da, scale, shift, mean, invstd, gamma, sums, tickets, dy, dgamma=None, dbeta=None, nseg=1,
-                      dres=None, dres_accumulate=False, atomic_param_grads=False):
-    """bn_silu_bwd_reduce + bn_silu_bwd_apply in one launch (sy_bn_silu_bwd_fused).  sums: zero fp32 [nseg * 2 * C] (at least);
-    tickets: zeroed int32 [nseg * slices * 2] counters of this layer.  Returns False when the tensor is too large for a resident
-    launch — nothing was launched, the caller runs the two passes."""
-    assert dres is None or (dres.C == y.C and dres.pixels == y.pixels)
-    assert tickets.dtype == torch.int32 and tickets.numel() >= nseg * 2 * max(1, y.C // 8)
-    rc = _lib.lib().sy_bn_silu_bwd_fused(y.ptr(), y.ld, da.ptr(), da.ld, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                                         invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(), tickets.data_ptr(), dy.ptr(), dy.ld,
-                                         y.pixels // nseg, y.C, _p(dgamma), _p(dbeta), None if dres is None else dres.ptr(),
-                                         0 if dres is None else dres.ld,
-                                         (1 if dres_accumulate else 0) | (2 if atomic_param_grads else 0), y.dtype, nseg,
-                                         stream_of(y.buf))
-    if rc == _lib.SY_ERR_UNSUPPORTED:
-        return False
-    check(rc, "sy_bn_silu_bwd_fused")
-    return True
-
-
 def head_decode(out, hw=None, strides=None, boxes=True, obj_sigmoid=False, corners=False):
     """sy_head_decode in place on out [B, A, 5+nc] fp32 contiguous: boxes -> (xy + grid) * stride, exp(wh) * stride over the
     levels hw = [(h, w)] with `strides`; obj_sigmoid -> sigmoid of column 4; corners -> (cx, cy, w, h) to (x1, y1, x2, y2)."""

@@ -69,11 +69,6 @@ def _schedule_bn_caps():
     return ops.bn_grid_caps(bwd_apply=BN_BAPPLY_BLOCKS_SCHEDULED)["bwd_reduce"]
 
 
-# Round 6: BatchNorm.SiLU backward of a frame chain's layer as ONE launch (sy_bn_silu_bwd_fused: the workgroups of a channel slice
-# hold their piece of both tensors in registers across a rendezvous) where the tensor fits a grid that is resident at once; the
-# two frame chains are the only streams that run it (the library bounds a launch to half the chip's guaranteed residency).
-# "1": on; "0": the two passes (A/B timing).
-BN_BWD_FUSED = __import__("os").environ.get("STREAMYOLO_BN_BWD_FUSED", "0") != "0"
 # Measured and REMOVED in round 4 (profiles/r04/README.md): BatchNorm finalisation by the producing convolution's last workgroup
 # (every statistics launch got 8-13 us slower — each workgroup waits for its own atomics and a ticket round trip — the l step
 # 22.6-23.9 vs 22.3-23.0 ms at 2 ... 32 replicas) and BatchNorm backward as one resident launch whose workgroups wait for each
@@ -688,25 +683,9 @@ class TrainPlan:
         g, b_ = self.cache.bn[id(op.mod)]
         return g, b_, bn.eps, mom
 
-    def _tickets(self, n):
-        """n zeroed int32 counters (self-resetting arrival words of the fused BatchNorm backward)."""
-        if getattr(self, "_tk", None) is None or self._tk_off + n > self._tk.numel():
-            self._tk, self._tk_off = torch.zeros(max(1 << 16, n), dtype=torch.int32, device=self.device), 0
-        tk = self._tk[self._tk_off:self._tk_off + n]
-        self._tk_off += n
-        return tk
-
-    def _bn_bwd(self, op, y, da, aff, gamma, bsum, dy, dgamma, dbeta, nseg=1, dres=None, acc=False, atomic=False, chain=False):
+    def _bn_bwd(self, op, y, da, aff, gamma, bsum, dy, dgamma, dbeta, nseg=1, dres=None, acc=False, atomic=False):
         """BatchNorm.SiLU backward of one launch unit: the reduce pass (unless the data gradient that produced `da` carried it:
-        op.bnr_by), then the apply pass — or, on a frame chain (`chain`) with BN_BWD_FUSED, both as one resident launch where the
-        tensor allows it."""
-        if chain and BN_BWD_FUSED and getattr(op, "bnr_by", None) is None and self.dtype != ops.DT_F32:
-            tk = op._tiles.get("bwdtk")
-            if tk is None:
-                tk = op._tiles["bwdtk"] = self._tickets(nseg * 2 * max(1, y.C // 8))
-            if ops.bn_silu_bwd_fused(y, da, *aff, gamma, bsum, tk, dy, dgamma, dbeta, nseg=nseg, dres=dres, dres_accumulate=acc,
-                                     atomic_param_grads=atomic):
-                return
+        op.bnr_by), then the apply pass."""
         fused = getattr(op, "bnr_by", None) is not None
         if not fused:
             ops.bn_silu_bwd_reduce(y, da, *aff, bsum, nseg=nseg)
@@ -1179,7 +1158,7 @@ class TrainPlan:
             dres, acc = (None, False) if op.res is None else G.target(op.res)
             scale, shift, mean, invstd = op.aff
             self._bn_bwd(op, op.yraw, G.view(op.y), (scale, shift, mean, invstd), gamma, op.bsum, dyr, dgamma, dbeta,
-                         dres=dres, acc=acc, atomic=True, chain=True)
+                         dres=dres, acc=acc, atomic=True)
         self._chain = 0
         self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot, chains=(0, 2))
         if a.need_dx:
