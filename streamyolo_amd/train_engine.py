@@ -73,6 +73,12 @@ def _schedule_bn_caps():
 # (every statistics launch got 8-13 us slower — each workgroup waits for its own atomics and a ticket round trip — the l step
 # 22.6-23.9 vs 22.3-23.0 ms at 2 ... 32 replicas) and BatchNorm backward as one resident launch whose workgroups wait for each
 # other (parity-green on the MI355X, the step 24.58 vs 22.70 ms: spinning workgroups hold the CUs the other chains need).
+# Round 6 built that launch AGAIN (commit 13db7f2, reverted: sy_bn_silu_bwd_fused — rows held in registers across a per-channel-slice
+# rendezvous, the largest piece per thread that keeps a launch within half the chip's guaranteed residency, one lane per workgroup
+# polling every ~0.5 us, bounded spin; kernel + model parity green on the MI355X) on the two frame chains: 20.83-20.88 vs 19.96 ms with
+# the 38x60 / 19x30 layers fused (114 launches), 20.75-20.89 vs 20.76-20.81 ms with only the 19x30 layers (same-box alternating runs,
+# profiles/r06 stages i, j) although tools/ablate_step.py prices the reduce launches at 1.77 ms of the step.  Removing launches from
+# the chains does not pay here; a launch that holds CUs while it waits costs more than the second read it saves.
 
 class _GradSpace:
     """Gradient mirrors of activation buffers + first-write / accumulate bookkeeping per channel range."""
