@@ -282,6 +282,22 @@ HEAD_BWD_CHAINS = os.environ.get("STREAMYOLO_HEAD_BWD_CHAINS", "1") != "0"
 # Round 5, forward: a head level (+ its two DFP fusion convs) starts as soon as its PAN output exists in both frames, on a third
 # chain beside the rest of the frame chains (TrainPlan._early_levels).  "0": the levels behind the join of the frame chains.
 HEAD_EARLY = os.environ.get("STREAMYOLO_HEAD_EARLY", "1") != "0"
+# Round 6: stream-wait packets on the frame chains are not free.  A timing experiment that dropped every ring-slot event of the
+# backward pass (results invalid, profiles/r06 stage u) ran the l step in 20.39 instead of 21.09 ms, dropping the chain -> weight-gradient
+# dependencies on top 20.12-20.17: each hipStreamWaitEvent is a barrier packet the chain's queue stops at (~3 us), signalled or not,
+# and a frame chain issued two of them per layer.  In the split backward a chain's half of a raw-gradient slot is only ever rewritten
+# by the SAME chain (stream order) — its own "slot done" event (STREAMYOLO_CHAIN_SLOT_DONE=1 restores it) made the OTHER chain wait for
+# nothing — and the weight gradients retire in order on their streams, so a chain needs to wait for them once per STREAMYOLO_SLOT_BATCH
+# layers (on the newest slot of each weight-gradient stream), not once per layer.
+CHAIN_SLOT_DONE = os.environ.get("STREAMYOLO_CHAIN_SLOT_DONE", "0") != "0"
+# Measured (profiles/r06 stage v, same box): both events per layer (rounds 3-5) 20.61 / 20.64 ms; no chain-side event 20.20 / 20.18;
+# + a wait every 2 / 3 / 4 layers 20.18 / 20.12, 20.11 / 20.14 (3 or 4 with a ring of 12: 20.12 / 20.10) -> default 3.
+SLOT_BATCH = max(1, int(os.environ.get("STREAMYOLO_SLOT_BATCH", "3")))
+# ... and the chain -> weight-gradient dependencies (one event record per frame chain and layer, one wait per weight-gradient stream):
+# without them — results invalid — the step was another 0.3 ms shorter (stage x).  The split backward therefore issues its weight
+# gradients in batches of STREAMYOLO_WGRAD_DEFER layers behind ONE event per chain ("depn": both weight-gradient streams wait for the
+# same record); batches are flushed in front of every gradient-bucket mark and at the end of the pass.
+WGRAD_DEFER = max(1, int(os.environ.get("STREAMYOLO_WGRAD_DEFER", "3")))
 DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "1") != "0"
 WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD_STREAMS", "2")) if DUAL_WGRAD else 1))]
 # (Weight gradients on streams of their own instead of sharing stream 1 with the forward pass's support-frame chain, with or without
@@ -339,12 +355,13 @@ class TrainPlan:
     #  reads every replica in every workgroup; 32 stays the fp32 default when the exact one-row-per-workgroup layout is switched off)
     STAT_COPIES = int(os.environ.get("STREAMYOLO_STAT_COPIES", "0"))     # 0 = by compute dtype: 4 (16-bit) / 32 (fp32)
     WGRAD_WS_BYTES = 256 << 20   # split-K slabs of sy_conv2d_wgrad
-    # raw-gradient scratch slots: the weight gradient of layer i (side streams) overlaps BatchNorm backward / data gradient of the
-    # layers behind it, and a frame chain that wants a slot back waits for the weight gradient that last read it.  5 vs 3: -0.1 ms
-    # per l step (round 2); with round 5's shorter frame chains the weight-gradient streams trail further behind: 9 vs 5 21.19-21.21
-    # vs 21.37-21.43 ms and 20.85-21.00 vs 21.02-21.08 on another box (7: half of it; 12 / 16 / 24: the same as 9 — profiles/r05
-    # stages zi, zj).  A slot is the largest raw gradient of the plan (l, 8 pairs: 295 MB).
-    RING = int(os.environ.get("STREAMYOLO_RING", "9"))
+    # raw-gradient scratch: the weight gradient of layer i (side streams) overlaps BatchNorm backward / data gradient of the layers
+    # behind it.  Rounds 2-5 recycled a RING of slots (5, then 9 of the largest raw gradient: a frame chain that wants a slot back waits
+    # for the weight gradient that last read it) — round 6 found that the WAITING is not the cost, the stream-wait packets are: with a
+    # buffer per layer (RING = 0: ~4 GB for l at 8 pairs of the GPU's 288, no slot events at all) the l step is 0.24 ms shorter than
+    # with the ring and the cheapest event schedule, 0.7 ms (8 pairs) / 0.9 ms (4 pairs) shorter than rounds 3-5's (profiles/r06
+    # stages u-w).  RING > 0 keeps the ring (memory-tight hosts, A/B timing).
+    RING = int(os.environ.get("STREAMYOLO_RING", "0"))
     STREAMS = int(os.environ.get("STREAMYOLO_STREAMS", "2"))   # 1: everything on the caller's stream
     TAPE_ON_CPU = True           # the SIMT-emulator test runs replay launch tapes too (same code path as the GPU)
 
@@ -525,13 +542,16 @@ class TrainPlan:
         # allocation, so a single flat ring (RING x ~300 MB for l at 8 pairs) must not grow past 2 GiB
         if self.pool is not None:
             self.wgrad_ws = self.pool.shared_scratch("wgrad_ws", self.WGRAD_WS_BYTES, self.device)
-            slots = [self.pool.shared_scratch("dyraw_ring_%d" % i, ring_bytes, self.device) for i in range(self.RING)]
+            slots = [self.pool.shared_scratch("dyraw_ring_%d" % i, ring_bytes, self.device) for i in range(max(self.RING, 0))]
             self._scratch_gen = self.pool.scratch_gen
         else:
             self.wgrad_ws = torch.empty(self.WGRAD_WS_BYTES, dtype=torch.uint8, device=self.device)
-            slots = [torch.empty(ring_bytes, dtype=torch.uint8, device=self.device) for _ in range(self.RING)]
+            slots = [torch.empty(ring_bytes, dtype=torch.uint8, device=self.device) for _ in range(max(self.RING, 0))]
             self._scratch_gen = 0
         self.dyraw_ring = [t[:self.max_raw * esz].view(self.tdtype) for t in slots]
+        # RING == 0: no reuse at all — every layer's raw gradient gets a buffer of its own (allocated at its first use, ~4 GB for l at
+        # 8 pairs of the GPU's 288), so no chain ever waits for a weight gradient and no ring-slot event exists
+        self.dyraw_own = []
         self.wgrad_ws_by = {WGRAD_STREAMS[0]: self.wgrad_ws}       # WGRAD_STREAMS[0] == 1: the prediction convs' wgrads run there too
         for k in WGRAD_STREAMS[1:]:                              # one split-K workspace per weight-gradient stream
             self.wgrad_ws_by[k] = (self.pool.shared_scratch("wgrad_ws%d" % k, self.WGRAD_WS_BYTES, self.device)
@@ -544,6 +564,7 @@ class TrainPlan:
         hold raw pointers into buffers that go back to the allocator with this object) and break the plan <-> gradient-space reference cycle so that the buffers are freed NOW,
         not at some later cyclic-GC pass (measured: without this, cycling through five sizes doubled the allocated memory)."""
         self.programs.clear()
+        self.dyraw_own = []
         self.grads.py = None
         self.grads.mirror.clear()
         self.on_bucket = None
@@ -946,6 +967,8 @@ class TrainPlan:
             self.bucket_at.setdefault(r, []).append(k)
 
     def _bucket_marks(self, pos):
+        if self.bucket_at.get(pos) and getattr(self, "_pend", None):
+            self._flush_wgrads()                                 # a bucket is final only behind the weight gradients that fill it
         for k in self.bucket_at.get(pos, ()):
             self._mark("bucket", k)
 
@@ -956,6 +979,8 @@ class TrainPlan:
             if op.kind == "conv":
                 op.bnr_by = None
         self.ring_i = 0
+        self._split_j = 0                                        # layers issued by _conv_pair_backward_split in this pass
+        self._pend = []                                          # weight gradients of the split backward waiting for their batch
         nf = self.n_frame_ops
         if self.head is None:                                    # backbone alone: the feature gradients come from the caller
             for i, f in enumerate(self.fused):
@@ -1004,6 +1029,9 @@ class TrainPlan:
                         elif op.kind == "spp":
                             ops.spp_pool_bwd(G.view(op.v), op.argmax)
             self._bucket_marks(pos)
+        if self._pend:
+            self._chain = 0
+            self._flush_wgrads()
         if split:
             self._mark("cur", 0)
             self._mark("dep", (2, 0))
@@ -1022,10 +1050,22 @@ class TrainPlan:
         stream behind its launch, and the chain that overwrites the slot next waits ("acquire_cur") for every one of those
         events that lives on ANOTHER stream — several chains share the ring (head levels 1-2 / the support frame on chain 2),
         so the next writer is not necessarily on the stream of the previous data gradient."""
+        if self.RING <= 0:
+            self._slot = None
+            return self._own_buffer(numel)
         self.ring_i = (self.ring_i + 1) % self.RING
         self._slot = self.ring_i
         self._mark("acquire_cur", self._slot)
         return self.dyraw_ring[self._slot][:numel]
+
+    def _own_buffer(self, numel):
+        """RING == 0: the raw-gradient buffer of the ring_i-th convolution of the backward walk (the walk is the same every pass)."""
+        i = self.ring_i
+        self.ring_i += 1
+        if i == len(self.dyraw_own):
+            self.dyraw_own.append(torch.empty(numel, dtype=self.tdtype, device=self.device))
+        assert self.dyraw_own[i].numel() >= numel
+        return self.dyraw_own[i][:numel]
 
     def _wgrad_stream(self, fixed=None):
         """Stream the next weight gradient goes to: round robin over WGRAD_STREAMS (1, 3, ...)."""
@@ -1034,10 +1074,16 @@ class TrainPlan:
         self._wg_flip = (self._wg_flip + 1) % len(WGRAD_STREAMS)
         return WGRAD_STREAMS[self._wg_flip]
 
-    def _on_side(self, fn, slot=None, chains=None, stream=None):
+    def _on_side(self, fn, slot=None, chains=None, stream=None, defer=False):
         """fn's launches (a weight gradient + fold) go to a weight-gradient stream, after everything issued so far on the
-        chain(s) that produced its raw gradient; the ring slot is marked free behind them."""
+        chain(s) that produced its raw gradient; the ring slot is marked free behind them.  defer (split backward): the launches
+        are queued and issued with the next batch (_flush_wgrads) behind one event per chain."""
         chains = (self._chain,) if chains is None else chains
+        if defer and WGRAD_DEFER > 1:
+            self._pend.append((fn, slot, chains, stream))
+            if len(self._pend) >= WGRAD_DEFER:
+                self._flush_wgrads()
+            return
         w = self._wgrad_stream(stream)
         for k in chains:
             self._mark("dep", (k, w))
@@ -1047,6 +1093,24 @@ class TrainPlan:
         self._wg_stream = 1
         if slot is not None:
             self._mark("slot_done", slot)
+        self._mark("cur", self._chain)
+
+    def _flush_wgrads(self):
+        """Issue the queued weight gradients: ONE event per producing chain, every weight-gradient stream of the batch waits for it."""
+        if not self._pend:
+            return
+        items = [(fn, slot, chains, self._wgrad_stream(stream)) for fn, slot, chains, stream in self._pend]
+        self._pend = []
+        ws = sorted({w for _, _, _, w in items})
+        for k in sorted({k for _, _, chains, _ in items for k in chains}):
+            self._mark("depn", (k, ws))
+        for fn, slot, _, w in items:
+            self._mark("cur", w)
+            self._wg_stream = w
+            fn()
+            if slot is not None:
+                self._mark("slot_done", slot)
+        self._wg_stream = 1
         self._mark("cur", self._chain)
 
     def _ws(self):
@@ -1143,7 +1207,8 @@ class TrainPlan:
             ops.conv2d(dy2, self.cache.conv_weight(a.mod, transpose=True), dxa.pair(), a.k, a.stride,
                        mode=CONV_DGRAD, accumulate=acca, tile=t,
                        wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None)
-            self._mark("slot_done", slot)                            # ... and this chain's reader of the slot (see _scratch)
+            if slot is not None:
+                self._mark("slot_done", slot)                        # ... and this chain's reader of the slot (see _scratch)
 
     def _conv_pair_backward_split(self, a, b2):
         """Layer i of the two frames as two chains: BatchNorm backward + data gradient of the current frame on stream 0, of the
@@ -1151,22 +1216,37 @@ class TrainPlan:
         data gradient), the weight gradient ONCE over both frames on stream 1 behind both chains' raw gradients."""
         G = self.grads
         N, H, W, C = a.y.N, a.y.H, a.y.W, a.y.C
-        self.ring_i = (self.ring_i + 1) % self.RING
-        slot = self.ring_i
-        full = self.dyraw_ring[slot][:2 * N * H * W * C].view(2 * N, H, W, C)
+        if self.RING <= 0:
+            slot, full = None, self._own_buffer(2 * N * H * W * C).view(2 * N, H, W, C)
+        else:
+            self.ring_i = (self.ring_i + 1) % self.RING
+            slot = self.ring_i
+            full = self.dyraw_ring[slot][:2 * N * H * W * C].view(2 * N, H, W, C)
         dy2 = View(full, 2 * N, H, W, C)
         dys = (View(full[:N], N, H, W, C), View(full[N:], N, H, W, C))
         gamma = self._bn_params(a)[0]
         dgamma, dbeta = self._bn_grads(a)
+        j, K = self._split_j, max(1, min(SLOT_BATCH, self.RING - 2))
+        self._split_j += 1
+        # the first RING layers of the split phase reuse slots of the head / fusion ops (other streams): per-layer waits; afterwards a
+        # chain waits once per K layers, for the newest slot of each weight-gradient stream among the K it is about to overwrite (the
+        # weight gradients of consecutive layers alternate between the streams and retire in order on each)
+        batched = K > 1 and j >= self.RING
         for k, (op, dyr) in enumerate(zip((a, b2), dys)):            # BatchNorm / SiLU backward, frame by frame
             self._mark("cur", 2 * k)
-            self._mark("acquire_cur", slot)                          # the wgrad that last read this slot has retired
+            if slot is None:
+                pass                                                 # a buffer of its own: nobody to wait for
+            elif not batched:
+                self._mark("acquire_cur", slot)                      # the wgrad that last read this slot has retired
+            elif (j - self.RING) % K == 0:
+                for m in range(min(K, len(WGRAD_STREAMS))):
+                    self._mark("acquire_cur", (slot + K - 1 - m) % self.RING)
             dres, acc = (None, False) if op.res is None else G.target(op.res)
             scale, shift, mean, invstd = op.aff
             self._bn_bwd(op, op.yraw, G.view(op.y), (scale, shift, mean, invstd), gamma, op.bsum, dyr, dgamma, dbeta,
                          dres=dres, acc=acc, atomic=True)
         self._chain = 0
-        self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot, chains=(0, 2))
+        self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot, chains=(0, 2), defer=True)
         if a.need_dx:
             t = a.tile("dgrad")
             for k, (op, dyr) in enumerate(zip((a, b2), dys)):
@@ -1179,7 +1259,8 @@ class TrainPlan:
                            accumulate=acc, tile=t,
                            wfrag=self.cache.conv_weight_frag(a.mod, transpose=True) if t >= ops.TILE_WR else None,
                            bn_reduce=None if pre is None else (pre.yraw, pre.aff[0], pre.aff[1], pre.bsum))
-                self._mark("slot_done", slot)                        # this chain's reader of its half of the slot
+                if CHAIN_SLOT_DONE and slot is not None:
+                    self._mark("slot_done", slot)                    # this chain's reader of its half of the slot
         self._mark("cur", 0)
 
     def _conv_backward(self, op):
@@ -1195,7 +1276,8 @@ class TrainPlan:
             ops.conv2d(dyraw, self.cache.conv_weight(op.mod, transpose=True), dx, op.k, op.stride,
                        mode=CONV_DGRAD, accumulate=acc, tile=t,
                        wfrag=self.cache.conv_weight_frag(op.mod, transpose=True) if t >= ops.TILE_WR else None)
-            self._mark("slot_done", slot)                            # ... and this chain's reader of the slot (see _scratch)
+            if slot is not None:
+                self._mark("slot_done", slot)                        # ... and this chain's reader of the slot (see _scratch)
 
     # ------------------------------------------------------------------------------------------------
     def profile(self, x, targets, iters=2, detail=False):

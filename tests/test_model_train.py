@@ -132,7 +132,8 @@ def test_launch_tape_replay_matches_direct_step(backend, golden_dir):
 #       ~8x below bf16 (2^-8), which a defect common to the 16-bit code paths (staging, epilogues, g-space fusion) would
 #       break; bounds: fp16 median <= 3x measured, bf16 / fp16 ratio inside [2.5, 25];
 #   (3) per-kernel 16-bit parity on bf16-rounded operands (tests/test_kernels_*.py, 2e-2).
-S_TRAIN_TOL = {"fp32": (1e-3, 2e-3), "fp16": (3e-3, None), "bf16": (3e-2, None)}       # (loss, worst per-parameter rel L2)
+# (loss, worst per-parameter rel L2); fp16 loss measured 1.0e-3 ... 3.5e-3 depending on the tuner's tile choices (summation order): 2x
+S_TRAIN_TOL = {"fp32": (1e-3, 2e-3), "fp16": (7e-3, None), "bf16": (3e-2, None)}
 S_FP16_MEDIAN_BOUND = 0.30         # 3x the measured fp16 median (profiles/r02 pytest log)
 
 
@@ -473,7 +474,7 @@ def test_frames_as_stream_parallel_chains_match_the_paired_launches(backend, gol
         assert _rel(rb[k], ra[k]) < (1e-6 if str(backend) == "cpu" else 1e-5), k
 
 
-@pytest.mark.parametrize("ring", [3, 9])
+@pytest.mark.parametrize("ring", [3, 9, 0])             # 0: no ring — a raw-gradient buffer per layer, no slot events at all (round 6)
 def test_raw_gradient_ring_depth_does_not_change_the_step(backend, ring, monkeypatch):
     """TrainPlan.RING raw-gradient slots (9 by default, round 5): a frame chain that wants a slot back waits for the weight gradient
     and the data gradients that last read it ("acquire_cur" / "slot_done" in the launch tape).  With 3 slots every layer reuses a
@@ -514,6 +515,53 @@ def test_raw_gradient_ring_depth_does_not_change_the_step(backend, ring, monkeyp
     tol = 1e-5 if str(backend) == "cpu" else 1e-3
     for k in g0:
         assert _rel(g1[k], g0[k]) < tol, k
+
+
+@pytest.mark.parametrize("ring", [9])
+def test_frame_chains_wait_for_the_weight_gradients_once_per_batch_of_layers(backend, ring, monkeypatch):
+    """Round 6: in the split backward a frame chain records no "slot done" event of its own (its half of a raw-gradient slot is only
+    rewritten by itself) and waits for the weight gradients once per SLOT_BATCH layers (they retire in order on their streams) — the
+    recorded tape issues far fewer stream waits than the rounds 3-5 schedule (both events, every layer), and the replayed step's
+    gradients equal the single-stream step's either way."""
+    from streamyolo_amd import train_engine
+    from streamyolo_amd.train_engine import TrainPlan, TrainStep
+    monkeypatch.setattr(TrainPlan, "RING", ring)
+    monkeypatch.setattr(train_engine, "BWD_SPLIT_FRAMES", "1")
+    cfg = O.OracleConfig.named("nano")
+    sd = synth_state_dict(O.param_shapes(cfg), seed=0)
+    Hh, Ww = (32, 64) if str(backend) == "cpu" else (128, 192)
+    x = synth_frames(2, Hh, Ww, seed=5).to(backend)
+    lab, sup = synth_labels(2, Hh, Ww, cfg.num_classes, num_gt=3, seed=6)
+    targets = (lab.to(backend), sup.to(backend))
+    res, waits = {}, {}
+    for name, chain_ev, batch, serial in (("serial", False, 3, True), ("old", True, 1, False), ("new", False, 3, False)):
+        monkeypatch.setattr(train_engine, "CHAIN_SLOT_DONE", chain_ev)
+        monkeypatch.setattr(train_engine, "SLOT_BATCH", batch)
+        model = sy.build_model("nano")
+        model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        model = model.to(backend).train().set_compute_dtype("fp32")
+        model.head.use_l1 = True
+        st = TrainStep(model, graph=False)
+        plan = st._ensure(x)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        for _ in range(3):                                       # direct, recorded, replayed
+            model.load_state_dict(state0)
+            plan.force_serial = serial
+            out = st.step(x, targets)
+        names = {id(p): n for n, p in model.named_parameters()}
+        res[name] = (float(out["total_loss"]), {names[id(p)]: plan.gview[id(p)].clone().cpu() for p in plan.params})
+        if not serial:
+            tape = plan.programs["bwd"][1]
+            if str(backend) == "cpu":                            # no streams on the emulator: count on a replay over stand-in handles
+                import ctypes as C                               # (the kernels run again, synchronously; the results above are copies)
+                tape.replay(C.c_void_p(1), C.c_void_p(2), more=[C.c_void_p(3), C.c_void_p(4), C.c_void_p(5)])
+            waits[name] = tape.counters()[1]
+    assert 0 < waits["new"] < 0.7 * waits["old"], waits
+    tol = 1e-5 if str(backend) == "cpu" else 1e-3
+    for name in ("old", "new"):
+        assert abs(res[name][0] - res["serial"][0]) / abs(res["serial"][0]) < 1e-5
+        for k in res["serial"][1]:
+            assert _rel(res[name][1][k], res["serial"][1][k]) < tol, (name, k)
 
 
 def test_backward_tape_joins_every_weight_gradient_stream(backend, monkeypatch):
