@@ -416,10 +416,8 @@ enum { SY_TAPE_END = -1, SY_TAPE_LAUNCH = 0,
        SY_TAPE_DEP = 10,     /* stream (arg >> 4) records an event, stream (arg & 15) waits for it            */
        SY_TAPE_SLOT_DONE = 11,   /* event on the CURRENT stream = "this stream's readers of ring slot `arg` are done"; a slot keeps
                                     one such event PER STREAM, the first one after an acquisition starts a new set      */
-       SY_TAPE_ACQUIRE_CUR = 12, /* the CURRENT stream waits for every event of slot `arg`'s set recorded on ANOTHER stream
-                                    (the set stays: several chains may acquire their part of one slot)                  */
-       SY_TAPE_DEPN = 13         /* stream (arg >> 8) records ONE event, every stream whose bit is set in (arg & 255) waits for it
-                                    (a batch of weight gradients on several streams behind one mark of a frame chain)    */ };
+       SY_TAPE_ACQUIRE_CUR = 12  /* the CURRENT stream waits for every event of slot `arg`'s set recorded on ANOTHER stream
+                                    (the set stays: several chains may acquire their part of one slot)                  */ };
 SY_API void* sy_tape_begin(void);
 SY_API int sy_tape_mark(int kind, int arg);
 SY_API void* sy_tape_end(void);

@@ -223,10 +223,10 @@ def replay(tape, stream):
 # runs, at gradient-bucket marks.
 TAPE_END, TAPE_LAUNCH, TAPE_SIDE, TAPE_FORK, TAPE_SIDE_NW, TAPE_MAIN, TAPE_ACQUIRE, TAPE_JOIN, TAPE_BREAK, TAPE_BUCKET = \
     -1, 0, 1, 2, 3, 4, 5, 6, 7, 8
-TAPE_CUR, TAPE_DEP, TAPE_SLOT_DONE, TAPE_ACQUIRE_CUR, TAPE_DEPN = 9, 10, 11, 12, 13
+TAPE_CUR, TAPE_DEP, TAPE_SLOT_DONE, TAPE_ACQUIRE_CUR = 9, 10, 11, 12
 TAPE_MARKS = {"side": TAPE_SIDE, "fork": TAPE_FORK, "side_nw": TAPE_SIDE_NW, "main": TAPE_MAIN, "acquire": TAPE_ACQUIRE,
               "join": TAPE_JOIN, "bucket": TAPE_BUCKET, "cur": TAPE_CUR, "dep": TAPE_DEP, "slot_done": TAPE_SLOT_DONE,
-              "acquire_cur": TAPE_ACQUIRE_CUR, "depn": TAPE_DEPN}
+              "acquire_cur": TAPE_ACQUIRE_CUR}
 
 
 class NativeTape:
@@ -253,8 +253,6 @@ class NativeTape:
     def mark(self, name, arg=None):
         if name == "dep":                                         # arg = (from, to)
             arg = arg[0] * 16 + arg[1]
-        elif name == "depn":                                      # arg = (from, (to, to, ...))
-            arg = arg[0] * 256 + sum(1 << int(b) for b in set(arg[1]))
         check(self._lib.sy_tape_mark(TAPE_MARKS[name], -1 if arg is None else int(arg)), "sy_tape_mark")
 
     def snippet(self, fn):

@@ -19,9 +19,6 @@
 //                 that produced it): the first SLOT_DONE after an acquisition starts a new set.
 //   ACQUIRE_CUR(s) the CURRENT stream waits for EVERY event of the slot's set that was recorded on another stream (the set stays:
 //                 several chains may acquire the same slot — each frame's half of it)
-//   DEPN(a, mask)  stream a records ONE event, every stream in the bit mask waits for it (arg = a * 256 + mask): a stream-wait is a
-//                 barrier packet its queue stops at (~3 us, signalled or not), and so is an event record — a frame chain that feeds
-//                 a BATCH of weight gradients on two streams pays one record instead of one per layer and stream (round 6)
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
 
@@ -89,8 +86,7 @@ extern "C" void* sy_tape_begin(void) {
 }
 
 extern "C" int sy_tape_mark(int kind, int arg) {
-    if (g_rec == nullptr || kind <= SY_TAPE_LAUNCH || kind > SY_TAPE_DEPN) return SY_ERR_ARG;
-    if (kind == SY_TAPE_DEPN && (arg < 0 || (arg >> 8) >= kMaxStreams || (arg & 255) == 0)) return SY_ERR_ARG;
+    if (g_rec == nullptr || kind <= SY_TAPE_LAUNCH || kind > SY_TAPE_ACQUIRE_CUR) return SY_ERR_ARG;
     if ((kind == SY_TAPE_MAIN || kind == SY_TAPE_ACQUIRE || kind == SY_TAPE_SLOT_DONE || kind == SY_TAPE_ACQUIRE_CUR) && arg >= kMaxSlots)
         return SY_ERR_ARG;
     if ((kind == SY_TAPE_SLOT_DONE || kind == SY_TAPE_ACQUIRE_CUR || kind == SY_TAPE_ACQUIRE || kind == SY_TAPE_CUR || kind == SY_TAPE_DEP) && arg < 0)
@@ -219,19 +215,6 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
                 void* const to = stream_of(e.arg & 15);
                 if (from == to) break;
                 wait(to, record(from));
-                break;
-            }
-            case SY_TAPE_DEPN: {
-                if (!two) break;
-                void* const from = stream_of(e.arg >> 8);
-                int ev = -1;
-                for (int b = 0; b < kMaxStreams; ++b) {
-                    if (!((e.arg >> b) & 1)) continue;
-                    void* const to = stream_of(b);
-                    if (to == from) continue;
-                    if (ev < 0) ev = record(from);
-                    wait(to, ev);
-                }
                 break;
             }
             case SY_TAPE_SLOT_DONE:

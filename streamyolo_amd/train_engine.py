@@ -293,11 +293,9 @@ CHAIN_SLOT_DONE = os.environ.get("STREAMYOLO_CHAIN_SLOT_DONE", "0") != "0"
 # Measured (profiles/r06 stage v, same box): both events per layer (rounds 3-5) 20.61 / 20.64 ms; no chain-side event 20.20 / 20.18;
 # + a wait every 2 / 3 / 4 layers 20.18 / 20.12, 20.11 / 20.14 (3 or 4 with a ring of 12: 20.12 / 20.10) -> default 3.
 SLOT_BATCH = max(1, int(os.environ.get("STREAMYOLO_SLOT_BATCH", "3")))
-# ... and the chain -> weight-gradient dependencies (one event record per frame chain and layer, one wait per weight-gradient stream):
-# without them — results invalid — the step was another 0.3 ms shorter (stage x).  The split backward therefore issues its weight
-# gradients in batches of STREAMYOLO_WGRAD_DEFER layers behind ONE event per chain ("depn": both weight-gradient streams wait for the
-# same record); batches are flushed in front of every gradient-bucket mark and at the end of the pass.
-WGRAD_DEFER = max(1, int(os.environ.get("STREAMYOLO_WGRAD_DEFER", "3")))
+# (The chain -> weight-gradient dependencies were sized the same way — 0.3 ms without them, stage x — but they are real dependencies,
+#  not packet overhead: issuing the split backward's weight gradients in batches of 2 ... 6 layers behind ONE event per chain bought
+#  nothing, 20.12-20.24 vs 20.11-20.12 ms, stage y; removed.)
 DUAL_WGRAD = os.environ.get("STREAMYOLO_DUAL_WGRAD", "1") != "0"
 WGRAD_STREAMS = [1, 3, 4, 5][:max(1, min(4, int(os.environ.get("STREAMYOLO_WGRAD_STREAMS", "2")) if DUAL_WGRAD else 1))]
 # (Weight gradients on streams of their own instead of sharing stream 1 with the forward pass's support-frame chain, with or without
@@ -967,8 +965,6 @@ class TrainPlan:
             self.bucket_at.setdefault(r, []).append(k)
 
     def _bucket_marks(self, pos):
-        if self.bucket_at.get(pos) and getattr(self, "_pend", None):
-            self._flush_wgrads()                                 # a bucket is final only behind the weight gradients that fill it
         for k in self.bucket_at.get(pos, ()):
             self._mark("bucket", k)
 
@@ -980,7 +976,6 @@ class TrainPlan:
                 op.bnr_by = None
         self.ring_i = 0
         self._split_j = 0                                        # layers issued by _conv_pair_backward_split in this pass
-        self._pend = []                                          # weight gradients of the split backward waiting for their batch
         nf = self.n_frame_ops
         if self.head is None:                                    # backbone alone: the feature gradients come from the caller
             for i, f in enumerate(self.fused):
@@ -1029,9 +1024,6 @@ class TrainPlan:
                         elif op.kind == "spp":
                             ops.spp_pool_bwd(G.view(op.v), op.argmax)
             self._bucket_marks(pos)
-        if self._pend:
-            self._chain = 0
-            self._flush_wgrads()
         if split:
             self._mark("cur", 0)
             self._mark("dep", (2, 0))
@@ -1074,16 +1066,10 @@ class TrainPlan:
         self._wg_flip = (self._wg_flip + 1) % len(WGRAD_STREAMS)
         return WGRAD_STREAMS[self._wg_flip]
 
-    def _on_side(self, fn, slot=None, chains=None, stream=None, defer=False):
+    def _on_side(self, fn, slot=None, chains=None, stream=None):
         """fn's launches (a weight gradient + fold) go to a weight-gradient stream, after everything issued so far on the
-        chain(s) that produced its raw gradient; the ring slot is marked free behind them.  defer (split backward): the launches
-        are queued and issued with the next batch (_flush_wgrads) behind one event per chain."""
+        chain(s) that produced its raw gradient; the ring slot is marked free behind them."""
         chains = (self._chain,) if chains is None else chains
-        if defer and WGRAD_DEFER > 1:
-            self._pend.append((fn, slot, chains, stream))
-            if len(self._pend) >= WGRAD_DEFER:
-                self._flush_wgrads()
-            return
         w = self._wgrad_stream(stream)
         for k in chains:
             self._mark("dep", (k, w))
@@ -1093,24 +1079,6 @@ class TrainPlan:
         self._wg_stream = 1
         if slot is not None:
             self._mark("slot_done", slot)
-        self._mark("cur", self._chain)
-
-    def _flush_wgrads(self):
-        """Issue the queued weight gradients: ONE event per producing chain, every weight-gradient stream of the batch waits for it."""
-        if not self._pend:
-            return
-        items = [(fn, slot, chains, self._wgrad_stream(stream)) for fn, slot, chains, stream in self._pend]
-        self._pend = []
-        ws = sorted({w for _, _, _, w in items})
-        for k in sorted({k for _, _, chains, _ in items for k in chains}):
-            self._mark("depn", (k, ws))
-        for fn, slot, _, w in items:
-            self._mark("cur", w)
-            self._wg_stream = w
-            fn()
-            if slot is not None:
-                self._mark("slot_done", slot)
-        self._wg_stream = 1
         self._mark("cur", self._chain)
 
     def _ws(self):
@@ -1246,7 +1214,7 @@ class TrainPlan:
             self._bn_bwd(op, op.yraw, G.view(op.y), (scale, shift, mean, invstd), gamma, op.bsum, dyr, dgamma, dbeta,
                          dres=dres, acc=acc, atomic=True)
         self._chain = 0
-        self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot, chains=(0, 2), defer=True)
+        self._on_side(lambda: self._wgrad(a, a.x.pair(), dy2), slot, chains=(0, 2))
         if a.need_dx:
             t = a.tile("dgrad")
             for k, (op, dyr) in enumerate(zip((a, b2), dys)):
