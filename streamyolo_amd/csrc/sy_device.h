@@ -26,6 +26,7 @@
 #define SY_LAUNCH_OK() 0
 #else
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #define SY_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #include "sy_tape.h"
 #include <tuple>
@@ -38,8 +39,13 @@
         const size_t sy_smem_ = (smem);                                                                              \
         auto sy_args_ = std::make_tuple(__VA_ARGS__);                                                                \
         auto sy_launch_fn_ = [=](void* sy_stream_) {                                                                 \
+            hipEvent_t const sy_stop_ = (hipEvent_t)sy_tape_stop_event_take();   /* a dependency follows this launch */ \
             std::apply([&](auto... sy_a_) {                                                                          \
-                hipLaunchKernelGGL(kernel, sy_grid_, sy_block_, sy_smem_, (hipStream_t)sy_stream_, sy_a_...);        \
+                if (sy_stop_ != nullptr)                                                                             \
+                    hipExtLaunchKernelGGL(kernel, sy_grid_, sy_block_, (std::uint32_t)sy_smem_, (hipStream_t)sy_stream_,  \
+                                          nullptr, sy_stop_, 0u, sy_a_...);                                          \
+                else                                                                                                 \
+                    hipLaunchKernelGGL(kernel, sy_grid_, sy_block_, sy_smem_, (hipStream_t)sy_stream_, sy_a_...);    \
             }, sy_args_);                                                                                            \
         };                                                                                                           \
         if (sy_tape_recording()) sy_tape_push(std::function<void(void*)>(sy_launch_fn_));                            \

@@ -13,3 +13,9 @@
 bool sy_tape_recording();
 // append one launch closure (called with the stream to launch on) to the open recording
 void sy_tape_push(std::function<void(void*)>&& fn);
+// Round 6: an event record on a frame chain is a marker packet its queue stops at (~3 us each, ~250 per l step: a replay with one
+// EXTRA record per dependency ran 0.36 ms longer, profiles/r06 stage A).  When the tape replay knows that a cross-stream dependency
+// follows a launch directly, it hands that launch the event instead (this thread's pending "stop event"): SY_LAUNCH then issues the
+// kernel through hipExtLaunchKernelGGL, whose stop event is the dispatch packet's own completion signal — no marker packet.
+// Returns the pending event (a hipEvent_t) and clears it; nullptr: a plain launch.
+void* sy_tape_stop_event_take();

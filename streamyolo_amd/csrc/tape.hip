@@ -22,6 +22,7 @@
 #include "sy_device.h"
 #include "../../include/streamyolo_hip.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -36,6 +37,11 @@ constexpr int kMaxSlots = 32, kMaxStreams = 8;
 struct Tape {
     std::vector<Entry> entries;
     int launches = 0;
+    // attach[i] >= 0 for a LAUNCH entry i: the index of the DEP entry that follows it on its stream with nothing in between — the
+    // launch carries that dependency's event as its stop event (sy_tape.h); folded[d] = the event index the launch was given in this
+    // pass (-1: the DEP records for itself)
+    std::vector<int> attach, folded;
+    void plan_attachments();
     // replay state (persists across the BREAK / BUCKET returns of one pass)
     int cur_k = 0;                       // index of the cursor stream (0 = main, 1 = side, ...)
     int ei = 0;                          // events used so far in this pass
@@ -69,8 +75,52 @@ struct Tape {
 };
 
 thread_local Tape* g_rec = nullptr;
+thread_local void* g_stop_event = nullptr;
+
+// Walk the recorded marks once: a DEP whose producing stream has issued a launch and NOTHING else since (no wait, no record, no
+// return to the host on that stream) can ride on that launch.  Anything else on the stream in between — a wait would make the
+// original record cover what the stream waited for — keeps the separate record.
+void Tape::plan_attachments() {
+    const int n = (int)entries.size();
+    attach.assign(n, -1);
+    folded.assign(n, -1);
+    int last[kMaxStreams];
+    for (int k = 0; k < kMaxStreams; ++k) last[k] = -1;
+    int cur = 0;
+    auto touch = [&](int k) { if (k >= 0 && k < kMaxStreams) last[k] = -1; };
+    for (int i = 0; i < n; ++i) {
+        const Entry& e = entries[i];
+        switch (e.kind) {
+            case SY_TAPE_LAUNCH: last[cur] = i; break;
+            case SY_TAPE_SIDE: touch(0); touch(1); cur = 1; break;
+            case SY_TAPE_FORK: touch(0); touch(1); break;
+            case SY_TAPE_SIDE_NW: cur = 1; break;
+            case SY_TAPE_MAIN: if (e.arg >= 0) touch(1); cur = 0; break;
+            case SY_TAPE_ACQUIRE: touch(0); break;
+            case SY_TAPE_JOIN: touch(0); touch(1); break;
+            case SY_TAPE_BREAK:
+            case SY_TAPE_BUCKET: for (int k = 0; k < kMaxStreams; ++k) last[k] = -1; break;
+            case SY_TAPE_CUR: cur = e.arg; break;
+            case SY_TAPE_DEP: {
+                const int f = e.arg >> 4, to = e.arg & 15;
+                if (f >= 0 && f < kMaxStreams && last[f] >= 0 && attach[last[f]] < 0) attach[last[f]] = i;
+                touch(f); touch(to);
+                break;
+            }
+            case SY_TAPE_SLOT_DONE: touch(cur); break;
+            case SY_TAPE_ACQUIRE_CUR: touch(cur); break;
+            default: break;
+        }
+    }
+}
 
 }  // namespace
+
+void* sy_tape_stop_event_take() {
+    void* const e = g_stop_event;
+    g_stop_event = nullptr;
+    return e;
+}
 
 bool sy_tape_recording() { return g_rec != nullptr; }
 
@@ -99,6 +149,7 @@ extern "C" int sy_tape_mark(int kind, int arg) {
 extern "C" void* sy_tape_end(void) {
     Tape* t = g_rec;
     g_rec = nullptr;
+    if (t != nullptr) t->plan_attachments();
     return t;
 }
 
@@ -131,10 +182,12 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
     const int n = (int)t->entries.size();
     int i = *pos;
     if (i < 0 || i > n) return SY_ERR_ARG;
+    if ((int)t->attach.size() != n) t->plan_attachments();
     if (i == 0) {
         t->cur_k = 0;
         t->ei = 0;
         t->waits = 0;
+        for (int& f : t->folded) f = -1;
         for (int s = 0; s < kMaxSlots; ++s) t->slot_clear(s);
     }
     void* const main_stream = streams[0];
@@ -162,11 +215,32 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
         (void)who; (void)ev;
 #endif
     };
+    static const bool use_stop_events = [] { const char* v = getenv("SY_TAPE_STOP_EVENTS"); return v == nullptr || atoi(v) != 0; }();   // "0": A/B timing
+    (void)use_stop_events;
     void* cur = stream_of(t->cur_k);
     for (; i < n && !failed; ++i) {
         Entry& e = t->entries[i];
         switch (e.kind) {
             case SY_TAPE_LAUNCH:
+#ifndef SY_EMU
+                if (two && use_stop_events && t->attach[i] >= 0) {          // the dependency behind this launch rides on it (no marker packet)
+                    const Entry& d = t->entries[t->attach[i]];
+                    void* const from = stream_of(d.arg >> 4);
+                    void* const to = stream_of(d.arg & 15);
+                    if (from == cur && from != to) {
+                        hipEvent_t ev = t->next_event();
+                        if (ev == nullptr) { failed = true; break; }
+                        g_stop_event = ev;
+                        e.fn(cur);
+                        if (g_stop_event != nullptr) {   // the closure did not take it: record the ordinary way
+                            g_stop_event = nullptr;
+                            if (hipEventRecord(ev, (hipStream_t)cur) != hipSuccess) failed = true;
+                        }
+                        t->folded[t->attach[i]] = t->ei - 1;
+                        break;
+                    }
+                }
+#endif
                 e.fn(cur);
                 break;
             case SY_TAPE_BREAK:
@@ -214,6 +288,11 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
                 void* const from = stream_of(e.arg >> 4);
                 void* const to = stream_of(e.arg & 15);
                 if (from == to) break;
+                if (t->folded[i] >= 0) {                 // the producing launch carried the event
+                    wait(to, t->folded[i]);
+                    t->folded[i] = -1;
+                    break;
+                }
                 wait(to, record(from));
                 break;
             }
