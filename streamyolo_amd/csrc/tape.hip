@@ -216,14 +216,21 @@ extern "C" int sy_tape_replay_n(void* tape, void* const* streams, int n_streams,
 #endif
     };
     static const bool use_stop_events = [] { const char* v = getenv("SY_TAPE_STOP_EVENTS"); return v == nullptr || atoi(v) != 0; }();   // "0": A/B timing
-    (void)use_stop_events;
+    bool stop_events_now = use_stop_events;
+#ifndef SY_EMU
+    {   // inside a hipGraph capture the events of the tape become graph edges: keep the plain record / wait form there
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)main_stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) stop_events_now = false;
+    }
+#endif
+    (void)stop_events_now;
     void* cur = stream_of(t->cur_k);
     for (; i < n && !failed; ++i) {
         Entry& e = t->entries[i];
         switch (e.kind) {
             case SY_TAPE_LAUNCH:
 #ifndef SY_EMU
-                if (two && use_stop_events && t->attach[i] >= 0) {          // the dependency behind this launch rides on it (no marker packet)
+                if (two && stop_events_now && t->attach[i] >= 0) {          // the dependency behind this launch rides on it (no marker packet)
                     const Entry& d = t->entries[t->attach[i]];
                     void* const from = stream_of(d.arg >> 4);
                     void* const to = stream_of(d.arg & 15);
