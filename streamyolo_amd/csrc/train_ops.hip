@@ -78,22 +78,32 @@ __global__ __launch_bounds__(kBlock) void spp_pool_kernel(typename T::elem* buf,
 // LDS layout: in[HW] chunks | rv[3][HW] chunks (row maxima) | ra[3][HW][kEPC] bytes (dw + 6 of the row maximum).
 // LSEL >= 0: only pooling level LSEL (5 + 4 LSEL wide) — the eval launch of a small batch runs the three levels as three
 // workgroups per channel chunk (gridDim.y = 3: 64 workgroups of 39 us -> 192 of ~15 at one streamed frame); same arithmetic.
+// Threads of a tile workgroup: one pass over its work items where that fits (19x30 at 600x960: 576 threads for the 570 pixels of the
+// forward passes, 1024 for the 1710 (level, row-stage element) items of the backward's phase A) — round 6: with 256 threads the
+// 512 workgroups of a training launch were 4 waves per CU (backward: 109 KB of LDS, one workgroup per CU) walking 3-7 dependent
+// passes, 66 / 149 us per launch on each frame chain's critical path.
+constexpr int kSppTileThreads = 1024;
+inline int spp_tile_threads(long long items) {
+    long long t = (items + 63) / 64 * 64;
+    return (int)(t < 256 ? 256 : (t > kSppTileThreads ? kSppTileThreads : t));
+}
+
 template <typename T, int LSEL>
 __device__ __forceinline__ void spp_pool_tile_body(typename T::elem* buf, int H, int W, int C, int ld, long long bs,
-                                                   unsigned char* argmax, unsigned char* smem) {
+                                                   unsigned char* argmax, unsigned char* smem, int bx) {
     typedef typename T::elem elem;
     constexpr int E = T::kEPC;
     constexpr int L0 = LSEL < 0 ? 0 : LSEL, L1 = LSEL < 0 ? 3 : LSEL + 1, RH = 2 * L1;
-    const int HW = H * W;
+    const int HW = H * W, nt = (int)blockDim.x;
     const int cpp = C / E;
-    const int cc = blockIdx.x % cpp, n = blockIdx.x / cpp;
+    const int cc = bx % cpp, n = bx / cpp;
     unsigned char* s_in = smem;
     unsigned char* s_rv = smem + (size_t)HW * 16;
     unsigned char* s_ra = s_rv + (size_t)3 * HW * 16;
     elem* base = buf + n * bs + cc * E;
-    for (int p = threadIdx.x; p < HW; p += kBlock) Chunk<T>::load(base + (long long)p * ld).store(s_in + (size_t)p * 16);
+    for (int p = threadIdx.x; p < HW; p += nt) Chunk<T>::load(base + (long long)p * ld).store(s_in + (size_t)p * 16);
     __syncthreads();
-    for (int p = threadIdx.x; p < HW; p += kBlock) {
+    for (int p = threadIdx.x; p < HW; p += nt) {
         const int w = p % W, row = p - w;
         float m[3][E];
         unsigned char a[3][E];
@@ -124,7 +134,7 @@ __device__ __forceinline__ void spp_pool_tile_body(typename T::elem* buf, int H,
         }
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < HW; p += kBlock) {
+    for (int p = threadIdx.x; p < HW; p += nt) {
         const int w = p % W, h = p / W;
         elem* dst = base + (long long)p * ld;
 #pragma unroll
@@ -158,14 +168,18 @@ __device__ __forceinline__ void spp_pool_tile_body(typename T::elem* buf, int H,
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void spp_pool_tile_kernel(typename T::elem* buf, int H, int W, int C, int ld,
+__global__ __launch_bounds__(kSppTileThreads) void spp_pool_tile_kernel(typename T::elem* buf, int H, int W, int C, int ld,
                                                                long long bs, unsigned char* argmax) {
     SY_TL_BEGIN(15);
     SY_DYN_SMEM(smem);
-    if (gridDim.y == 1) spp_pool_tile_body<T, -1>(buf, H, W, C, ld, bs, argmax, smem);
-    else if (blockIdx.y == 0) spp_pool_tile_body<T, 0>(buf, H, W, C, ld, bs, argmax, smem);
-    else if (blockIdx.y == 1) spp_pool_tile_body<T, 1>(buf, H, W, C, ld, bs, argmax, smem);
-    else spp_pool_tile_body<T, 2>(buf, H, W, C, ld, bs, argmax, smem);
+    // XCD-contiguous order: a workgroup touches 16 bytes of every pixel's channel row, the workgroups of the neighbouring channel
+    // chunks the rest of the same 128-byte lines — in hardware order they sit on eight different L2s and every XCD fetches every
+    // line (round 6)
+    const sy_block_id b = sy_xcd_block_id();
+    if (gridDim.y == 1) spp_pool_tile_body<T, -1>(buf, H, W, C, ld, bs, argmax, smem, b.x);
+    else if (b.y == 0) spp_pool_tile_body<T, 0>(buf, H, W, C, ld, bs, argmax, smem, b.x);
+    else if (b.y == 1) spp_pool_tile_body<T, 1>(buf, H, W, C, ld, bs, argmax, smem, b.x);
+    else spp_pool_tile_body<T, 2>(buf, H, W, C, ld, bs, argmax, smem, b.x);
     SY_TL_END();
 }
 
@@ -231,27 +245,28 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_kernel(typename T::elem* 
 // grouped by row, so fp32 partial sums may differ from spp_pool_bwd_kernel's in the last bit.
 // LDS layout: g[HW][3] chunks | am[HW][3][E] bytes | T[3][HW][E] fp32 | dw[3][HW][E] bytes (0xFF: no contribution).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::elem* dbuf, const unsigned char* argmax,
+__global__ __launch_bounds__(kSppTileThreads) void spp_pool_bwd_tile_kernel(typename T::elem* dbuf, const unsigned char* argmax,
                                                                    int H, int W, int C, int ld, long long bs) {
     SY_TL_BEGIN(15);
     typedef typename T::elem elem;
     constexpr int E = T::kEPC;
     SY_DYN_SMEM(smem);
-    const int HW = H * W;
+    const int HW = H * W, nt = (int)blockDim.x;
     const int cpp = C / E;
-    const int cc = blockIdx.x % cpp, n = blockIdx.x / cpp;
+    const int bx = sy_xcd_block_id().x;                             // XCD-contiguous order, as in the forward kernel
+    const int cc = bx % cpp, n = bx / cpp;
     unsigned char* s_g = smem;
     unsigned char* s_am = s_g + (size_t)HW * 3 * 16;
     float* s_T = reinterpret_cast<float*>(s_am + (size_t)HW * 3 * E);      // HW * 3 * (16 + E) is a multiple of 4
     unsigned char* s_dw = reinterpret_cast<unsigned char*>(s_T + (size_t)3 * HW * E);
     elem* base = dbuf + n * bs + cc * E;
-    for (int i = threadIdx.x; i < HW * 3; i += kBlock) {
+    for (int i = threadIdx.x; i < HW * 3; i += nt) {
         const int p = i / 3, l = i - 3 * p;
         Chunk<T>::load(base + (long long)p * ld + (l + 1) * C).store(s_g + (size_t)i * 16);
         __builtin_memcpy(s_am + (size_t)i * E, argmax + (((long long)n * HW + p) * 3 + l) * C + cc * E, E);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HW * 3; i += kBlock) {            // phase A: (level, row-stage element)
+    for (int i = threadIdx.x; i < HW * 3; i += nt) {            // phase A: (level, row-stage element)
         const int l = i / HW, p = i - l * HW;
         const int w = p % W, hr = p / W;
         const int r = 2 * (l + 1);
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void spp_pool_bwd_tile_kernel(typename T::e
         __builtin_memcpy(s_dw + (size_t)i * E, rec, E);
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < HW; p += kBlock) {                // phase B: source pixels
+    for (int p = threadIdx.x; p < HW; p += nt) {                // phase B: source pixels
         const int x = p % W, row = p - x;
         elem* gslot0 = base + (long long)p * ld;
         Chunk<T> g0 = Chunk<T>::load(gslot0);
@@ -808,7 +823,7 @@ extern "C" int sy_spp_pool(void* buf, int N, int H, int W, int C, int ld, int64_
     const size_t tile_lds = (size_t)H * W * (16 + 3 * 16 + 3 * e);      // in | row maxima | row arg-max bytes
     if (tile_lds <= kSppTileLds && !spp_force_scan()) {
         SY_DISPATCH_DTYPE(dtype, if (!spp_lds_ok((const void*)spp_pool_tile_kernel<T>, T::kCode)) return SY_ERR_LAUNCH;
-                          SY_LAUNCH((spp_pool_tile_kernel<T>), dim3(N * (C / e), N * (C / e) < 256 ? 3 : 1), dim3(kBlock), tile_lds, stream,
+                          SY_LAUNCH((spp_pool_tile_kernel<T>), dim3(N * (C / e), N * (C / e) < 256 ? 3 : 1), dim3(spp_tile_threads((long long)H * W)), tile_lds, stream,
                                     (typename T::elem*)buf, H, W, C, ld, (long long)bs, (unsigned char*)argmax));
     }
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((spp_pool_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream,
@@ -824,7 +839,7 @@ extern "C" int sy_spp_pool_bwd(void* dbuf, const void* argmax, int N, int H, int
     const size_t tile_lds = (size_t)H * W * 3 * (16 + e + 4 * e + e);    // pooled gradients | arg-max bytes | row sums | row dw
     if (tile_lds <= kSppTileLds && !spp_force_scan()) {
         SY_DISPATCH_DTYPE(dtype, if (!spp_lds_ok((const void*)spp_pool_bwd_tile_kernel<T>, 3 + T::kCode)) return SY_ERR_LAUNCH;
-                          SY_LAUNCH((spp_pool_bwd_tile_kernel<T>), dim3(N * (C / e)), dim3(kBlock), tile_lds, stream,
+                          SY_LAUNCH((spp_pool_bwd_tile_kernel<T>), dim3(N * (C / e)), dim3(spp_tile_threads(3LL * H * W)), tile_lds, stream,
                                     (typename T::elem*)dbuf, (const unsigned char*)argmax, H, W, C, ld, (long long)bs));
     }
     SY_DISPATCH_DTYPE(dtype, SY_LAUNCH((spp_pool_bwd_kernel<T>), dim3(grid_for(work)), dim3(kBlock), 0, stream,

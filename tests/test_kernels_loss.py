@@ -68,3 +68,32 @@ def test_tal_loss_empty_image_and_no_gt(backend):
     assert int(fg[1].sum()) == 0 and int(fg[0].sum()) == int(ref["_fg_mask"][0].sum())
     assert abs(float(losses[0]) - float(ref["total_loss"])) / abs(float(ref["total_loss"])) < 2e-5
     assert _rel(d_raw.cpu(), gref) < 2e-4
+
+
+def test_tal_loss_more_anchors_than_one_mask_pass_covers(backend):
+    """The matching / conflict kernels scan a thread's anchors 64 at a time (candidate flags as a bit mask, then the candidates): a
+    1536x2560 image (80640 anchors) takes five passes in tal_match_kernel (256 x 64 anchors each) and two in tal_resolve_kernel
+    (1024 x 64) — foreground mask and matched ground truths equal to the oracle's, loss and gradient as in the small cases."""
+    cfg = O.OracleConfig.named("nano")
+    hw = [(192, 320), (96, 160), (48, 80)]
+    A = sum(h * w for h, w in hw)
+    g = torch.Generator().manual_seed(3)
+    raw = torch.randn(1, A, 13, generator=g) * 0.5
+    lab = torch.zeros(1, 120, 5)
+    sup = torch.zeros(1, 120, 5)
+    n = 9
+    cx, cy = torch.rand(n, generator=g) * 2300 + 100, torch.rand(n, generator=g) * 1300 + 100
+    w, h = torch.rand(n, generator=g) * 300 + 40, torch.rand(n, generator=g) * 200 + 40
+    cls = torch.randint(0, 8, (n,), generator=g).float()
+    lab[0, :n] = torch.stack([cls, cx, cy, w, h], 1)
+    sup[0, :n] = torch.stack([cls, cx + 6, cy - 4, w * 1.05, h * 0.97], 1)
+    ws = ops.TalLossWorkspace(1, A, 13, hw, cfg.strides, backend)
+    losses, d_raw, fg = ops.tal_loss(raw.to(backend), lab, sup, 8, cfg.gamma, cfg.ignore_thr, cfg.ignore_value, True, ws)
+    ref, gref = _oracle_loss_and_grad(raw, hw, lab, sup, cfg)
+    fg_ref = ref["_fg_mask"][0].numpy().astype(bool)
+    assert fg_ref[256 * 64:].any() and fg_ref[1024 * 64:].any()          # later passes hold matches
+    assert np.array_equal(fg[0].cpu().numpy().astype(bool), fg_ref)
+    mg = ops.tal_assignment(ws)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(mg, ref["_matched_gt"].numpy().reshape(-1))
+    assert abs(float(losses[0]) - float(ref["total_loss"])) / abs(float(ref["total_loss"])) < 2e-5
+    assert _rel(d_raw.cpu(), gref) < 2e-4

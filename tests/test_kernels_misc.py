@@ -324,6 +324,26 @@ def test_pack_weights_matches_host_packing(backend, dt):
         e.packed, e.packed_t, e.frag, e.frag_t = [None if b is None else b.data_ptr() for b in bufs]
         e.co_n, e.ci_n, e.taps, e.r0, e.R, e.R_t, e.CI, e.dtype = co, ci, k * k, 0, co, co, CI, code
         rows.append(e); keep.append((wd, bufs)); want.append((p, pt, f, ft))
+    # a stacked pair (MergedConv: two modules' rows r0 = 0 / 64 of ONE set of layouts, R = R_t = 128) and a 3x3 whose rows start at
+    # r0 = 8: full 32 x 32 tiles off the fast path's row origin
+    for parts, ci, k in (((64, 64), 64, 3), ((8, 32), 32, 3)):
+        ws = [torch.randn(co, ci, k, k, generator=g) for co in parts]
+        wcat = torch.cat(ws, 0)
+        R = wcat.shape[0]
+        p = pack_conv_weight(wcat, code)
+        pt = pack_conv_weight(wcat, code, transpose=True)
+        f = pack_conv_weight_frag(p, k)
+        ft = pack_conv_weight_frag(pt, k) if R % 32 == 0 else None
+        bufs = [torch.zeros(t.numel(), dtype=tdt, device=backend) if t is not None else None for t in (p, pt, f, ft)]
+        r0 = 0
+        for w in ws:
+            wd = w.to(backend)
+            e = _lib.PackEntry()
+            e.w = wd.data_ptr()
+            e.packed, e.packed_t, e.frag, e.frag_t = [None if b is None else b.data_ptr() for b in bufs]
+            e.co_n, e.ci_n, e.taps, e.r0, e.R, e.R_t, e.CI, e.dtype = w.shape[0], ci, k * k, r0, R, R, ci, code
+            rows.append(e); keep.append((wd, bufs if r0 == 0 else [None] * 4)); want.append((p, pt, f, ft) if r0 == 0 else (None,) * 4)
+            r0 += w.shape[0]
     arr, total = _lib.pack_table(rows)
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(backend)
     ops.check(_lib.lib().sy_pack_weights(table.data_ptr(), len(rows), total, ops.stream_of(table)), "sy_pack_weights")
