@@ -1,0 +1,89 @@
+// What does a DEPENDENT launch cost on an in-order HIP stream of the MI355X (development aid, round 6)?
+//   A  N kernels back to back on one stream (barrier bit: kernel i + 1 starts after kernel i has ended): gap = first workgroup entry of
+//      i + 1 minus last workgroup exit of i, by the 100 MHz device clock;
+//   B  the same kernels issued with hipExtAnyOrderLaunch (no barrier bit) and the dependency carried in the kernels: every workgroup of
+//      launch i bumps done[i] when it leaves (agent-scope release), every workgroup of launch i + 1 waits at its entry until done[i] has
+//      reached the grid size (acquire; bounded by a 2 ms timeout, so the probe cannot hang): gap = first workgroup PAST its wait minus
+//      last exit of i — the consumer's workgroups are resident (and would have their prologue behind them) when the producer ends.
+// hipcc --offload-arch=gfx950 -O3 tools/probes/chain_gap_probe.hip -o /tmp/chain_gap_probe && /tmp/chain_gap_probe
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+__global__ __launch_bounds__(256) void link_kernel(unsigned long long* stamps, unsigned* done, int i, int grid, int spin_ticks, int wait_on_prev,
+                                                   unsigned* timeouts) {
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+    if (wait_on_prev && i > 0) {
+        if (threadIdx.x == 0) {
+            while (__hip_atomic_load(&done[i - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)grid) {
+                if (__builtin_amdgcn_s_memrealtime() - t_in > 200000ull) { atomicAdd(timeouts, 1u); break; }   // 2 ms
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned long long t_go = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t_go < (unsigned long long)spin_ticks) __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* s = stamps + ((long long)i * grid + blockIdx.x) * 3;
+        s[0] = t_in; s[1] = t_go; s[2] = __builtin_amdgcn_s_memrealtime();
+        if (wait_on_prev) __hip_atomic_fetch_add(&done[i], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (an agent-scope release per
+                                                                                      // workgroup: ~18 ns each, serialised — see README)
+    }
+}
+
+static void run(const char* name, int N, int grid, int spin_ticks, bool any_order, unsigned long long* d_st, unsigned* d_done, unsigned* d_to) {
+    hipStream_t st;
+    hipStreamCreate(&st);
+    std::vector<unsigned long long> h((size_t)N * grid * 3);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipMemsetAsync(d_done, 0, sizeof(unsigned) * N, st);
+        hipMemsetAsync(d_to, 0, sizeof(unsigned), st);
+        for (int i = 0; i < N; ++i) {
+            if (any_order)
+                hipExtLaunchKernelGGL(link_kernel, dim3(grid), dim3(256), 0, st, nullptr, nullptr, (i > 0 ? hipExtAnyOrderLaunch : 0), d_st, d_done, i, grid,
+                                      spin_ticks, 1, d_to);
+            else
+                hipLaunchKernelGGL(link_kernel, dim3(grid), dim3(256), 0, st, d_st, d_done, i, grid, spin_ticks, 0, d_to);
+        }
+        hipStreamSynchronize(st);
+    }
+    unsigned to = 0;
+    hipMemcpy(&to, d_to, sizeof(to), hipMemcpyDeviceToHost);
+    hipMemcpy(h.data(), d_st, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+    std::vector<double> gap, early;
+    for (int i = 1; i < N; ++i) {
+        unsigned long long last_exit = 0, first_go = ~0ull, first_in = ~0ull;
+        for (int b = 0; b < grid; ++b) {
+            last_exit = std::max(last_exit, h[((size_t)(i - 1) * grid + b) * 3 + 2]);
+            first_go = std::min(first_go, h[((size_t)i * grid + b) * 3 + 1]);
+            first_in = std::min(first_in, h[((size_t)i * grid + b) * 3 + 0]);
+        }
+        gap.push_back(((double)first_go - (double)last_exit) / 100.0);
+        early.push_back(((double)last_exit - (double)first_in) / 100.0);
+    }
+    std::sort(gap.begin(), gap.end());
+    std::sort(early.begin(), early.end());
+    const double total = ((double)h[((size_t)(N - 1) * grid) * 3 + 2] - (double)h[0]) / 100.0;
+    printf("%-44s grid %5d  body %5.1f us: gap p10 %6.2f  p50 %6.2f  p90 %6.2f us | entry before producer's end p50 %6.2f us | %d launches in %8.1f us = %6.2f us each | timeouts %u\n",
+           name, grid, spin_ticks / 100.0, gap[gap.size() / 10], gap[gap.size() / 2], gap[gap.size() * 9 / 10], early[early.size() / 2], N, total, total / N, to);
+    hipStreamDestroy(st);
+}
+
+int main() {
+    const int N = 200, GMAX = 2048;
+    unsigned long long* d_st;
+    unsigned *d_done, *d_to;
+    hipMalloc(&d_st, sizeof(unsigned long long) * (size_t)N * GMAX * 3);
+    hipMalloc(&d_done, sizeof(unsigned) * N);
+    hipMalloc(&d_to, sizeof(unsigned));
+    for (int grid : {64, 256, 512, 1024, 2048})
+        for (int spin : {500, 2000}) {
+            run("A  in-order stream (barrier bit)", N, grid, spin, false, d_st, d_done, d_to);
+            run("B  any-order launch + in-kernel wait", N, grid, spin, true, d_st, d_done, d_to);
+        }
+    return 0;
+}
