@@ -12,8 +12,10 @@
 #include <cstdio>
 #include <vector>
 
+//   C  as A, but every workgroup also WRITES (and, in the next launch, reads) `wr_bytes` of a buffer: what the end-of-kernel write-back of
+//      dirty L2 lines (eight non-coherent L2s) and the next kernel's cold reads add to the boundary.
 __global__ __launch_bounds__(256) void link_kernel(unsigned long long* stamps, unsigned* done, int i, int grid, int spin_ticks, int wait_on_prev,
-                                                   unsigned* timeouts) {
+                                                   unsigned* timeouts, uint4* data, int wr_bytes, int nt) {
     const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
     if (wait_on_prev && i > 0) {
         if (threadIdx.x == 0) {
@@ -25,6 +27,19 @@ __global__ __launch_bounds__(256) void link_kernel(unsigned long long* stamps, u
         __syncthreads();
     }
     const unsigned long long t_go = __builtin_amdgcn_s_memrealtime();
+    if (wr_bytes > 0) {
+        typedef unsigned v4 __attribute__((ext_vector_type(4)));
+        v4* mine = reinterpret_cast<v4*>(data) + (size_t)blockIdx.x * (wr_bytes / 16);
+        v4 acc = {0u, 0u, 0u, 0u};
+        for (int k = threadIdx.x; k < wr_bytes / 16; k += 256) {
+            const v4 v = mine[k];                                        // what the previous launch wrote
+            acc += v;
+        }
+        for (int k = threadIdx.x; k < wr_bytes / 16; k += 256) {
+            v4 o = acc; o.x += (unsigned)k;
+            if (nt) __builtin_nontemporal_store(o, &mine[k]); else mine[k] = o;
+        }
+    }
     while (__builtin_amdgcn_s_memrealtime() - t_go < (unsigned long long)spin_ticks) __builtin_amdgcn_s_sleep(2);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -35,7 +50,8 @@ __global__ __launch_bounds__(256) void link_kernel(unsigned long long* stamps, u
     }
 }
 
-static void run(const char* name, int N, int grid, int spin_ticks, bool any_order, unsigned long long* d_st, unsigned* d_done, unsigned* d_to) {
+static void run(const char* name, int N, int grid, int spin_ticks, bool any_order, unsigned long long* d_st, unsigned* d_done, unsigned* d_to,
+                uint4* d_data = nullptr, int wr_bytes = 0, int nt = 0) {
     hipStream_t st;
     hipStreamCreate(&st);
     std::vector<unsigned long long> h((size_t)N * grid * 3);
@@ -45,9 +61,9 @@ static void run(const char* name, int N, int grid, int spin_ticks, bool any_orde
         for (int i = 0; i < N; ++i) {
             if (any_order)
                 hipExtLaunchKernelGGL(link_kernel, dim3(grid), dim3(256), 0, st, nullptr, nullptr, (i > 0 ? hipExtAnyOrderLaunch : 0), d_st, d_done, i, grid,
-                                      spin_ticks, 1, d_to);
+                                      spin_ticks, 1, d_to, (uint4*)nullptr, 0, 0);
             else
-                hipLaunchKernelGGL(link_kernel, dim3(grid), dim3(256), 0, st, d_st, d_done, i, grid, spin_ticks, 0, d_to);
+                hipLaunchKernelGGL(link_kernel, dim3(grid), dim3(256), 0, st, d_st, d_done, i, grid, spin_ticks, 0, d_to, d_data, wr_bytes, nt);
         }
         hipStreamSynchronize(st);
     }
@@ -68,6 +84,7 @@ static void run(const char* name, int N, int grid, int spin_ticks, bool any_orde
     std::sort(gap.begin(), gap.end());
     std::sort(early.begin(), early.end());
     const double total = ((double)h[((size_t)(N - 1) * grid) * 3 + 2] - (double)h[0]) / 100.0;
+    if (wr_bytes > 0) printf("   [%5.1f MB written + read per launch%s] ", (double)grid * wr_bytes / 1e6, nt ? ", nontemporal stores" : "");
     printf("%-44s grid %5d  body %5.1f us: gap p10 %6.2f  p50 %6.2f  p90 %6.2f us | entry before producer's end p50 %6.2f us | %d launches in %8.1f us = %6.2f us each | timeouts %u\n",
            name, grid, spin_ticks / 100.0, gap[gap.size() / 10], gap[gap.size() / 2], gap[gap.size() * 9 / 10], early[early.size() / 2], N, total, total / N, to);
     hipStreamDestroy(st);
@@ -85,5 +102,14 @@ int main() {
             run("A  in-order stream (barrier bit)", N, grid, spin, false, d_st, d_done, d_to);
             run("B  any-order launch + in-kernel wait", N, grid, spin, true, d_st, d_done, d_to);
         }
+    uint4* d_data;
+    hipMalloc(&d_data, (size_t)64 << 20);
+    hipMemset(d_data, 0, (size_t)64 << 20);
+    for (int grid : {256, 1024})
+        for (int wr : {4096, 16384, 65536})
+            for (int nt : {0, 1}) {
+                if ((size_t)grid * wr > ((size_t)64 << 20)) continue;
+                run("C  in-order stream, writes + reads", N, grid, 500, false, d_st, d_done, d_to, d_data, wr, nt);
+            }
     return 0;
 }
