@@ -7,6 +7,8 @@ int sy_conv_launch_bf16(const ConvArgs& a, void* stream);
 int sy_conv_launch_f16(const ConvArgs& a, void* stream);
 int sy_conv_launch_f32(const ConvArgs& a, void* stream);
 
+constexpr long long kWtMinBytes = 8ll << 20;   // outputs of 8 MB or more are written through (measured: stages W, X of profiles/r06)
+
 extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
     if (d == nullptr || d->x == nullptr || d->w == nullptr || d->y == nullptr) return SY_ERR_ARG;
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return SY_ERR_ARG;
@@ -61,6 +63,14 @@ extern "C" int sy_conv2d(const sy_conv_desc* d, void* stream) {
             d->scale != nullptr || d->shift != nullptr || d->res != nullptr || d->stat_sum != nullptr || d->accumulate || d->k_splits > 16)
             return SY_ERR_UNSUPPORTED;
         a.ksplit = d->k_splits;
+    }
+    {   // Write-through output stores (sy_device.h, sy_store16_wt) for outputs the L2s would not keep anyway: the kernel boundary behind
+        // a launch that leaves tens of MB of dirty lines costs 2.6-3.2 us instead of 1.2 (profiles/r06 stages N, R-X: l step -0.17 ms,
+        // s inference at 8 pairs -3 %).  Small outputs (the batch-1 streaming frame: 1.55 vs 1.52 ms when everything is written
+        // through) stay in the L2 for their consumer.  SY_WT_MIN_BYTES overrides the threshold (A/B).
+        static const long long wt_min = [] { const char* e = std::getenv("SY_WT_MIN_BYTES"); return e ? std::atoll(e) : (long long)kWtMinBytes; }();
+        const long long out_bytes = (long long)d->N * d->Ho * d->Wo * d->Cout * (d->y_f32 ? 4 : (d->dtype == SY_DT_F32 ? 4 : 2));
+        a.wt = out_bytes >= wt_min ? 1 : 0;
     }
     a.tile = d->tile & 0xff;
     a.ablate = (d->tile >> 8) & 1023;    // profiling / tests: 1 no pixel loads, 2 no weight loads, 4 no stride-2 parity classes, 8 / 16 statistics, 32.. see ConvArgs

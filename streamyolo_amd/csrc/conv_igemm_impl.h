@@ -65,6 +65,7 @@ struct ConvArgs {
     const float* pre_shift;
     int pre_cin;                // ... and its input channels (x has pre_cin channels then, Cin = the hidden width)
     int ksplit;                 // > 1: split-K over channel-slab ranges (conv3x3_halo2_kernel), gridDim.z splits, fp32 partial outputs
+    int wt;                     // write the output through the L2 (sy_store16_wt): set by sy_conv2d for outputs of SY_WT_MIN_BYTES or more
     int ablate;                 // profiling only (tools/conv_probe.py): 1 = no pixel loads, 2 = no weight loads, 8 = no statistics atomics, 16 = no cross-lane statistics reduction
 };
 
@@ -917,7 +918,10 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
             for (int k = 0; k < UB; ++k) {
                 const int i = tid + (b0 + k) * kThreads;
                 const int ck = i % CPR;
-                if (off[k] >= 0) *reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + off[k] + c0 + ck * 8) = v[k];
+                if (off[k] >= 0) {
+                    if (SY_WT_CONV && p.wt) sy_store16_wt(reinterpret_cast<elem*>(p.y) + off[k] + c0 + ck * 8, v[k]);
+                    else *reinterpret_cast<uint4*>(reinterpret_cast<elem*>(p.y) + off[k] + c0 + ck * 8) = v[k];
+                }
             }
         }
     } else if (kCanStage && stage_out) {
@@ -940,7 +944,7 @@ __device__ __forceinline__ void conv_epilogue(const Args& p, const Map& mp, int 
                     w[j] = T::pack2(T::to_f32(ev[2 * j]) + T::to_f32(eo[2 * j]), T::to_f32(ev[2 * j + 1]) + T::to_f32(eo[2 * j + 1]));
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            *dst = v;
+            if (SY_WT_CONV && p.wt) sy_store16_wt(dst, v); else *dst = v;
         }
     }
     sy_probe(5);

@@ -60,9 +60,20 @@ __device__ __forceinline__ void wgrad_store_slab(const WgradArgs& p, int split, 
         uint2 u;
         u.x = BF16::pack2(v0, v1);
         u.y = BF16::pack2(v2, v3);
+#if SY_WT_SLAB
+        sy_store8_wt(reinterpret_cast<uint2*>(p.part) + g, u);
+#else
         reinterpret_cast<uint2*>(p.part)[g] = u;
+#endif
     } else {
-        reinterpret_cast<float4*>(p.part)[g] = make_float4(v0, v1, v2, v3);
+        const float4 f = make_float4(v0, v1, v2, v3);
+        uint4 q;
+        __builtin_memcpy(&q, &f, 16);
+#if SY_WT_SLAB
+        sy_store16_wt(reinterpret_cast<float4*>(p.part) + g, q);
+#else
+        reinterpret_cast<float4*>(p.part)[g] = f;
+#endif
     }
 }
 
@@ -775,7 +786,14 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* part, floa
                 const int tap = k / Cin, ci = k - tap * Cin;
                 o = (long long)co * K + (long long)ci * taps + tap;
             }
-            dw[o] += v;
+            const float nv = dw[o] + v;
+            unsigned nb;
+            __builtin_memcpy(&nb, &nv, 4);
+#if SY_WT_FOLD
+            sy_store4_wt(dw + o, nb);
+#else
+            dw[o] = nv;
+#endif
         }
     }
     SY_TL_END();

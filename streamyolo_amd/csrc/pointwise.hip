@@ -143,7 +143,9 @@ __global__ __launch_bounds__(kBlock) void zero_rows_kernel(V* p, long long rows,
     V z;
     __builtin_memset(&z, 0, sizeof(V));
     if (row_v == pitch_v) {
-        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) p[i] = z;
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+            if constexpr (sizeof(V) == 16 && SY_WT_ZERO) sy_store16_wt(p + i, *reinterpret_cast<const uint4*>(&z)); else p[i] = z;
+        }
     } else {
         for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
             const long long r = i / row_v;

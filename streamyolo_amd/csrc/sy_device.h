@@ -408,6 +408,60 @@ __device__ __forceinline__ unsigned long long sy_readlane64(unsigned long long v
 }
 #endif
 
+// ---- write-through 16-byte global store ---------------------------------------------------------------------------------------------
+// A kernel boundary on an in-order stream costs 1.2-1.3 us — unless the finished kernel leaves dirty lines in the eight (mutually
+// non-coherent) L2s: then the end-of-kernel release writes them back first, 2.6-3.2 us from ~17 MB written (tools/probes/
+// chain_gap_probe.hip, profiles/r06 stage N).  Every launch of the training step writes 10-150 MB.  `sc1` makes the store write
+// through to the memory side while the kernel is still running (same kernel time in the probe), so nothing is left for the boundary.
+// -DSY_WT_STORES=0 builds the plain-store library for A/B.
+#ifndef SY_WT_STORES
+#define SY_WT_STORES 1
+#endif
+// per-site switches (A/B builds): convolution epilogue, BatchNorm forward apply, BatchNorm backward apply, weight-gradient slabs,
+// the fold's read-modify-write of dW, the arena clears
+#ifndef SY_WT_CONV
+#define SY_WT_CONV 1
+#endif
+#ifndef SY_WT_BNF
+#define SY_WT_BNF 1
+#endif
+#ifndef SY_WT_BNB
+#define SY_WT_BNB 1
+#endif
+#ifndef SY_WT_SLAB
+#define SY_WT_SLAB 0
+#endif
+#ifndef SY_WT_FOLD
+#define SY_WT_FOLD 0
+#endif
+#ifndef SY_WT_ZERO
+#define SY_WT_ZERO 0
+#endif
+#if defined(SY_EMU) || !SY_WT_STORES
+static inline __host__ __device__ void sy_store16_wt(void* dst, const uint4& v) { *reinterpret_cast<uint4*>(dst) = v; }
+static inline __host__ __device__ void sy_store8_wt(void* dst, const uint2& v) { *reinterpret_cast<uint2*>(dst) = v; }
+static inline __host__ __device__ void sy_store4_wt(void* dst, unsigned v) { *reinterpret_cast<unsigned*>(dst) = v; }
+#else
+__device__ __forceinline__ void sy_store8_wt(void* dst, const uint2& v) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    v2u d;
+    __builtin_memcpy(&d, &v, 8);
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(dst), "v"(d) : "memory");
+}
+__device__ __forceinline__ void sy_store4_wt(void* dst, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void sy_store16_wt(void* dst, const uint4& v) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u d;
+    __builtin_memcpy(&d, &v, 16);
+    // s_nop: a store of more than 8 bytes reads its data registers over several cycles, a VALU write to them in the next cycle is a
+    // hazard (gfx90a / gfx940 "VMEM store data" hazard, one wait state) — the compiler inserts the wait state for its own stores,
+    // not behind inline assembly (found the hard way: every fourth 64-byte piece of a BatchNorm output held integers)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(d) : "memory");
+}
+#endif
+
 #ifdef SY_EMU
 static inline unsigned long long sy_uniform64(unsigned long long v) { return v; }
 #else

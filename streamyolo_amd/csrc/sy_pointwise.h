@@ -30,6 +30,11 @@ template <typename T> struct Chunk {
         __builtin_memcpy(&v, e, 16);
         *reinterpret_cast<uint4*>(p) = v;
     }
+    __device__ __forceinline__ void store_wt(void* p) const {      // GLOBAL destinations only: write-through (sy_store16_wt)
+        uint4 v;
+        __builtin_memcpy(&v, e, 16);
+        sy_store16_wt(p, v);
+    }
 };
 
 inline int epc_of(int dtype) { return dtype == SY_DT_F32 ? 4 : 8; }

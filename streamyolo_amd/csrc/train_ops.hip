@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_apply_kernel(const typename T:
         for (int j = 0; j < T::kEPC; ++j) r[j] = res != nullptr ? T::to_f32(rv.e[j]) : 0.0f;
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
-        o.store(out + pix * ldo + c0);
+        if constexpr (SY_WT_BNF) o.store_wt(out + pix * ldo + c0); else o.store(out + pix * ldo + c0);
     }
     SY_TL_END();
 }
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_apply_kernel(const float* 
         for (int j = 0; j < T::kEPC; ++j) r[j] = res != nullptr ? T::to_f32(rv.e[j]) : 0.0f;
 #pragma unroll
         for (int j = 0; j < T::kEPC; ++j) o.e[j] = T::from_f32(sy_silu(T::to_f32(v.e[j]) * sc[j] + sh[j]) + r[j]);
-        o.store(out + pix * ldo + c0);
+        if constexpr (SY_WT_BNF) o.store_wt(out + pix * ldo + c0); else o.store(out + pix * ldo + c0);
         v = vn; rv = rn;
     }
     SY_TL_END();
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
             const float dz = T::to_f32(gv.e[j]) * sy_silu_grad(yy * sc[j] + sh[j]);
             o.e[j] = T::from_f32(gi[j] * (dz - m0[j] - (yy - mu[j]) * is[j] * m1[j]));
         }
-        o.store(dy + pix * lddy + c0);
+        if constexpr (SY_WT_BNB) o.store_wt(dy + pix * lddy + c0); else o.store(dy + pix * lddy + c0);
         if (dres != nullptr) {          // y = silu(bn(conv)) + res: the residual branch receives da unchanged (view_copy fused)
             typename T::elem* dst = dres + pix * lddres + c0;
             if (dres_acc & 1) {
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(kBlock) void bn_silu_bwd_apply_kernel(const typenam
 #pragma unroll
                 for (int j = 0; j < T::kEPC; ++j) gv.e[j] = T::from_f32(T::to_f32(gv.e[j]) + T::to_f32(r.e[j]));
             }
-            gv.store(dst);
+            if constexpr (SY_WT_BNB) gv.store_wt(dst); else gv.store(dst);
         }
     }
     SY_TL_END();

@@ -37,7 +37,11 @@ __global__ __launch_bounds__(256) void link_kernel(unsigned long long* stamps, u
         }
         for (int k = threadIdx.x; k < wr_bytes / 16; k += 256) {
             v4 o = acc; o.x += (unsigned)k;
-            if (nt) __builtin_nontemporal_store(o, &mine[k]); else mine[k] = o;
+            if (nt == 1) __builtin_nontemporal_store(o, &mine[k]);
+            else if (nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(&mine[k]), "v"(o) : "memory");   // write-through, system scope
+            else if (nt == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(&mine[k]), "v"(o) : "memory");
+            else if (nt == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(&mine[k]), "v"(o) : "memory");
+            else mine[k] = o;
         }
     }
     while (__builtin_amdgcn_s_memrealtime() - t_go < (unsigned long long)spin_ticks) __builtin_amdgcn_s_sleep(2);
@@ -48,6 +52,46 @@ __global__ __launch_bounds__(256) void link_kernel(unsigned long long* stamps, u
         if (wait_on_prev) __hip_atomic_fetch_add(&done[i], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (an agent-scope release per
                                                                                       // workgroup: ~18 ns each, serialised — see README)
     }
+}
+
+//   D  is a write-through store a legal replacement?  Writer launch i stores the value i into every word of a buffer (store variant
+//      `mode`, optionally s_waitcnt vmcnt(0) before the wave ends), reader launch i (next on the stream, in order) has every workgroup
+//      check ANOTHER workgroup's region (another XCD: blockIdx + 3) and counts the words that are not i.  The reader's L2 holds the
+//      lines of launch i - 1.
+typedef unsigned v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void wr_kernel(v4* data, int words16_per_wg, unsigned val, int mode, int drain) {
+    v4* mine = data + (size_t)blockIdx.x * words16_per_wg;
+    const v4 o = {val, val, val, val};
+    for (int k = threadIdx.x; k < words16_per_wg; k += 256) {
+        if (mode == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(&mine[k]), "v"(o) : "memory");
+        else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(&mine[k]), "v"(o) : "memory");
+        else mine[k] = o;
+    }
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__global__ __launch_bounds__(256) void rd_kernel(const v4* data, int words16_per_wg, unsigned val, unsigned* bad) {
+    const v4* theirs = data + (size_t)((blockIdx.x + 3) % gridDim.x) * words16_per_wg;
+    unsigned n = 0;
+    for (int k = threadIdx.x; k < words16_per_wg; k += 256) {
+        const v4 v = theirs[k];
+        n += (v.x != val) + (v.y != val) + (v.z != val) + (v.w != val);
+    }
+    if (n) atomicAdd(bad, n);
+}
+static void coherence(const char* name, int grid, int bytes_per_wg, int mode, int drain, uint4* d_data, unsigned* d_bad) {
+    hipStream_t st;
+    hipStreamCreate(&st);
+    hipMemsetAsync(d_bad, 0, sizeof(unsigned), st);
+    const int N = 300;
+    for (int i = 1; i <= N; ++i) {
+        hipLaunchKernelGGL(wr_kernel, dim3(grid), dim3(256), 0, st, (v4*)d_data, bytes_per_wg / 16, (unsigned)i, mode, drain);
+        hipLaunchKernelGGL(rd_kernel, dim3(grid), dim3(256), 0, st, (const v4*)d_data, bytes_per_wg / 16, (unsigned)i, d_bad);
+    }
+    hipStreamSynchronize(st);
+    unsigned bad = 0;
+    hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    printf("D  %-52s grid %5d x %6d B: %u stale words in %d write -> read rounds\n", name, grid, bytes_per_wg, bad, N);
+    hipStreamDestroy(st);
 }
 
 static void run(const char* name, int N, int grid, int spin_ticks, bool any_order, unsigned long long* d_st, unsigned* d_done, unsigned* d_to,
@@ -84,7 +128,7 @@ static void run(const char* name, int N, int grid, int spin_ticks, bool any_orde
     std::sort(gap.begin(), gap.end());
     std::sort(early.begin(), early.end());
     const double total = ((double)h[((size_t)(N - 1) * grid) * 3 + 2] - (double)h[0]) / 100.0;
-    if (wr_bytes > 0) printf("   [%5.1f MB written + read per launch%s] ", (double)grid * wr_bytes / 1e6, nt ? ", nontemporal stores" : "");
+    if (wr_bytes > 0) printf("   [%5.1f MB written + read per launch%s] ", (double)grid * wr_bytes / 1e6, nt == 1 ? ", nontemporal stores" : nt == 2 ? ", stores sc0 sc1" : nt == 3 ? ", stores sc1" : nt == 4 ? ", stores sc0 sc1 nt" : "");
     printf("%-44s grid %5d  body %5.1f us: gap p10 %6.2f  p50 %6.2f  p90 %6.2f us | entry before producer's end p50 %6.2f us | %d launches in %8.1f us = %6.2f us each | timeouts %u\n",
            name, grid, spin_ticks / 100.0, gap[gap.size() / 10], gap[gap.size() / 2], gap[gap.size() * 9 / 10], early[early.size() / 2], N, total, total / N, to);
     hipStreamDestroy(st);
@@ -107,9 +151,18 @@ int main() {
     hipMemset(d_data, 0, (size_t)64 << 20);
     for (int grid : {256, 1024})
         for (int wr : {4096, 16384, 65536})
-            for (int nt : {0, 1}) {
+            for (int nt : {0, 1, 2, 3, 4}) {
                 if ((size_t)grid * wr > ((size_t)64 << 20)) continue;
                 run("C  in-order stream, writes + reads", N, grid, 500, false, d_st, d_done, d_to, d_data, wr, nt);
             }
+    for (int grid : {8, 64, 1024})
+        for (int bpw : {256, 4096, 65536}) {
+            if ((size_t)grid * bpw > ((size_t)64 << 20)) continue;
+            coherence("plain stores", grid, bpw, 0, 0, d_data, d_to);
+            coherence("sc1 stores", grid, bpw, 1, 0, d_data, d_to);
+            coherence("sc1 stores + s_waitcnt vmcnt(0) at the wave's end", grid, bpw, 1, 1, d_data, d_to);
+            coherence("sc0 sc1 stores", grid, bpw, 2, 0, d_data, d_to);
+            coherence("sc0 sc1 stores + s_waitcnt vmcnt(0)", grid, bpw, 2, 1, d_data, d_to);
+        }
     return 0;
 }
